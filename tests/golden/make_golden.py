@@ -1,0 +1,295 @@
+"""Generate the golden fixtures tests/golden/*.npz from the REFERENCE itself.
+
+Run in the build container only (it imports /root/reference read-only through
+_ref_import.py):
+
+    python tests/golden/make_golden.py
+
+Fixtures are data only: inputs and the reference's outputs.  Network weights
+come from oracle.plnerf_oracle.closed_form_state_dict (an RNG-free recipe), so
+they are not stored.  Fixture ids follow SURVEY.md section 8c (G1..G7).
+"""
+import os
+import sys
+import tempfile
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+from _ref_import import import_reference  # noqa: E402
+from oracle import plnerf_oracle as orc  # noqa: E402
+
+R_, H_ = import_reference()
+torch.set_num_threads(8)
+
+
+def npz(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path} ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+def make_args(N_samples, N_importance, mode, white_bkgd=True, dataset="blender", raw_noise_std=0.0):
+    d = tempfile.mkdtemp()
+    os.makedirs(os.path.join(d, "exp"))
+    return Namespace(multires=10, i_embed=0, use_viewdirs=True, multires_views=4,
+                     N_importance=N_importance, N_samples=N_samples, netdepth=8, netwidth=256,
+                     netdepth_fine=8, netwidth_fine=256, netchunk=65536, lrate=5e-4,
+                     coarse_lrate=5e-4, ft_path=None, ckpt_dir=d, expname="exp", no_reload=True,
+                     perturb=1.0, white_bkgd=white_bkgd, raw_noise_std=raw_noise_std, mode=mode,
+                     color_mode="midpoint", dataset=dataset, no_ndc=False, lindisp=False)
+
+
+def ref_nets(args, seed_c=0, seed_f=1, sharpen=True):
+    kw_train, kw_test, start, grad_vars, opt, opt_c = R_.create_nerf(args)
+    kw_train["network_fn"].load_state_dict(orc.closed_form_state_dict(seed_c, sharpen))
+    kw_train["network_fine"].load_state_dict(orc.closed_form_state_dict(seed_f, sharpen))
+    return kw_train, kw_test, opt, opt_c
+
+
+def scene_rays(n, seed, near=2.0, far=6.0):
+    batch, target = orc.synthetic_blender_rays(n, seed=seed, near=near, far=far)
+    return batch, target
+
+
+# ---------------------------------------------------------------- G1: PE + MLP
+def g1():
+    g = torch.Generator().manual_seed(11)
+    R, S = 6, 40
+    pts = (torch.rand(R, S, 3, generator=g) * 2 - 1) * 3.0
+    vd = torch.randn(R, 3, generator=g)
+    vd = vd / vd.norm(dim=-1, keepdim=True)
+    args = make_args(64, 128, "linear")
+    out = {}
+    for tag, sharpen in (("plain", False), ("sharp", True)):
+        kw, _, _, _ = ref_nets(args, 0, 1, sharpen)
+        with torch.no_grad():
+            raw = kw["network_query_fn"](pts, vd, kw["network_fn"])
+            emb = torch.cat([H_.get_embedder(10, 0)[0](pts.reshape(-1, 3)),
+                             H_.get_embedder(4, 0)[0](vd[:, None].expand(R, S, 3).reshape(-1, 3))], -1)
+            raw_emb = kw["network_fn"](emb)
+        out[f"raw_{tag}"] = raw
+        out[f"raw_from_embedded_{tag}"] = raw_emb
+        out["embedded"] = emb
+    npz("g1_mlp", pts=pts, viewdirs=vd, **out)
+
+
+# ---------------------------------------------------------------- G2: raw2outputs
+def quad_inputs(R, S, seed, near=2.0, far=6.0, end_at_far=False):
+    g = torch.Generator().manual_seed(seed)
+    raw = torch.randn(R, S, 4, generator=g)
+    raw[..., 3] = raw[..., 3] * 3.0 + 0.5          # densities on both sides of zero
+    raw[R // 2:, S // 3: S // 2, 3] += 25.0        # an opaque slab on half the rays
+    z, _ = torch.sort(near + (far - near) * torch.rand(R, S, generator=g), -1)
+    if end_at_far:
+        z[:, -1] = far
+    nr = torch.full((R, 1), near)
+    fr = torch.full((R, 1), far)
+    d = torch.randn(R, 3, generator=g) * 1.3
+    return raw, z, nr, fr, d
+
+
+def g2():
+    out = {}
+    case = 0
+    for S in (64, 128, 192):
+        for mode, cmode in (("linear", "midpoint"), ("linear", "left"), ("constant", "midpoint")):
+            for wb in (False, True):
+                raw, z, nr, fr, d = quad_inputs(12, S, 100 + case, end_at_far=(case % 4 == 3))
+                res = R_.raw2outputs(raw, z, nr, fr, d, mode, cmode, 0.0, pytest=False, white_bkgd=wb)
+                p = f"c{case}_"
+                out.update({p + "raw": raw, p + "z": z, p + "near": nr, p + "far": fr, p + "rays_d": d,
+                            p + "S": S, p + "mode": mode, p + "color_mode": cmode, p + "white_bkgd": wb,
+                            p + "noise_std": 0.0})
+                names = ["rgb_map", "disp_map", "acc_map", "weights", "depth_map", "tau", "T"]
+                for nme, v in zip(names, res):
+                    if v is not None:
+                        out[p + nme] = v
+                case += 1
+    # noise (pytest=True -> uniform np.random.rand, seed 0) and farcolorfix
+    for mode, ffix in (("linear", False), ("constant", False), ("linear", True)):
+        raw, z, nr, fr, d = quad_inputs(12, 64, 100 + case)
+        res = R_.raw2outputs(raw, z, nr, fr, d, mode, "midpoint", 1.0, pytest=True, white_bkgd=True,
+                             farcolorfix=ffix)
+        p = f"c{case}_"
+        out.update({p + "raw": raw, p + "z": z, p + "near": nr, p + "far": fr, p + "rays_d": d,
+                    p + "S": 64, p + "mode": mode, p + "color_mode": "midpoint", p + "white_bkgd": True,
+                    p + "noise_std": 1.0, p + "farcolorfix": ffix})
+        for nme, v in zip(["rgb_map", "disp_map", "acc_map", "weights", "depth_map", "tau", "T"], res):
+            if v is not None:
+                out[p + nme] = v
+        case += 1
+    out["n_cases"] = case
+    npz("g2_raw2outputs", **out)
+
+
+# ---------------------------------------------------------------- G3: sample_pdf (det)
+class CaptureSearchsorted:
+    def __enter__(self):
+        self.orig = torch.searchsorted
+        self.inds = []
+
+        def wrapped(*a, **k):
+            r = self.orig(*a, **k)
+            self.inds.append(r.clone())
+            return r
+        torch.searchsorted = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        torch.searchsorted = self.orig
+
+
+def g3():
+    out = {}
+    for ci, (B, N) in enumerate(((63, 128), (127, 64), (63, 64))):
+        g = torch.Generator().manual_seed(300 + ci)
+        R = 48
+        bins, _ = torch.sort(2.0 + 4.0 * torch.rand(R, B, generator=g), -1)
+        w = torch.rand(R, B - 1, generator=g) ** 4
+        w[R // 3: 2 * R // 3] *= 1e-4                   # near-empty rays: pdf ~ uniform from the +1e-5
+        w[: R // 6, 5:20] = 0.0                         # zero runs -> denom < 1e-5 branch
+        w[-4:] = 0.0                                    # all-zero rays
+        for det in (True, False):
+            with CaptureSearchsorted() as cap:
+                # det: the real torch.linspace draw (pytest=False); random: numpy seed-0 draw
+                s = H_.sample_pdf(bins, w, N, det=det, pytest=not det)
+            p = f"c{ci}_{'det' if det else 'rnd'}_"
+            out.update({p + "samples": s, p + "inds": cap.inds[0]})
+        out.update({f"c{ci}_bins": bins, f"c{ci}_weights": w, f"c{ci}_N": N})
+    out["n_cases"] = 3
+    npz("g3_sample_pdf", **out)
+
+
+# ---------------------------------------------------------------- G4: PL sampler
+def g4():
+    out = {}
+    for ci, (S, N) in enumerate(((64, 128), (128, 64))):
+        raw, z, nr, fr, d = quad_inputs(40, S, 400 + ci)
+        # engineered branches: equal neighbouring densities (|dtau| < zero_tol), a NaN density,
+        # and near-coincident knots (s_r - s_l < epsilon)
+        raw[0:6, 10:20, 3] = 0.75
+        raw[6:10, :, 3] = -1.0                          # all tau == 0 -> constant branch everywhere
+        z[10:14, 20:24] = z[10:14, 20:21] + torch.arange(4) * 1e-5
+        z, _ = torch.sort(z, -1)
+        _, _, _, w, _, tau, T = R_.raw2outputs(raw, z, nr, fr, d, "linear", "midpoint", 0.0,
+                                               pytest=False, white_bkgd=True)
+        with CaptureSearchsorted() as cap:
+            s, Tb, taub, binb = H_.sample_pdf_reformulation(z, w, tau, T, nr, fr, N, det=False,
+                                                            pytest=True, zero_threshold=1e-4,
+                                                            epsilon_=1e-3)
+        np.random.seed(0)
+        u = torch.Tensor(np.random.rand(40, N))
+        p = f"c{ci}_"
+        out.update({p + "z": z, p + "weights": w, p + "tau": tau, p + "T": T, p + "near": nr, p + "far": fr,
+                    p + "u": u, p + "N": N, p + "samples": s, p + "T_below": Tb, p + "tau_below": taub,
+                    p + "bin_below": binb, p + "inds": cap.inds[0]})
+    out["n_cases"] = 2
+    npz("g4_sample_pl", **out)
+
+
+# ---------------------------------------------------------------- G5: render_rays end to end
+def g5():
+    out = {}
+    ci = 0
+    for (Ns, Ni, mode, ndc) in ((64, 128, "linear", False), (128, 64, "linear", False),
+                                (64, 128, "constant", False), (128, 64, "linear", True)):
+        args = make_args(Ns, Ni, mode, white_bkgd=not ndc, dataset="llff" if ndc else "blender",
+                         raw_noise_std=1.0 if ndc else 0.0)
+        kw, _, _, _ = ref_nets(args, 0, 1, sharpen=True)
+        R = 12
+        if not ndc:
+            batch, _ = scene_rays(R, seed=50 + ci)
+            rays = (batch[:, 0:3], batch[:, 3:6])
+            near, far, H, W, K = 2.0, 6.0, 800, 800, None
+            res = R_.render(800, 800, [[1111.111, 0, 400], [0, 1111.111, 400], [0, 0, 1]], chunk=32768,
+                            rays=rays, near=near, far=far, retraw=True, pytest=True,
+                            **kw)
+        else:
+            g = torch.Generator().manual_seed(77)
+            H, W, f = 378, 504, 407.0
+            Kc = [[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]]
+            c2w = torch.eye(4)[:3, :4].clone()
+            c2w[:, 3] = torch.tensor([0.05, -0.02, 0.1])
+            o, dd = H_.get_rays(H, W, Kc, c2w)
+            pix = torch.randperm(H * W, generator=g)[:R]
+            rays = (o.reshape(-1, 3)[pix], dd.reshape(-1, 3)[pix])
+            res = R_.render(H, W, Kc, chunk=32768, rays=rays, near=0.0, far=1.0, retraw=True, pytest=True,
+                            **kw)
+            near, far = 0.0, 1.0
+        rgb, disp, acc, extras = res
+        p = f"c{ci}_"
+        out.update({p + "rays_o": rays[0], p + "rays_d": rays[1], p + "near": near, p + "far": far,
+                    p + "N_samples": Ns, p + "N_importance": Ni, p + "mode": mode, p + "ndc": ndc,
+                    p + "H": H, p + "W": W, p + "focal": 1111.111 if not ndc else 407.0,
+                    p + "white_bkgd": not ndc, p + "raw_noise_std": 1.0 if ndc else 0.0,
+                    p + "rgb_map": rgb, p + "disp_map": disp, p + "acc_map": acc})
+        for k, v in extras.items():
+            out[p + k] = v
+        ci += 1
+    out["n_cases"] = ci
+    npz("g5_render_rays", **out)
+
+
+# ---------------------------------------------------------------- G6: one training step
+def sample_elems(t, stride=97):
+    return t.detach().reshape(-1)[::stride].clone()
+
+
+def g6():
+    out = {}
+    for ci, (Ns, Ni) in enumerate(((64, 128), (128, 64))):
+        args = make_args(Ns, Ni, "linear")
+        kw, _, opt, opt_c = ref_nets(args, 0, 1, sharpen=False)
+        R = 24
+        batch, target = scene_rays(R, seed=60 + ci)
+        rays = (batch[:, 0:3], batch[:, 3:6])
+        rgb, disp, acc, extras = R_.render(800, 800, [[1111.111, 0, 400], [0, 1111.111, 400], [0, 0, 1]],
+                                           chunk=32768, rays=rays, near=2.0, far=6.0, retraw=True,
+                                           pytest=True, **kw)
+        opt.zero_grad()
+        opt_c.zero_grad()
+        loss = H_.img2mse(rgb, target) + H_.img2mse(extras["rgb0"], target)
+        loss.backward()
+        p = f"c{ci}_"
+        out.update({p + "ray_batch": batch, p + "target": target, p + "N_samples": Ns, p + "N_importance": Ni,
+                    p + "loss": loss.detach()})
+        for net, tag in ((kw["network_fn"], "coarse"), (kw["network_fine"], "fine")):
+            for name, prm in net.named_parameters():
+                out[p + f"grad_{tag}_{name}_norm"] = prm.grad.norm()
+                out[p + f"grad_{tag}_{name}_sample"] = sample_elems(prm.grad)
+        opt.step()
+        opt_c.step()
+        for net, tag in ((kw["network_fn"], "coarse"), (kw["network_fine"], "fine")):
+            for name, prm in net.named_parameters():
+                out[p + f"param_{tag}_{name}_sample"] = sample_elems(prm)
+    out["n_cases"] = 2
+    out["sample_stride"] = 97
+    npz("g6_train_step", **out)
+
+
+# ---------------------------------------------------------------- G7: rays
+def g7():
+    H, W, f = 6, 8, 7.5
+    K = [[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]]
+    c2w = orc.pose_spherical(37.0, -30.0, 4.0)[:3, :4]
+    o, d = H_.get_rays(H, W, K, c2w)
+    o2, d2 = H_.ndc_rays(H, W, f, 1.0, o, d)
+    npz("g7_rays", H=H, W=W, focal=f, c2w=c2w, rays_o=o, rays_d=d, ndc_o=o2, ndc_d=d2)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    for name in which:
+        globals()[name]()
