@@ -1,0 +1,170 @@
+/*
+ * plnerf_hip.h -- C ABI of libplnerf_hip.so, the MI355X (gfx950) implementation of
+ * PL-NeRF's ray-batched volume-rendering hot path.
+ *
+ * The reference (mikacuy/PL-NeRF) is pure Python on PyTorch and has no FFI layer; the
+ * entry points below are what a binding for this path would bind, one per reference
+ * function (cited per entry as file:line into the reference tree).  All functions
+ *   - take raw DEVICE pointers (fp32 unless noted) plus explicit sizes,
+ *   - allocate nothing: the caller owns every input, output and workspace,
+ *   - only ENQUEUE work on `stream` (a hipStream_t passed as void*; NULL = default),
+ *   - are re-entrant and keep no global mutable state,
+ *   - return 0 on success or a negative PLNERF_E* code (never throw).
+ *
+ * Row-major contiguous layouts throughout.  R = rays, S = samples per ray in this
+ * pass, N = number of new samples to draw.
+ */
+#ifndef PLNERF_HIP_H
+#define PLNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLNERF_VERSION 100 /* major*10000 + minor*100 + patch */
+
+/* error codes */
+#define PLNERF_OK 0
+#define PLNERF_EINVAL (-1)   /* bad size / null pointer / unsupported combination */
+#define PLNERF_ELAUNCH (-2)  /* hipGetLastError() after the launch was not hipSuccess */
+#define PLNERF_ERANGE (-3)   /* size outside the compiled limits (e.g. S > PLNERF_MAX_SAMPLES) */
+#define PLNERF_ENOSYS (-4)   /* precision mode not built */
+
+/* quadrature mode: run_plnerf.py:579 (linear) / :607 (constant) */
+#define PLNERF_MODE_CONSTANT 0
+#define PLNERF_MODE_LINEAR 1
+/* colour rule of the linear mode: run_plnerf.py:581 / :593 */
+#define PLNERF_COLOR_MIDPOINT 0
+#define PLNERF_COLOR_LEFT 1
+/* arithmetic of the MLP contractions */
+#define PLNERF_PREC_FP32 0   /* v_mfma_f32_32x32x2_f32: exact fp32 fma chains        */
+#define PLNERF_PREC_BF16X3 1 /* 3-term bf16 split on v_mfma_f32_32x32x16_bf16        */
+#define PLNERF_PREC_BF16 2   /* plain bf16 operands, fp32 accumulate                 */
+
+#define PLNERF_MAX_SAMPLES 1022 /* S+2 knots must fit the per-wave LDS row */
+
+/* Network geometry this library is specialised for: the reference defaults
+ * (run_plnerf.py:784-825: netdepth 8, netwidth 256, skips [4], multires 10,
+ * multires_views 4, use_viewdirs).  595,844 parameters per network. */
+#define PLNERF_N_PARAM_TENSORS 24
+#define PLNERF_N_PARAMS 595844
+
+typedef void* plnerf_stream_t;
+
+int plnerf_version(void);
+const char* plnerf_error_string(int code);
+
+/* ------------------------------------------------------------------------------------
+ * Quadrature -- raw2outputs (run_plnerf.py:553-624) with compute_weights_piecewise_linear
+ * (:516-550) or compute_weights (:504-513) fused in.  One wavefront per ray.
+ *
+ *   raw    [R,S,4]  (r,g,b,sigma) pre-activation          z      [R,S] sample depths
+ *   near   [R], far [R]                                    rays_d [R,3]
+ *   noise  [R,S] or NULL (added to sigma before the relu)
+ * outputs (any of weights/tau/T may be NULL):
+ *   rgb_map [R,3], disp_map [R], acc_map [R], depth_map [R]
+ *   weights [R,S+1] linear | [R,S] constant;  tau, T [R,S+2] (linear only)
+ */
+int plnerf_quad_fwd(const float* raw, const float* z, const float* near, const float* far,
+                    const float* rays_d, const float* noise, int R, int S, int mode,
+                    int color_mode, int white_bkgd, int farcolorfix, float* rgb_map,
+                    float* disp_map, float* acc_map, float* depth_map, float* weights,
+                    float* tau, float* T, plnerf_stream_t stream);
+
+/* Backward of plnerf_quad_fwd with respect to `raw` (what autograd derives for the
+ * reference at loss.backward(), run_plnerf.py:1300).  Upstream gradients g_rgb [R,3]
+ * (required), g_depth [R], g_acc [R], g_weights [R,S+1|S] (each may be NULL = zero).
+ * disp_map's gradient is folded into g_depth/g_acc by the caller.  g_raw [R,S,4]. */
+int plnerf_quad_bwd(const float* raw, const float* z, const float* near, const float* far,
+                    const float* rays_d, const float* noise, int R, int S, int mode,
+                    int color_mode, int white_bkgd, int farcolorfix, const float* g_rgb,
+                    const float* g_depth, const float* g_acc, const float* g_weights,
+                    float* g_raw, plnerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Hierarchical samplers.  `u` holds the uniform draws: [R,N] when u_row_stride == N, or
+ * one shared row [N] when u_row_stride == 0 (det=True: torch.linspace(0,1,N)).
+ *
+ * sample_pdf (run_nerf_helpers.py:241-284): bins [R,B], weights [R,B-1].
+ * Bit-exact contract: `inds` (int64 [R,N], may be NULL) equals torch.searchsorted on the
+ * reference's CPU cdf for B-1 >= 8: the row sum replays torch's vectorised fp32 reduction
+ * tree, the cdf is an fp64 running sum rounded per element, the divide is IEEE.
+ */
+int plnerf_sample_const(const float* bins, const float* weights, const float* u,
+                        int u_row_stride, int R, int B, int N, float* samples, int64_t* inds,
+                        plnerf_stream_t stream);
+
+/* sample_pdf_reformulation (run_nerf_helpers.py:364-445) with pw_linear_sample_increasing /
+ * _decreasing (:340-361): z [R,S], weights [R,S+1], tau,T [R,S+2], near,far [R].
+ * Outputs samples [R,N] and (each may be NULL) T_below, tau_below, bin_below [R,N],
+ * inds int64 [R,N].  u == 1.0 (where the reference indexes out of bounds) is defined by
+ * clamping the interval index to S. */
+int plnerf_sample_pl(const float* z, const float* weights, const float* tau, const float* T,
+                     const float* near, const float* far, const float* u, int u_row_stride,
+                     int R, int S, int N, float zero_tol, float epsilon, float* samples,
+                     float* T_below, float* tau_below, float* bin_below, int64_t* inds,
+                     plnerf_stream_t stream);
+
+/* clamp(z_new, near, far) ++ z, sorted ascending per ray (run_plnerf.py:731-734).
+ * z [R,S], z_new [R,N] -> out [R,S+N]; S+N <= 1024. */
+int plnerf_merge_sort(const float* z, const float* z_new, const float* near, const float* far,
+                      int R, int S, int N, float* out, plnerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * The MLP: run_network (run_plnerf.py:78-92) = Embedder (run_nerf_helpers.py:24-54) +
+ * NeRF.forward (:105-128), fused: positional encoding -> 8x256 trunk with skip ->
+ * sigma / feature / view layer / rgb, activations staged in LDS, contractions on MFMA.
+ *
+ * params[24]: DEVICE pointers to the fp32 parameter tensors in state_dict order
+ *   pts_linears.{0..7}.{weight,bias}, views_linears.0.{weight,bias},
+ *   feature_linear.{weight,bias}, alpha_linear.{weight,bias}, rgb_linear.{weight,bias}
+ * (the host array itself lives in host memory and is read during the call).
+ */
+
+/* Size in bytes of the packed-weight buffer for a precision mode. */
+size_t plnerf_mlp_packed_bytes(int precision);
+/* Re-layout the 24 parameter tensors into MFMA fragment order (call after every
+ * optimizer step; cheap: one pass over 2.4 MB). */
+int plnerf_mlp_pack_weights(const float* const* params, int precision, void* packed,
+                            plnerf_stream_t stream);
+
+/* Bytes of forward state saved for the backward pass (activations of every layer) and of
+ * backward scratch (per-layer pre-activation gradients, split-K partial sums). */
+size_t plnerf_mlp_saved_bytes(int n_rows, int precision);
+size_t plnerf_mlp_bwd_workspace_bytes(int n_rows, int precision);
+
+/* Forward.  Either (pts [n_rows,3] AND viewdirs [n_rows/samples_per_ray, 3]) with
+ * embedded == NULL -- the encoding is computed in the kernel prologue, once per sample
+ * for xyz and from the per-ray direction -- or embedded [n_rows, 90] (a caller-supplied
+ * encoding; NeRF.forward's own signature).  saved == NULL for inference.
+ * raw_out [n_rows,4]. */
+int plnerf_mlp_fwd(const void* packed, int precision, const float* pts, const float* viewdirs,
+                   const float* embedded, int n_rows, int samples_per_ray, float* raw_out,
+                   void* saved, plnerf_stream_t stream);
+
+/* Backward: g_raw [n_rows,4] -> gradients of all 24 parameter tensors, written (not
+ * accumulated) to grads[24] (device pointers, same shapes as params).  Needs the `saved`
+ * buffer of the matching forward call and a workspace of
+ * plnerf_mlp_bwd_workspace_bytes().  Inputs (pts / viewdirs) receive no gradient, as on
+ * the reference path (they do not depend on parameters; z_samples is detached,
+ * run_plnerf.py:728). */
+int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, int n_rows,
+                   const void* saved, void* workspace, float* const* grads,
+                   plnerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused Adam step over a flat parameter buffer (torch.optim.Adam semantics as used at
+ * run_plnerf.py:446-447, 1302-1303: betas (0.9,0.999), eps 1e-8, no weight decay, no
+ * amsgrad).  step >= 1 is the step count AFTER this update. grad_scale multiplies the
+ * gradient first (1/world_size after an all-reduce sum). */
+int plnerf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                     int64_t n, float lr, float beta1, float beta2, float eps, int step,
+                     float grad_scale, plnerf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLNERF_HIP_H */

@@ -1,0 +1,91 @@
+"""ctypes binding of libplnerf_hip.so (C ABI declared in include/plnerf_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a tensor is not on a HIP
+device, the call raises.  Build the library with `python __graft_entry__.py` (or
+`make -C pl-nerf_amd/csrc`); hipcc cross-compiles gfx950 without a GPU present.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libplnerf_hip.so")
+
+MODE = {"constant": 0, "linear": 1}
+COLOR = {"midpoint": 0, "left": 1}
+PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2}
+N_PARAM_TENSORS = 24
+
+c_f = ctypes.c_void_p      # device pointer
+c_i = ctypes.c_int
+c_s = ctypes.c_void_p      # hipStream_t
+
+# name -> (restype, argtypes); mirrors include/plnerf_hip.h one to one
+SIGNATURES = {
+    "plnerf_version": (c_i, []),
+    "plnerf_error_string": (ctypes.c_char_p, [c_i]),
+    "plnerf_quad_fwd": (c_i, [c_f] * 6 + [c_i] * 6 + [c_f] * 7 + [c_s]),
+    "plnerf_quad_bwd": (c_i, [c_f] * 6 + [c_i] * 6 + [c_f] * 5 + [c_s]),
+    "plnerf_sample_const": (c_i, [c_f] * 3 + [c_i] * 4 + [c_f] * 2 + [c_s]),
+    "plnerf_sample_pl": (c_i, [c_f] * 7 + [c_i] * 4 + [ctypes.c_float] * 2 + [c_f] * 5 + [c_s]),
+    "plnerf_merge_sort": (c_i, [c_f] * 4 + [c_i] * 3 + [c_f] + [c_s]),
+    "plnerf_mlp_packed_bytes": (ctypes.c_size_t, [c_i]),
+    "plnerf_mlp_pack_weights": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_i, c_f, c_s]),
+    "plnerf_mlp_saved_bytes": (ctypes.c_size_t, [c_i, c_i]),
+    "plnerf_mlp_bwd_workspace_bytes": (ctypes.c_size_t, [c_i, c_i]),
+    "plnerf_mlp_fwd": (c_i, [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_s]),
+    "plnerf_mlp_bwd": (c_i, [c_f, c_i, c_f, c_i, c_f, c_f, ctypes.POINTER(ctypes.c_void_p), c_s]),
+    "plnerf_adam_step": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_int64] + [ctypes.c_float] * 4 + [c_i, ctypes.c_float, c_s]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises ImportError (with the build recipe) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` or "
+                "`make -C pl-nerf_amd/csrc` (hipcc --offload-arch=gfx950). "
+                "plnerf_amd has no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {lib().plnerf_error_string(rc).decode()} (code {rc})")
+
+
+def dptr(t, name="tensor", dtype=torch.float32):
+    """Device pointer of a contiguous tensor on a HIP device (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"plnerf_amd: `{name}` is on {t.device}; the HIP path needs a GPU tensor "
+            "(there is no CPU fallback)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"plnerf_amd: `{name}` must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"plnerf_amd: `{name}` must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr_table(tensors, name="params"):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = dptr(t, f"{name}[{i}]").value
+    return arr

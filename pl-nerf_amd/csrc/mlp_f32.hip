@@ -1,0 +1,893 @@
+// The PL-NeRF MLP in exact-fp32 mode (PLNERF_PREC_FP32) on v_mfma_f32_32x32x2_f32.
+//
+// Reference: run_network (run_plnerf.py:78-92) = Embedder (run_nerf_helpers.py:24-54) +
+// NeRF.forward (:105-128); the backward is what autograd derives for it at
+// loss.backward() (run_plnerf.py:1300).
+//
+// Forward (mlp_fwd_f32_kernel): one 256-thread workgroup owns a tile of TM = 64 samples
+// and walks all 12 layers with the tile's activations resident in LDS:
+//   prologue  positional encoding computed into LDS (xyz: 60 sincos per sample; the view
+//             direction is encoded from the per-ray vector, never materialised per sample)
+//   per layer each of the 4 wavefronts owns a 64-column slab of the output; the K loop
+//             reads A fragments (activations) from LDS with 16-byte reads and B fragments
+//             (weights, pre-packed in MFMA fragment order, L2 resident) with one coalesced
+//             16-byte global load per 4 MFMA steps; accumulators stay in registers until
+//             the layer is complete, so the output overwrites the input tile in place
+//             (bias + ReLU fused into that write; optional copy to HBM for backward)
+//   heads     sigma (256->1) and rgb (128->3) are VALU dot products out of LDS.
+// The skip connection (layer 5 = [encoding, h4]) is two K ranges over the two LDS buffers;
+// no concatenation is ever materialised.
+//
+// Backward: mlp_bwd_f32_kernel is the same tile walk in reverse for the dgrad chain
+// (dz_l = (dz_{l+1} W_{l+1}) * relu'(h_l)), writing every dz_l to HBM; wgrad_f32_kernel then
+// forms dW_l = dz_l^T a_{l-1} as split-K MFMA GEMMs straight out of HBM (both operands are
+// K-major in memory, which is exactly the f32 MFMA fragment order, so no LDS staging), and
+// wgrad_reduce_kernel sums the split-K partials deterministically into the 24 gradient
+// tensors in their original [out][in] layout.
+//
+// Numerics: f32 MFMA is bit-for-bit an fmaf chain; only the summation order differs from
+// the reference's CPU GEMM, i.e. fp32 round-off (~1e-7 relative), well inside the 1e-5
+// parity bound.
+#include "common.h"
+#include "mlp_layout.h"
+
+using namespace plnerf;
+using namespace plnerf::lay;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct ParamPtrs { const float* p[PLNERF_N_PARAM_TENSORS]; };
+struct GradPtrs { float* p[PLNERF_N_PARAM_TENSORS]; };
+
+constexpr int LDA = 260;  // activation tile row stride (floats): == 4 mod 64 -> conflict-free b128 reads
+constexpr int LDP = 68;   // xyz-encoding tile row stride
+constexpr int LDD = 36;   // direction-encoding tile row stride
+
+// ------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float fwd_src(const ParamPtrs& P, int g, int k, int j) {
+    switch (g) {
+        case G_L0: return k < XYZ_CH ? P.p[0][j * XYZ_CH + k] : 0.0f;
+        case G_L5:
+            if (k < PE_K) return k < XYZ_CH ? P.p[10][j * (W + XYZ_CH) + k] : 0.0f;
+            return P.p[10][j * (W + XYZ_CH) + XYZ_CH + (k - PE_K)];
+        case G_FEAT: return P.p[P_WF][j * W + k];
+        case G_VIEWS:
+            if (k < W) return P.p[P_WV][j * (W + DIR_CH) + k];
+            return (k - W) < DIR_CH ? P.p[P_WV][j * (W + DIR_CH) + k] : 0.0f;
+        default: return P.p[2 * g][j * W + k];  // G_L1..G_L4, G_L6, G_L7: layer index == g
+    }
+}
+
+__device__ __forceinline__ float bwd_src(const ParamPtrs& P, int g, int o, int i) {
+    switch (g) {
+        case D_VIEWS: return P.p[P_WV][o * (W + DIR_CH) + i];
+        case D_FEAT: return P.p[P_WF][o * W + i];
+        case D_L5: return P.p[10][o * (W + XYZ_CH) + XYZ_CH + i];
+        case D_L7: return P.p[14][o * W + i];
+        case D_L6: return P.p[12][o * W + i];
+        case D_L4: return P.p[8][o * W + i];
+        case D_L3: return P.p[6][o * W + i];
+        case D_L2: return P.p[4][o * W + i];
+        default: return P.p[2][o * W + i];  // D_L1
+    }
+}
+
+__global__ void pack_f32_kernel(ParamPtrs P, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= PACKED_FLOATS) return;
+    float v;
+    if (idx < FWD_FLOATS) {
+        int g = 0, off = 0;
+        while (g < N_FWD - 1 && idx >= off + fwd_K[g] * fwd_N[g]) { off += fwd_K[g] * fwd_N[g]; ++g; }
+        const int rem = idx - off, KC = fwd_K[g] >> 3;
+        const int blk = rem >> 8, w = rem & 255;
+        const int jt = blk / KC, kc = blk - jt * KC, lane = w >> 2, t = w & 3;
+        v = fwd_src(P, g, kc * 8 + (lane >> 5) * 4 + t, jt * 32 + (lane & 31));
+    } else if (idx < HB_END) {
+        if (idx < HB_BF) { const int r = idx - HB_BIAS; v = P.p[2 * (r >> 8) + 1][r & 255]; }
+        else if (idx < HB_BV) v = P.p[P_BF][idx - HB_BF];
+        else if (idx < HB_WA) v = P.p[P_BV][idx - HB_BV];
+        else if (idx < HB_BA) v = P.p[P_WA][idx - HB_WA];
+        else if (idx < HB_WR) v = (idx == HB_BA) ? P.p[P_BA][0] : 0.0f;
+        else if (idx < HB_BR) v = P.p[P_WR][idx - HB_WR];
+        else v = (idx - HB_BR) < 3 ? P.p[P_BR][idx - HB_BR] : 0.0f;
+    } else {
+        int g = 0, off = BWD;
+        while (g < N_BWD - 1 && idx >= off + bwd_K[g] * bwd_N[g]) { off += bwd_K[g] * bwd_N[g]; ++g; }
+        const int rem = idx - off, KC = bwd_K[g] >> 3;
+        const int blk = rem >> 8, w = rem & 255;
+        const int jt = blk / KC, kc = blk - jt * KC, lane = w >> 2, t = w & 3;
+        v = bwd_src(P, g, kc * 8 + (lane >> 5) * 4 + t, jt * 32 + (lane & 31));
+    }
+    out[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------
+// the tile GEMM: acc[i][j] += A[32 i .. +31][kc range] . B[kc range][32 j .. +31]
+//   a_lane = &A[lane & 31][4 * (lane >> 5)]           (LDS, row stride lda)
+//   b_lane = packed B of the wave's first j tile at this K range, + 4 * lane
+// One K chunk = 8 k values = 4 MFMA steps; B for chunk kc+1 is loaded while chunk kc's
+// NI*NJ*4 MFMAs (64 cycles each) issue.
+// ------------------------------------------------------------------------------------
+template <int NI, int NJ>
+__device__ __forceinline__ void mma_run(f32x16 (&acc)[NI][NJ], const float* a_lane, const int lda,
+                                        const float* __restrict__ b_lane, const int b_jt_stride,
+                                        const int kcount) {
+    f32x4 bcur[NJ], bnxt[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bcur[j] = *reinterpret_cast<const f32x4*>(b_lane + j * b_jt_stride);
+    for (int kc = 0; kc < kcount; ++kc) {
+        if (kc + 1 < kcount) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                bnxt[j] = *reinterpret_cast<const f32x4*>(b_lane + j * b_jt_stride + (kc + 1) * 256);
+        }
+        f32x4 a[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) a[i] = *reinterpret_cast<const f32x4*>(a_lane + i * 32 * lda + kc * 8);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], bcur[j][t], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bcur[j] = bnxt[j];
+    }
+}
+
+template <int NI, int NJ>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NI][NJ]) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+}
+
+// C/D fragment coordinates of v_mfma_f32_32x32x*: col = lane & 31,
+// row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+__device__ __forceinline__ int frag_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------
+struct FwdArgs {
+    const float* packed;
+    const float* pts;
+    const float* viewdirs;
+    const float* embedded;
+    int n_rows, spr;
+    float* raw_out;
+    float* saved;
+};
+
+// bias (+relu) epilogue: accumulators -> LDS tile in place (+ saved plane in HBM)
+template <int NI, int NJ, bool RELU, bool SAVE>
+__device__ __forceinline__ void store_act(f32x16 (&acc)[NI][NJ], const float* __restrict__ bias, float* act,
+                                          const int col0, float* __restrict__ plane, const int ld_plane,
+                                          const int row0, const int rows_valid, const int lane) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int col = col0 + j * 32 + (lane & 31);
+            const float b = bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + frag_row(r, lane);
+                float v = acc[i][j][r] + b;
+                if (RELU) v = v > 0.0f ? v : 0.0f;
+                act[row * LDA + col] = v;
+                if (SAVE && row < rows_valid) plane[(size_t)(row0 + row) * ld_plane + col] = v;
+            }
+        }
+}
+
+template <int NI, bool SAVE>
+__global__ __launch_bounds__(256) void mlp_fwd_f32_kernel(FwdArgs a) {
+    constexpr int TM = 32 * NI;
+    constexpr int TPR = 256 / TM;  // threads per row in the VALU heads
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* act = smem;
+    float* pe = act + TM * LDA;
+    float* dpe = pe + TM * LDP;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row0 = blockIdx.x * TM;
+    const int rows_valid = min(TM, a.n_rows - row0);
+    const size_t N = (size_t)a.n_rows;
+
+    // ---- prologue: encodings into LDS --------------------------------------------------
+    if (a.embedded) {
+        for (int e = tid; e < TM * EMB_CH; e += 256) {
+            const int row = e / EMB_CH, c = e - row * EMB_CH;
+            const int grow = min(row0 + row, a.n_rows - 1);
+            const float v = a.embedded[(size_t)grow * EMB_CH + c];
+            if (c < XYZ_CH) pe[row * LDP + c] = v;
+            else dpe[row * LDD + (c - XYZ_CH)] = v;
+        }
+        for (int row = tid; row < TM; row += 256) {
+            pe[row * LDP + XYZ_CH] = 0.0f;
+#pragma unroll
+            for (int c = DIR_CH; c < DPE_K; ++c) dpe[row * LDD + c] = 0.0f;
+        }
+    } else {
+        // thread -> (row, q): q indexes which frequencies this thread encodes
+        for (int e = tid; e < TM * 4; e += 256) {
+            const int row = e % TM, q = e / TM;
+            const int grow = min(row0 + row, a.n_rows - 1);
+            const float px = a.pts[3 * (size_t)grow + 0], py = a.pts[3 * (size_t)grow + 1],
+                        pz = a.pts[3 * (size_t)grow + 2];
+            float* prow = pe + row * LDP;
+            for (int f = q; f < XYZ_FREQS; f += 4) {
+                const float sc = (float)(1 << f);
+                float s, c;
+                sincosf(px * sc, &s, &c); prow[3 + 6 * f + 0] = s; prow[3 + 6 * f + 3] = c;
+                sincosf(py * sc, &s, &c); prow[3 + 6 * f + 1] = s; prow[3 + 6 * f + 4] = c;
+                sincosf(pz * sc, &s, &c); prow[3 + 6 * f + 2] = s; prow[3 + 6 * f + 5] = c;
+            }
+            if (q == 0) { prow[0] = px; prow[1] = py; prow[2] = pz; prow[XYZ_CH] = 0.0f; }
+            const int ray = grow / a.spr;
+            const float dx = a.viewdirs[3 * (size_t)ray + 0], dy = a.viewdirs[3 * (size_t)ray + 1],
+                        dz = a.viewdirs[3 * (size_t)ray + 2];
+            float* drow = dpe + row * LDD;
+            {
+                const int f = q;  // DIR_FREQS == 4
+                const float sc = (float)(1 << f);
+                float s, c;
+                sincosf(dx * sc, &s, &c); drow[3 + 6 * f + 0] = s; drow[3 + 6 * f + 3] = c;
+                sincosf(dy * sc, &s, &c); drow[3 + 6 * f + 1] = s; drow[3 + 6 * f + 4] = c;
+                sincosf(dz * sc, &s, &c); drow[3 + 6 * f + 2] = s; drow[3 + 6 * f + 5] = c;
+            }
+            if (q == 1) { drow[0] = dx; drow[1] = dy; drow[2] = dz; }
+            if (q == 2) {
+#pragma unroll
+                for (int c = DIR_CH; c < DPE_K; ++c) drow[c] = 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+    if (SAVE) {
+        float* pe_plane = a.saved + (size_t)SV_PE_OFF * N;
+        float* dpe_plane = a.saved + (size_t)SV_DPE_OFF * N;
+        for (int e = tid; e < TM * PE_K; e += 256) {
+            const int row = e >> 6, c = e & 63;
+            if (row < rows_valid) pe_plane[(size_t)(row0 + row) * PE_K + c] = pe[row * LDP + c];
+        }
+        for (int e = tid; e < TM * DPE_K; e += 256) {
+            const int row = e >> 5, c = e & 31;
+            if (row < rows_valid) dpe_plane[(size_t)(row0 + row) * DPE_K + c] = dpe[row * LDD + c];
+        }
+    }
+
+    const float* pk = a.packed;
+    const int a_off = (lane & 31), a_k = 4 * (lane >> 5);
+    const float* act_lane = act + a_off * LDA + a_k;
+    const float* pe_lane = pe + a_off * LDP + a_k;
+    const float* dpe_lane = dpe + a_off * LDD + a_k;
+    const int jt0 = wave * 2;  // this wave's first 32-column tile (N = 256 layers)
+    f32x16 acc[NI][2];
+
+    // plane p of the saved buffer
+#define PLANE(p) (a.saved + (size_t)(p) * W * N)
+#define BLANE(g, KC) (pk + fwd_off(g) + (size_t)jt0 * (KC) * 256 + lane * 4)
+
+    // L0: encoding -> 256
+    zero_acc(acc);
+    mma_run<NI, 2>(acc, pe_lane, LDP, BLANE(G_L0, 8), 8 * 256, 8);
+    __syncthreads();
+    store_act<NI, 2, true, SAVE>(acc, pk + HB_BIAS + 0 * W, act, jt0 * 32, SAVE ? PLANE(0) : nullptr, W, row0,
+                                 rows_valid, lane);
+    __syncthreads();
+    // L1..L4
+#pragma unroll 1
+    for (int l = 1; l <= 4; ++l) {
+        zero_acc(acc);
+        mma_run<NI, 2>(acc, act_lane, LDA, pk + fwd_off(G_L1) + (size_t)(l - 1) * W * W + (size_t)jt0 * 32 * 256 + lane * 4,
+                       32 * 256, 32);
+        __syncthreads();
+        store_act<NI, 2, true, SAVE>(acc, pk + HB_BIAS + l * W, act, jt0 * 32, SAVE ? PLANE(l) : nullptr, W, row0,
+                                     rows_valid, lane);
+        __syncthreads();
+    }
+    // L5: [encoding | h4] -> 256  (K = 64 + 256, two ranges over the two LDS tiles)
+    zero_acc(acc);
+    mma_run<NI, 2>(acc, pe_lane, LDP, BLANE(G_L5, 40), 40 * 256, 8);
+    mma_run<NI, 2>(acc, act_lane, LDA, BLANE(G_L5, 40) + 8 * 256, 40 * 256, 32);
+    __syncthreads();
+    store_act<NI, 2, true, SAVE>(acc, pk + HB_BIAS + 5 * W, act, jt0 * 32, SAVE ? PLANE(5) : nullptr, W, row0,
+                                 rows_valid, lane);
+    __syncthreads();
+    // L6, L7
+#pragma unroll 1
+    for (int l = 6; l <= 7; ++l) {
+        zero_acc(acc);
+        mma_run<NI, 2>(acc, act_lane, LDA, pk + fwd_off(G_L6) + (size_t)(l - 6) * W * W + (size_t)jt0 * 32 * 256 + lane * 4,
+                       32 * 256, 32);
+        __syncthreads();
+        store_act<NI, 2, true, SAVE>(acc, pk + HB_BIAS + l * W, act, jt0 * 32, SAVE ? PLANE(l) : nullptr, W, row0,
+                                     rows_valid, lane);
+        __syncthreads();
+    }
+    // sigma = h7 . w_alpha + b_alpha  (VALU; TPR threads per row, interleaved columns)
+    const int hrow = tid / TPR, hq = tid % TPR;
+    float sigma = 0.0f;
+    {
+        const float* wa = pk + HB_WA;
+        const float* hr = act + hrow * LDA;
+#pragma unroll 8
+        for (int k = 0; k < W / TPR; ++k) sigma = fmaf(hr[TPR * k + hq], wa[TPR * k + hq], sigma);
+#pragma unroll
+        for (int d = 1; d < TPR; d <<= 1) sigma += __shfl_xor(sigma, d);
+        sigma += pk[HB_BA];
+    }
+    // feature = h7 W_f^T + b_f (no activation)
+    zero_acc(acc);
+    mma_run<NI, 2>(acc, act_lane, LDA, BLANE(G_FEAT, 32), 32 * 256, 32);
+    __syncthreads();
+    store_act<NI, 2, false, SAVE>(acc, pk + HB_BF, act, jt0 * 32, SAVE ? PLANE(SV_FEAT) : nullptr, W, row0,
+                                  rows_valid, lane);
+    __syncthreads();
+    // view layer: [feature | direction encoding] -> 128, relu; each wave owns 32 columns
+    f32x16 accv[NI][1];
+    zero_acc(accv);
+    {
+        const float* bl = pk + fwd_off(G_VIEWS) + (size_t)wave * 36 * 256 + lane * 4;
+        mma_run<NI, 1>(accv, act_lane, LDA, bl, 36 * 256, 32);
+        mma_run<NI, 1>(accv, dpe_lane, LDD, bl + 32 * 256, 36 * 256, 4);
+    }
+    __syncthreads();
+    store_act<NI, 1, true, SAVE>(accv, pk + HB_BV, act, wave * 32, SAVE ? a.saved + (size_t)SV_HV_OFF * N : nullptr,
+                                 HV, row0, rows_valid, lane);
+    __syncthreads();
+    // rgb = hv W_rgb^T + b_rgb
+    {
+        const float* wr = pk + HB_WR;
+        const float* hr = act + hrow * LDA;
+        float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
+#pragma unroll 8
+        for (int k = 0; k < HV / TPR; ++k) {
+            const float h = hr[TPR * k + hq];
+            o0 = fmaf(h, wr[0 * HV + TPR * k + hq], o0);
+            o1 = fmaf(h, wr[1 * HV + TPR * k + hq], o1);
+            o2 = fmaf(h, wr[2 * HV + TPR * k + hq], o2);
+        }
+#pragma unroll
+        for (int d = 1; d < TPR; d <<= 1) {
+            o0 += __shfl_xor(o0, d);
+            o1 += __shfl_xor(o1, d);
+            o2 += __shfl_xor(o2, d);
+        }
+        if (hq == 0 && hrow < rows_valid) {
+            float4 o;
+            o.x = o0 + pk[HB_BR + 0];
+            o.y = o1 + pk[HB_BR + 1];
+            o.z = o2 + pk[HB_BR + 2];
+            o.w = sigma;
+            reinterpret_cast<float4*>(a.raw_out)[row0 + hrow] = o;
+        }
+    }
+#undef PLANE
+#undef BLANE
+}
+
+// ------------------------------------------------------------------------------------
+// backward: dgrad chain
+// ------------------------------------------------------------------------------------
+struct BwdArgs {
+    const float* packed;
+    const float* g_raw;
+    int n_rows;
+    const float* saved;
+    float* dz;
+};
+
+// accumulators (dh) -> (optional + g_sigma w_alpha) -> (optional relu mask from the saved
+// activation plane) -> LDS tile in place + dz plane in HBM
+template <int NI, bool MASK, bool ALPHA>
+__device__ __forceinline__ void store_dz(f32x16 (&acc)[NI][2], float* g, const float* gr, const float* __restrict__ wa,
+                                         const float* __restrict__ mask_plane, float* __restrict__ out_plane,
+                                         const int col0, const int row0, const int rows_valid, const int lane) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = col0 + j * 32 + (lane & 31);
+            const float wac = ALPHA ? wa[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + frag_row(r, lane);
+                const bool ok = row < rows_valid;
+                float v = acc[i][j][r];
+                if (ALPHA) v = fmaf(gr[row * 4 + 3], wac, v);
+                if (MASK) {
+                    const float h = ok ? mask_plane[(size_t)(row0 + row) * W + col] : 0.0f;
+                    v = h > 0.0f ? v : 0.0f;
+                }
+                g[row * LDA + col] = v;
+                if (ok) out_plane[(size_t)(row0 + row) * W + col] = v;
+            }
+        }
+}
+
+template <int NI>
+__global__ __launch_bounds__(256) void mlp_bwd_f32_kernel(BwdArgs a) {
+    constexpr int TM = 32 * NI;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* g = smem;                 // TM x LDA: the current pre-activation gradient tile
+    float* gr = g + TM * LDA;        // TM x 4: upstream gradient of (r,g,b,sigma)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row0 = blockIdx.x * TM;
+    const int rows_valid = min(TM, a.n_rows - row0);
+    const size_t N = (size_t)a.n_rows;
+    const float* pk = a.packed;
+#define SPLANE(p) (a.saved + (size_t)(p) * W * N)
+#define DPLANE(p) (a.dz + (size_t)(p) * W * N)
+
+    for (int row = tid; row < TM; row += 256) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < rows_valid) v = reinterpret_cast<const float4*>(a.g_raw)[row0 + row];
+        reinterpret_cast<float4*>(gr)[row] = v;
+    }
+    __syncthreads();
+    // dz_view = (g_rgb W_rgb) * relu'(hv)
+    {
+        const float* wr = pk + HB_WR;
+        const float* hv_plane = a.saved + (size_t)SV_HV_OFF * N;
+        float* dzv_plane = a.dz + (size_t)DZ_V_OFF * N;
+        for (int e = tid; e < TM * HV; e += 256) {
+            const int row = e >> 7, i = e & 127;
+            const bool ok = row < rows_valid;
+            float v = gr[row * 4 + 0] * wr[i];
+            v = fmaf(gr[row * 4 + 1], wr[HV + i], v);
+            v = fmaf(gr[row * 4 + 2], wr[2 * HV + i], v);
+            const float h = ok ? hv_plane[(size_t)(row0 + row) * HV + i] : 0.0f;
+            v = h > 0.0f ? v : 0.0f;
+            g[row * LDA + i] = v;
+            if (ok) dzv_plane[(size_t)(row0 + row) * HV + i] = v;
+        }
+    }
+    __syncthreads();
+    const float* g_lane = g + (lane & 31) * LDA + 4 * (lane >> 5);
+    const int jt0 = wave * 2;
+    f32x16 acc[NI][2];
+#define DBLANE(d, KC) (pk + bwd_off(d) + (size_t)jt0 * (KC) * 256 + lane * 4)
+    // d feature = dz_view . W_view[:, :256]   (K = 128)
+    zero_acc(acc);
+    mma_run<NI, 2>(acc, g_lane, LDA, DBLANE(D_VIEWS, 16), 16 * 256, 16);
+    __syncthreads();
+    store_dz<NI, false, false>(acc, g, gr, nullptr, nullptr, DPLANE(DZ_FEAT), jt0 * 32, row0, rows_valid, lane);
+    __syncthreads();
+    // d h7 = dz_feature . W_f + g_sigma w_alpha, masked by h7
+    zero_acc(acc);
+    mma_run<NI, 2>(acc, g_lane, LDA, DBLANE(D_FEAT, 32), 32 * 256, 32);
+    __syncthreads();
+    store_dz<NI, true, true>(acc, g, gr, pk + HB_WA, SPLANE(7), DPLANE(7), jt0 * 32, row0, rows_valid, lane);
+    __syncthreads();
+    // d h_{l-1} = dz_l . W_l (skip layer: hidden columns only), masked by h_{l-1};  l = 7..1
+#pragma unroll 1
+    for (int l = 7; l >= 1; --l) {
+        zero_acc(acc);
+        // packed order after D_FEAT: D_L7, D_L6, D_L5, D_L4, D_L3, D_L2, D_L1
+        mma_run<NI, 2>(acc, g_lane, LDA, pk + bwd_off(D_L7) + (size_t)(7 - l) * W * W + (size_t)jt0 * 32 * 256 + lane * 4,
+                       32 * 256, 32);
+        __syncthreads();
+        store_dz<NI, true, false>(acc, g, gr, nullptr, SPLANE(l - 1), DPLANE(l - 1), jt0 * 32, row0, rows_valid, lane);
+        __syncthreads();
+    }
+#undef SPLANE
+#undef DPLANE
+#undef DBLANE
+}
+
+// ------------------------------------------------------------------------------------
+// backward: weight gradients, split-K TN GEMM  C[o][i] = sum_m A[m][o] B[m][i]
+// ------------------------------------------------------------------------------------
+struct WJob {
+    const float* A;   // dz plane, row stride lda
+    const float* B;   // activation plane, row stride ldb
+    int lda, ldb, O, I;
+    int part_off;     // offset (floats) of this job's [O][I] partial inside a split block
+    int bias_off;     // offset of the [O] bias partial, or -1
+};
+constexpr int MAX_WTILES = 20;
+struct WgradArgs {
+    WJob jobs[10];
+    int tile_job[MAX_WTILES];
+    int tile_o0[MAX_WTILES];
+    int n_rows, rows_per_split;
+    float* part;      // [splits][PART_PER_SPLIT]
+};
+
+// Waves are arranged WO x WI over the workgroup tile; each owns NO x NI 32x32 MFMA tiles.
+// KS k-steps (2 rows each) are loaded per iteration, one iteration ahead of the MFMAs.
+template <int WO, int WI, int NO, int NI, int KS>
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradArgs a) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const WJob job = a.jobs[a.tile_job[blockIdx.x]];
+    const int wo = wave / WI, wi = wave % WI;
+    const int o_base = a.tile_o0[blockIdx.x] + wo * NO * 32;
+    const int i_base = wi * NI * 32;
+    const int split = blockIdx.y;
+    const int m_begin = split * a.rows_per_split;
+    const int m_end = min(a.n_rows, m_begin + a.rows_per_split);
+    const int kh = lane >> 5, ll = lane & 31;
+    const float* Ap = job.A + o_base + ll;
+    const float* Bp = job.B + i_base + ll;
+    f32x16 acc[NO][NI];
+    zero_acc(acc);
+    float bsum[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) bsum[o] = 0.0f;
+    float ac[KS][NO], bc[KS][NI], an[KS][NO], bn[KS][NI];
+
+    auto load = [&](float (&av)[KS][NO], float (&bv)[KS][NI], int m) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int mm = m + 2 * s + kh;
+            const bool ok = mm < m_end;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) av[s][o] = ok ? Ap[(size_t)mm * job.lda + o * 32] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) bv[s][i] = ok ? Bp[(size_t)mm * job.ldb + i * 32] : 0.0f;
+        }
+    };
+    if (m_begin < m_end) load(ac, bc, m_begin);
+    for (int m = m_begin; m < m_end; m += 2 * KS) {
+        if (m + 2 * KS < m_end) load(an, bn, m + 2 * KS);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                bsum[o] += ac[s][o];
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    acc[o][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[s][o], bc[s][i], acc[o][i], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int o = 0; o < NO; ++o) ac[s][o] = an[s][o];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) bc[s][i] = bn[s][i];
+        }
+    }
+    float* part = a.part + (size_t)split * PART_PER_SPLIT;
+    float* cpart = part + job.part_off;
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int orow = o_base + o * 32 + frag_row(r, lane);
+                const int icol = i_base + i * 32 + ll;
+                cpart[(size_t)orow * job.I + icol] = acc[o][i][r];
+            }
+    if (job.bias_off >= 0 && wi == 0) {
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            const float b = bsum[o] + __shfl_xor(bsum[o], 32);
+            if (kh == 0) part[job.bias_off + o_base + o * 32 + ll] = b;
+        }
+    }
+}
+
+// sigma / rgb heads: dW_alpha = sum_m g_sigma h7, dW_rgb[c] = sum_m g_c hv, and their biases
+struct HeadArgs {
+    const float* g_raw;
+    const float* h7;
+    const float* hv;
+    int n_rows, rows_per_wg;
+    float* part;  // [n_wg][HEAD_PART]
+};
+
+__global__ __launch_bounds__(256) void wgrad_head_kernel(HeadArgs a) {
+    __shared__ float red[8][4];
+    __shared__ float rgbred[128][3];
+    const int tid = threadIdx.x;
+    const int m_begin = blockIdx.x * a.rows_per_wg;
+    const int m_end = min(a.n_rows, m_begin + a.rows_per_wg);
+    const float4* g4 = reinterpret_cast<const float4*>(a.g_raw);
+    float wa = 0.0f;                       // column tid of dW_alpha
+    float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f; // column (tid & 127) of dW_rgb, rows of parity (tid >> 7)
+    const int half = tid >> 7, ci = tid & 127;
+    for (int m = m_begin; m < m_end; ++m) {
+        const float4 g = g4[m];
+        wa = fmaf(g.w, a.h7[(size_t)m * W + tid], wa);
+        if (((m - m_begin) & 1) == half) {
+            const float h = a.hv[(size_t)m * HV + ci];
+            r0 = fmaf(g.x, h, r0);
+            r1 = fmaf(g.y, h, r1);
+            r2 = fmaf(g.z, h, r2);
+        }
+    }
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int m = m_begin + tid; m < m_end; m += 256) {
+        const float4 g = g4[m];
+        s0 += g.x; s1 += g.y; s2 += g.z; s3 += g.w;
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+    if ((tid & 63) == 0) { red[tid >> 6][0] = s0; red[tid >> 6][1] = s1; red[tid >> 6][2] = s2; red[tid >> 6][3] = s3; }
+    if (half == 1) { rgbred[ci][0] = r0; rgbred[ci][1] = r1; rgbred[ci][2] = r2; }
+    __syncthreads();
+    float* part = a.part + (size_t)blockIdx.x * HEAD_PART;
+    part[tid] = wa;
+    if (half == 0) {
+        part[256 + 0 * HV + ci] = r0 + rgbred[ci][0];
+        part[256 + 1 * HV + ci] = r1 + rgbred[ci][1];
+        part[256 + 2 * HV + ci] = r2 + rgbred[ci][2];
+    }
+    if (tid < 4) {
+        const float s = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        // layout: [640] = b_alpha, [641..643] = b_rgb
+        part[tid == 3 ? 640 : 641 + tid] = s;
+    }
+}
+
+struct ReduceArgs {
+    const float* part;
+    const float* head_part;
+    int splits, n_head;
+    GradPtrs G;
+};
+
+__global__ void wgrad_reduce_kernel(ReduceArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= PART_PER_SPLIT + HEAD_PART) return;
+    if (idx >= PART_PER_SPLIT) {
+        const int h = idx - PART_PER_SPLIT;
+        if (h >= 644) return;
+        float s = 0.0f;
+        for (int w = 0; w < a.n_head; ++w) s += a.head_part[(size_t)w * HEAD_PART + h];
+        if (h < 256) a.G.p[P_WA][h] = s;
+        else if (h < 640) a.G.p[P_WR][h - 256] = s;
+        else if (h == 640) a.G.p[P_BA][0] = s;
+        else a.G.p[P_BR][h - 641] = s;
+        return;
+    }
+    float s = 0.0f;
+    for (int sp = 0; sp < a.splits; ++sp) s += a.part[(size_t)sp * PART_PER_SPLIT + idx];
+    if (idx < PART_VMAIN) {
+        const int job = idx >> 16, r = idx & 65535, o = r >> 8, i = r & 255;
+        // jobs: L1, L2, L3, L4, L5 (hidden part), L6, L7, feature
+        if (job < 4) a.G.p[2 * (job + 1)][o * W + i] = s;
+        else if (job == 4) a.G.p[10][o * (W + XYZ_CH) + XYZ_CH + i] = s;
+        else if (job < 7) a.G.p[2 * (job + 1)][o * W + i] = s;
+        else a.G.p[P_WF][o * W + i] = s;
+    } else if (idx < PART_PE0) {
+        const int r = idx - PART_VMAIN, o = r >> 8, i = r & 255;
+        a.G.p[P_WV][o * (W + DIR_CH) + i] = s;
+    } else if (idx < PART_PE5) {
+        const int r = idx - PART_PE0, o = r >> 6, i = r & 63;
+        if (i < XYZ_CH) a.G.p[0][o * XYZ_CH + i] = s;
+    } else if (idx < PART_VDIR) {
+        const int r = idx - PART_PE5, o = r >> 6, i = r & 63;
+        if (i < XYZ_CH) a.G.p[10][o * (W + XYZ_CH) + i] = s;
+    } else if (idx < PART_BIAS) {
+        const int r = idx - PART_VDIR, o = r >> 5, i = r & 31;
+        if (i < DIR_CH) a.G.p[P_WV][o * (W + DIR_CH) + W + i] = s;
+    } else {
+        const int r = idx - PART_BIAS;
+        if (r < 8 * W) a.G.p[2 * (r >> 8) + 1][r & 255] = s;
+        else if (r < 9 * W) a.G.p[P_BF][r - 8 * W] = s;
+        else a.G.p[P_BV][r - 9 * W] = s;
+    }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float step_size, float b1, float b2, float eps,
+                            float bc2_sqrt, float gscale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // torch.optim.Adam (single-tensor path): m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2;
+    // denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m / denom
+    const float gi = g[i] * gscale;
+    const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+    const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+}
+
+inline int splits_for(int n_rows) {
+    int s = (n_rows + 1023) / 1024;
+    if (s < 1) s = 1;
+    if (s > MAX_SPLITS) s = MAX_SPLITS;
+    return s;
+}
+inline int head_wgs_for(int n_rows) {
+    int s = (n_rows + 255) / 256;
+    if (s < 1) s = 1;
+    if (s > MAX_HEAD_WGS) s = MAX_HEAD_WGS;
+    return s;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------
+extern "C" size_t plnerf_mlp_packed_bytes(int precision) {
+    if (precision == PLNERF_PREC_FP32) return (size_t)PACKED_FLOATS * sizeof(float);
+    return 0;
+}
+
+extern "C" int plnerf_mlp_pack_weights(const float* const* params, int precision, void* packed,
+                                       plnerf_stream_t stream) {
+    if (!params || !packed) return PLNERF_EINVAL;
+    if (precision != PLNERF_PREC_FP32) return PLNERF_ENOSYS;
+    ParamPtrs P;
+    for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i) {
+        if (!params[i]) return PLNERF_EINVAL;
+        P.p[i] = params[i];
+    }
+    const int threads = 256, blocks = (PACKED_FLOATS + threads - 1) / threads;
+    hipLaunchKernelGGL(pack_f32_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, P, (float*)packed);
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}
+
+extern "C" size_t plnerf_mlp_saved_bytes(int n_rows, int precision) {
+    if (precision != PLNERF_PREC_FP32 || n_rows < 0) return 0;
+    return (size_t)SAVED_PER_ROW * (size_t)n_rows * sizeof(float);
+}
+
+extern "C" size_t plnerf_mlp_bwd_workspace_bytes(int n_rows, int precision) {
+    if (precision != PLNERF_PREC_FP32 || n_rows < 0) return 0;
+    return ((size_t)DZ_PER_ROW * (size_t)n_rows + (size_t)MAX_SPLITS * PART_PER_SPLIT +
+            (size_t)MAX_HEAD_WGS * HEAD_PART) * sizeof(float);
+}
+
+extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pts, const float* viewdirs,
+                              const float* embedded, int n_rows, int samples_per_ray, float* raw_out,
+                              void* saved, plnerf_stream_t stream) {
+    if (precision != PLNERF_PREC_FP32) return PLNERF_ENOSYS;
+    if (!packed || !raw_out || n_rows < 0) return PLNERF_EINVAL;
+    if (!embedded && (!pts || !viewdirs || samples_per_ray < 1)) return PLNERF_EINVAL;
+    if (n_rows == 0) return PLNERF_OK;
+    constexpr int NI = 2, TM = 32 * NI;
+    FwdArgs a{(const float*)packed, pts, viewdirs, embedded, n_rows, samples_per_ray < 1 ? 1 : samples_per_ray,
+              raw_out, (float*)saved};
+    const size_t lds = (size_t)TM * (LDA + LDP + LDD) * sizeof(float);
+    dim3 grid((n_rows + TM - 1) / TM), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (saved) {
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_f32_kernel<NI, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((mlp_fwd_f32_kernel<NI, true>), grid, block, lds, st, a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_f32_kernel<NI, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((mlp_fwd_f32_kernel<NI, false>), grid, block, lds, st, a);
+    }
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}
+
+extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, int n_rows,
+                              const void* saved, void* workspace, float* const* grads,
+                              plnerf_stream_t stream) {
+    if (precision != PLNERF_PREC_FP32) return PLNERF_ENOSYS;
+    if (!packed || !g_raw || !saved || !workspace || !grads || n_rows < 1) return PLNERF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t N = (size_t)n_rows;
+    const float* sv = (const float*)saved;
+    float* dz = (float*)workspace;
+    float* part = dz + (size_t)DZ_PER_ROW * N;
+    float* head_part = part + (size_t)MAX_SPLITS * PART_PER_SPLIT;
+
+    // 1. dgrad chain
+    {
+        constexpr int NI = 2, TM = 32 * NI;
+        BwdArgs a{(const float*)packed, g_raw, n_rows, sv, dz};
+        const size_t lds = (size_t)(TM * LDA + TM * 4) * sizeof(float);
+        (void)hipFuncSetAttribute((const void*)mlp_bwd_f32_kernel<NI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        hipLaunchKernelGGL((mlp_bwd_f32_kernel<NI>), dim3((n_rows + TM - 1) / TM), dim3(256), lds, st, a);
+        PLNERF_CHECK_LAUNCH();
+    }
+    // 2. weight gradients (split-K partials)
+    const int splits = splits_for(n_rows);
+    int rps = (n_rows + splits - 1) / splits;
+    rps = (rps + 15) & ~15;
+    auto splane = [&](int p) { return sv + (size_t)p * W * N; };
+    auto dplane = [&](int p) { return dz + (size_t)p * W * N; };
+    const float* hv_plane = sv + (size_t)SV_HV_OFF * N;
+    const float* pe_plane = sv + (size_t)SV_PE_OFF * N;
+    const float* dpe_plane = sv + (size_t)SV_DPE_OFF * N;
+    const float* dzv_plane = dz + (size_t)DZ_V_OFF * N;
+    {
+        // main: 128(o) x 256(i) workgroup tiles
+        WgradArgs a{};
+        const int layer_of_job[8] = {1, 2, 3, 4, 5, 6, 7, -1};
+        int nt = 0;
+        for (int j = 0; j < 8; ++j) {
+            WJob& jb = a.jobs[j];
+            if (j < 7) {
+                const int l = layer_of_job[j];
+                jb.A = dplane(l);
+                jb.B = splane(l - 1);
+                jb.bias_off = PART_BIAS + l * W;
+            } else {
+                jb.A = dplane(DZ_FEAT);
+                jb.B = splane(7);
+                jb.bias_off = PART_BIAS + 8 * W;
+            }
+            jb.lda = W; jb.ldb = W; jb.O = W; jb.I = W;
+            jb.part_off = PART_MAIN + j * W * W;
+            a.tile_job[nt] = j; a.tile_o0[nt++] = 0;
+            a.tile_job[nt] = j; a.tile_o0[nt++] = 128;
+        }
+        WJob& jv = a.jobs[8];
+        jv.A = dzv_plane; jv.lda = HV; jv.B = splane(SV_FEAT); jv.ldb = W; jv.O = HV; jv.I = W;
+        jv.part_off = PART_VMAIN; jv.bias_off = PART_BIAS + 9 * W;
+        a.tile_job[nt] = 8; a.tile_o0[nt++] = 0;
+        a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
+        hipLaunchKernelGGL((wgrad_f32_kernel<2, 2, 2, 4, 4>), dim3(nt, splits), dim3(256), 0, st, a);
+        PLNERF_CHECK_LAUNCH();
+    }
+    {
+        // encoding parts: 256(o) x 64(i)
+        WgradArgs a{};
+        a.jobs[0] = WJob{dplane(0), pe_plane, W, PE_K, W, PE_K, PART_PE0, PART_BIAS + 0 * W};
+        a.jobs[1] = WJob{dplane(5), pe_plane, W, PE_K, W, PE_K, PART_PE5, -1};
+        a.tile_job[0] = 0; a.tile_o0[0] = 0;
+        a.tile_job[1] = 1; a.tile_o0[1] = 0;
+        a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
+        hipLaunchKernelGGL((wgrad_f32_kernel<4, 1, 2, 2, 4>), dim3(2, splits), dim3(256), 0, st, a);
+        PLNERF_CHECK_LAUNCH();
+    }
+    {
+        // view layer, direction-encoding part: 128(o) x 32(i)
+        WgradArgs a{};
+        a.jobs[0] = WJob{dzv_plane, dpe_plane, HV, DPE_K, HV, DPE_K, PART_VDIR, -1};
+        a.tile_job[0] = 0; a.tile_o0[0] = 0;
+        a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
+        hipLaunchKernelGGL((wgrad_f32_kernel<4, 1, 1, 1, 8>), dim3(1, splits), dim3(256), 0, st, a);
+        PLNERF_CHECK_LAUNCH();
+    }
+    const int n_head = head_wgs_for(n_rows);
+    {
+        HeadArgs a{g_raw, splane(7), hv_plane, n_rows, (n_rows + n_head - 1) / n_head, head_part};
+        hipLaunchKernelGGL(wgrad_head_kernel, dim3(n_head), dim3(256), 0, st, a);
+        PLNERF_CHECK_LAUNCH();
+    }
+    // 3. deterministic reduction into the 24 gradient tensors
+    {
+        ReduceArgs a{};
+        a.part = part; a.head_part = head_part; a.splits = splits; a.n_head = n_head;
+        for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i) {
+            if (!grads[i]) return PLNERF_EINVAL;
+            a.G.p[i] = grads[i];
+        }
+        const int total = PART_PER_SPLIT + HEAD_PART;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a);
+        PLNERF_CHECK_LAUNCH();
+    }
+    return PLNERF_OK;
+}
+
+extern "C" int plnerf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                int64_t n, float lr, float beta1, float beta2, float eps, int step,
+                                float grad_scale, plnerf_stream_t stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return PLNERF_EINVAL;
+    if (n == 0) return PLNERF_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const int threads = 256;
+    const int64_t blocks = (n + threads - 1) / threads;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, param, grad,
+                       exp_avg, exp_avg_sq, n, (float)((double)lr / bc1), beta1, beta2, eps, (float)sqrt(bc2), grad_scale);
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}

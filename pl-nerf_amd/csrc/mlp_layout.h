@@ -1,0 +1,101 @@
+// Static geometry of the PL-NeRF MLP (run_nerf_helpers.py:76-128 at the reference's default
+// flags) and of the buffers the fp32 MFMA kernels exchange.  Host and device code share this.
+//
+// Layers as GEMMs (y = x W^T + b; weight tensors are [out][in]):
+//   L0  63->256 | L1..L4 256->256 | L5 (63+256)->256, encoding channels first | L6,L7 256->256
+//   sigma 256->1 (from h7) | feature 256->256 (from h7, no activation)
+//   view layer (256 feature + 27 direction encoding)->128, relu | rgb 128->3
+// K is padded to a multiple of 8 (one MFMA chunk): encodings 63->64 and 27->32.
+#pragma once
+
+namespace plnerf {
+namespace lay {
+
+constexpr int W = 256;        // trunk width
+constexpr int HV = 128;       // view-layer width
+constexpr int XYZ_CH = 63;    // 3 + 6*10
+constexpr int DIR_CH = 27;    // 3 + 6*4
+constexpr int PE_K = 64;      // padded xyz encoding
+constexpr int DPE_K = 32;     // padded direction encoding
+constexpr int XYZ_FREQS = 10;
+constexpr int DIR_FREQS = 4;
+constexpr int EMB_CH = XYZ_CH + DIR_CH;  // 90
+
+// state_dict order of the 24 parameter tensors
+enum ParamIdx {
+    P_W0 = 0, P_B0 = 1,  // pts_linears.i.weight = 2i, .bias = 2i+1 (i = 0..7)
+    P_WV = 16, P_BV = 17, P_WF = 18, P_BF = 19, P_WA = 20, P_BA = 21, P_WR = 22, P_BR = 23
+};
+
+// ---- packed weights, fp32 mode ------------------------------------------------------
+// A GEMM's B operand (logical B[k][j], K x N) is stored as 1 KiB blocks, one per (32-wide
+// j tile, 8-deep k chunk), block order [jt][kc]; inside a block lane l = (kh<<5 | jj) owns 4
+// consecutive floats t = 0..3 holding B[kc*8 + kh*4 + t][jt*32 + jj].  A wavefront reads one
+// block with a single coalesced 16-byte-per-lane load and feeds v_mfma_f32_32x32x2_f32 step t
+// with register t; the matching A fragment is one 16-byte LDS read of
+// A[row][kc*8 + kh*4 .. +3].
+enum FwdGemm { G_L0 = 0, G_L1, G_L2, G_L3, G_L4, G_L5, G_L6, G_L7, G_FEAT, G_VIEWS, N_FWD };
+constexpr int fwd_K[N_FWD] = {64, 256, 256, 256, 256, 320, 256, 256, 256, 288};
+constexpr int fwd_N[N_FWD] = {256, 256, 256, 256, 256, 256, 256, 256, 256, 128};
+
+// dgrad: dh_in[m][i] = sum_o dz[m][o] W[o][col0+i]  -> B[k=o][j=i]
+enum BwdGemm { D_VIEWS = 0, D_FEAT, D_L7, D_L6, D_L5, D_L4, D_L3, D_L2, D_L1, N_BWD };
+constexpr int bwd_K[N_BWD] = {128, 256, 256, 256, 256, 256, 256, 256, 256};
+constexpr int bwd_N[N_BWD] = {256, 256, 256, 256, 256, 256, 256, 256, 256};
+
+constexpr int fwd_off(int g) {
+    int o = 0;
+    for (int i = 0; i < g; ++i) o += fwd_K[i] * fwd_N[i];
+    return o;
+}
+constexpr int FWD_FLOATS = fwd_off(N_FWD);  // 593,920
+
+// head block: biases and the two thin output layers, kept in original order
+constexpr int HB = FWD_FLOATS;
+constexpr int HB_BIAS = HB;                  // b0..b7: 8 x 256
+constexpr int HB_BF = HB_BIAS + 8 * W;       // feature bias 256
+constexpr int HB_BV = HB_BF + W;             // view-layer bias 128
+constexpr int HB_WA = HB_BV + HV;            // sigma weight 256
+constexpr int HB_BA = HB_WA + W;             // sigma bias 1 (+3 pad)
+constexpr int HB_WR = HB_BA + 4;             // rgb weight 3 x 128
+constexpr int HB_BR = HB_WR + 3 * HV;        // rgb bias 3 (+1 pad)
+constexpr int HB_END = HB_BR + 4;
+
+constexpr int BWD = HB_END;
+constexpr int bwd_off(int g) {
+    int o = BWD;
+    for (int i = 0; i < g; ++i) o += bwd_K[i] * bwd_N[i];
+    return o;
+}
+constexpr int PACKED_FLOATS = bwd_off(N_BWD);
+
+// ---- forward state saved for backward (floats per row, plane-major: plane p starts at
+// plane_off(p) * n_rows) ---------------------------------------------------------------
+// planes 0..7 = h0..h7 (post-relu), 8 = feature, then hv [128], pe [64], dpe [32]
+constexpr int SV_FEAT = 8;
+constexpr int SV_HV_OFF = 9 * W;             // floats-per-row offset of the hv plane
+constexpr int SV_PE_OFF = SV_HV_OFF + HV;
+constexpr int SV_DPE_OFF = SV_PE_OFF + PE_K;
+constexpr int SAVED_PER_ROW = SV_DPE_OFF + DPE_K;   // 2528
+
+// ---- backward workspace: pre-activation gradients, planes 0..7 = dz0..dz7, 8 = dz_feature,
+// then dz_view [128] ----------------------------------------------------------------------
+constexpr int DZ_FEAT = 8;
+constexpr int DZ_V_OFF = 9 * W;
+constexpr int DZ_PER_ROW = DZ_V_OFF + HV;    // 2432
+
+// split-K partial sums of the weight gradients (per split)
+constexpr int WG_MAIN_JOBS = 8;              // L1..L4, L5 (hidden part), L6, L7, feature
+constexpr int PART_MAIN = 0;                                   // 8 x [256][256]
+constexpr int PART_VMAIN = PART_MAIN + WG_MAIN_JOBS * W * W;   // [128][256]
+constexpr int PART_PE0 = PART_VMAIN + HV * W;                  // L0:  [256][64]
+constexpr int PART_PE5 = PART_PE0 + W * PE_K;                  // L5 encoding part: [256][64]
+constexpr int PART_VDIR = PART_PE5 + W * PE_K;                 // view layer direction part [128][32]
+constexpr int PART_BIAS = PART_VDIR + HV * DPE_K;              // b0..b7, bf: 9 x 256, bv: 128
+constexpr int PART_PER_SPLIT = PART_BIAS + 9 * W + HV;
+constexpr int MAX_SPLITS = 128;
+constexpr int HEAD_PART = 648;               // per-workgroup partial of the sigma/rgb heads
+constexpr int MAX_HEAD_WGS = 512;
+
+}  // namespace lay
+}  // namespace plnerf

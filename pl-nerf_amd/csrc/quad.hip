@@ -1,0 +1,372 @@
+// Quadrature kernels: raw2outputs forward and its backward with respect to `raw`.
+//
+// Reference semantics: run_plnerf.py:553-624 (raw2outputs), :516-550
+// (compute_weights_piecewise_linear), :504-513 (compute_weights).  HBM-bound streaming
+// scan: one 64-lane wavefront owns one ray, reads its (z, raw) rows with coalesced
+// 16-byte loads, keeps the ray's knots in LDS, and does the transmittance prefix product
+// as a wave scan (fp64 carry, like the reference's CPU cumprod) -- nothing is re-read
+// from HBM.  Algorithmic bytes per ray (linear): 32*S+64.
+#include "common.h"
+
+using namespace plnerf;
+
+namespace {
+
+constexpr int WAVES = 4;  // rays per 256-thread workgroup
+
+struct QuadArgs {
+    const float* raw;
+    const float* z;
+    const float* near;
+    const float* far;
+    const float* rays_d;
+    const float* noise;
+    int R, S;
+    int color_mode, white_bkgd, farcolorfix;
+    int lds_stride;  // floats per wave
+    // forward outputs
+    float* rgb_map;
+    float* disp_map;
+    float* acc_map;
+    float* depth_map;
+    float* weights;
+    float* tau;
+    float* T;
+    // backward inputs / output
+    const float* g_rgb;
+    const float* g_depth;
+    const float* g_acc;
+    const float* g_weights;
+    float* g_raw;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Loads one ray into LDS: knots zk[0..S+1] = [near, z, far], tau[0..S+1] =
+// relu([1e-10, sigma+noise, 1e10]), col[3*s+c] = sigmoid(raw rgb).
+__device__ __forceinline__ void load_ray(const QuadArgs& a, int ray, int lane, float* zk, float* tau,
+                                         float* col, float& dnorm) {
+    const int S = a.S;
+    const float4* raw4 = reinterpret_cast<const float4*>(a.raw) + (size_t)ray * S;
+    const float* zrow = a.z + (size_t)ray * S;
+    const float* nrow = a.noise ? a.noise + (size_t)ray * S : nullptr;
+    for (int s = lane; s < S; s += 64) {
+        const float4 r = raw4[s];
+        float sg = r.w;
+        if (nrow) sg = sg + nrow[s];
+        col[3 * s + 0] = sigmoidf_(r.x);
+        col[3 * s + 1] = sigmoidf_(r.y);
+        col[3 * s + 2] = sigmoidf_(r.z);
+        tau[s + 1] = tmax(sg, 0.0f);
+        zk[s + 1] = zrow[s];
+    }
+    if (lane == 0) {
+        zk[0] = a.near[ray];
+        zk[S + 1] = a.far[ray];
+        tau[0] = 1e-10f;
+        tau[S + 1] = 1e10f;
+    }
+    const float dx = a.rays_d[3 * ray + 0], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
+    dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+// Element i of the scan: e_i (the interval's exp term) and f_i (its transmittance factor).
+template <int MODE>
+__device__ __forceinline__ void interval(int i, int S, const float* zk, const float* tau, float dnorm,
+                                         float& seg, float& e, float& f) {
+    if (MODE == PLNERF_MODE_LINEAR) {
+        seg = (zk[i + 1] - zk[i]) * dnorm;
+        const float ave = 0.5f * (tau[i + 1] + tau[i]);
+        e = expf((-ave) * seg);
+        f = e;
+    } else {
+        seg = ((i < S - 1) ? (zk[i + 2] - zk[i + 1]) : 1e10f) * dnorm;
+        e = expf((-tau[i + 1]) * seg);
+        const float alpha = 1.0f - e;
+        f = 1.0f - alpha + 1e-10f;
+    }
+}
+
+// Colour attached to element i, per channel c (the reference's padded-colour rules).
+template <int MODE>
+__device__ __forceinline__ float elem_colour(int i, int c, int S, const float* col, int color_mode,
+                                             int farcolorfix) {
+    if (MODE == PLNERF_MODE_LINEAR) {
+        const float left = col[3 * (i > 0 ? i - 1 : 0) + c];  // padded[i]
+        if (color_mode == PLNERF_COLOR_LEFT) return left;
+        float right;                                           // padded[i+1]
+        if (i < S) right = col[3 * i + c];
+        else right = farcolorfix ? 0.0f : col[3 * (S - 1) + c];
+        return 0.5f * (right + left);
+    }
+    return col[3 * i + c];
+}
+
+template <int MODE>
+__device__ __forceinline__ float elem_depth(int i, const float* zk) {
+    return (MODE == PLNERF_MODE_LINEAR) ? 0.5f * (zk[i + 1] + zk[i]) : zk[i + 1];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void quad_fwd_kernel(QuadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int ray = blockIdx.x * WAVES + wave;
+    const bool live = ray < a.R;
+    if (!live) ray = a.R - 1;
+    const int S = a.S;
+    float* zk = smem + wave * a.lds_stride;
+    float* tau = zk + (S + 2);
+    float* col = tau + (S + 2);
+    float dnorm;
+    load_ray(a, ray, lane, zk, tau, col, dnorm);
+    __syncthreads();
+
+    const int n = (MODE == PLNERF_MODE_LINEAR) ? S + 1 : S;
+    double carry = 1.0;
+    double sr = 0, sg = 0, sb = 0, sd = 0, sa = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool valid = i < n;
+        float seg = 0.f, e = 1.f, f = 1.f;
+        if (valid) interval<MODE>(i, S, zk, tau, dnorm, seg, e, f);
+        const double incl = wave_incl_prod((double)f);
+        double excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.0;
+        const float Ti = (float)(carry * excl);
+        const float Tn = (float)(carry * incl);
+        carry = carry * __shfl(incl, 63);
+        if (valid) {
+            const float w = (1.0f - e) * Ti;
+            sr += (double)(w * elem_colour<MODE>(i, 0, S, col, a.color_mode, a.farcolorfix));
+            sg += (double)(w * elem_colour<MODE>(i, 1, S, col, a.color_mode, a.farcolorfix));
+            sb += (double)(w * elem_colour<MODE>(i, 2, S, col, a.color_mode, a.farcolorfix));
+            sd += (double)(w * elem_depth<MODE>(i, zk));
+            sa += (double)w;
+            if (live) {
+                if (a.weights) a.weights[(size_t)ray * n + i] = w;
+                if (MODE == PLNERF_MODE_LINEAR && a.T) a.T[(size_t)ray * (S + 2) + i + 1] = Tn;
+            }
+        }
+    }
+    if (MODE == PLNERF_MODE_LINEAR && live) {
+        if (a.T && lane == 0) a.T[(size_t)ray * (S + 2)] = 1.0f;
+        if (a.tau)
+            for (int s = lane; s < S + 2; s += 64) a.tau[(size_t)ray * (S + 2) + s] = tau[s];
+    }
+    sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd); sa = wave_sum(sa);
+    if (live && lane == 0) {
+        const float acc = (float)sa, depth = (float)sd;
+        float r = (float)sr, g = (float)sg, b = (float)sb;
+        if (a.white_bkgd) {
+            const float bg = 1.0f - acc;
+            r += bg; g += bg; b += bg;
+        }
+        a.rgb_map[3 * ray + 0] = r;
+        a.rgb_map[3 * ray + 1] = g;
+        a.rgb_map[3 * ray + 2] = b;
+        a.depth_map[ray] = depth;
+        a.acc_map[ray] = acc;
+        a.disp_map[ray] = 1.0f / tmax(1e-10f, depth / acc);
+    }
+}
+
+// Backward.  With w_i = (1-e_i) T_i and T_i = prod_{j<i} f_j:
+//   dL/de_k = T_k (X_k - G_k),  X_k = sum_{i>k} G_i (1-e_i) prod_{k<j<i} f_j
+// (division-free, so exact even when some e_k underflows to 0, like autograd's cumprod
+// backward).  X obeys the reverse recurrence X_k = G_{k+1}(1-e_{k+1}) + f_{k+1} X_{k+1},
+// evaluated as a wave scan over affine maps.
+template <int MODE>
+__global__ __launch_bounds__(256) void quad_bwd_kernel(QuadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int ray = blockIdx.x * WAVES + wave;
+    const bool live = ray < a.R;
+    if (!live) ray = a.R - 1;
+    const int S = a.S;
+    const int n = (MODE == PLNERF_MODE_LINEAR) ? S + 1 : S;
+    float* zk = smem + wave * a.lds_stride;
+    float* tau = zk + (S + 2);
+    float* col = tau + (S + 2);
+    float* fv = col + 3 * S;     // f_i (fv[n] = 1)
+    float* av = fv + (n + 1);    // G_i (1 - e_i)  (av[n] = 0)
+    float* wv = av + (n + 1);    // w_i
+    float* qv = wv + (n + 1);    // T_i, then Q_i = dL/de_i * seg_i * e_i
+    float dnorm;
+    load_ray(a, ray, lane, zk, tau, col, dnorm);
+    const float gr = a.g_rgb[3 * ray + 0], gg = a.g_rgb[3 * ray + 1], gb = a.g_rgb[3 * ray + 2];
+    const float gdep = a.g_depth ? a.g_depth[ray] : 0.0f;
+    float gacc = a.g_acc ? a.g_acc[ray] : 0.0f;
+    if (a.white_bkgd) gacc -= (gr + gg + gb);
+    __syncthreads();
+
+    // pass 1: forward scan, stash per-element terms
+    double carry = 1.0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool valid = i < n;
+        float seg = 0.f, e = 1.f, f = 1.f;
+        if (valid) interval<MODE>(i, S, zk, tau, dnorm, seg, e, f);
+        const double incl = wave_incl_prod((double)f);
+        double excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.0;
+        const float Ti = (float)(carry * excl);
+        carry = carry * __shfl(incl, 63);
+        if (valid) {
+            float G = gr * elem_colour<MODE>(i, 0, S, col, a.color_mode, a.farcolorfix) +
+                      gg * elem_colour<MODE>(i, 1, S, col, a.color_mode, a.farcolorfix) +
+                      gb * elem_colour<MODE>(i, 2, S, col, a.color_mode, a.farcolorfix) +
+                      gdep * elem_depth<MODE>(i, zk) + gacc;
+            if (a.g_weights) G += a.g_weights[(size_t)ray * n + i];
+            fv[i] = f;
+            av[i] = G * (1.0f - e);
+            wv[i] = (1.0f - e) * Ti;
+            qv[i] = Ti;   // G_i and seg_i are recomputed in pass 2 (cheaper than two more LDS rows)
+        }
+    }
+    if (lane == 0) { fv[n] = 1.0f; av[n] = 0.0f; }
+    __syncthreads();
+
+    // pass 2: reverse affine scan.  Position p = n-1-i ascending <=> i descending;
+    // y_p = A_p + F_p y_{p-1} with A_p = av[i+1], F_p = fv[i+1], y_{-1} = 0.
+    float ycarry = 0.0f;
+    for (int base = 0; base < n; base += 64) {
+        const int p = base + lane;
+        const bool valid = p < n;
+        const int i = n - 1 - p;
+        float A = 0.0f, F = 1.0f;
+        if (valid) { A = av[i + 1]; F = fv[i + 1]; }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float Alo = __shfl_up(A, d), Flo = __shfl_up(F, d);
+            if (lane >= d) { A = A + F * Alo; F = F * Flo; }
+        }
+        const float X = A + F * ycarry;            // X_i
+        ycarry = __shfl(X, 63);
+        if (valid) {
+            float seg, e, f;
+            interval<MODE>(i, S, zk, tau, dnorm, seg, e, f);
+            // (G_i = av[i] / (1-e_i) would divide by zero when e_i == 1: recompute it)
+            float G = gr * elem_colour<MODE>(i, 0, S, col, a.color_mode, a.farcolorfix) +
+                      gg * elem_colour<MODE>(i, 1, S, col, a.color_mode, a.farcolorfix) +
+                      gb * elem_colour<MODE>(i, 2, S, col, a.color_mode, a.farcolorfix) +
+                      gdep * elem_depth<MODE>(i, zk) + gacc;
+            if (a.g_weights) G += a.g_weights[(size_t)ray * n + i];
+            const float Ti = qv[i];
+            const float dLde = Ti * (X - G);
+            qv[i] = dLde * seg * e;                // Q_i
+        }
+    }
+    __syncthreads();
+
+    // pass 3: per-sample gradients
+    if (live) {
+        float4* out = reinterpret_cast<float4*>(a.g_raw) + (size_t)ray * S;
+        for (int s = lane; s < S; s += 64) {
+            float gtau, coef;
+            if (MODE == PLNERF_MODE_LINEAR) {
+                gtau = -0.5f * (qv[s + 1] + qv[s]);
+                if (a.color_mode == PLNERF_COLOR_MIDPOINT) {
+                    coef = 0.5f * (wv[s] + wv[s + 1]);
+                    if (s == 0) coef += 0.5f * wv[0];
+                    if (s == S - 1 && !a.farcolorfix) coef += 0.5f * wv[S];
+                } else {
+                    coef = wv[s + 1];
+                    if (s == 0) coef += wv[0];
+                }
+            } else {
+                gtau = -qv[s];
+                coef = wv[s];
+            }
+            const float c0 = col[3 * s + 0], c1 = col[3 * s + 1], c2 = col[3 * s + 2];
+            float4 g;
+            g.x = gr * coef * (c0 * (1.0f - c0));
+            g.y = gg * coef * (c1 * (1.0f - c1));
+            g.z = gb * coef * (c2 * (1.0f - c2));
+            g.w = (tau[s + 1] > 0.0f) ? gtau : 0.0f;
+            out[s] = g;
+        }
+    }
+}
+
+int check_common(const float* raw, const float* z, const float* near, const float* far,
+                 const float* rays_d, int R, int S, int mode, int color_mode) {
+    if (!raw || !z || !near || !far || !rays_d) return PLNERF_EINVAL;
+    if (R < 0 || S < 2) return PLNERF_EINVAL;
+    if (S > PLNERF_MAX_SAMPLES) return PLNERF_ERANGE;
+    if (mode != PLNERF_MODE_LINEAR && mode != PLNERF_MODE_CONSTANT) return PLNERF_EINVAL;
+    if (color_mode != PLNERF_COLOR_MIDPOINT && color_mode != PLNERF_COLOR_LEFT) return PLNERF_EINVAL;
+    return PLNERF_OK;
+}
+
+}  // namespace
+
+extern "C" int plnerf_quad_fwd(const float* raw, const float* z, const float* near, const float* far,
+                               const float* rays_d, const float* noise, int R, int S, int mode,
+                               int color_mode, int white_bkgd, int farcolorfix, float* rgb_map,
+                               float* disp_map, float* acc_map, float* depth_map, float* weights,
+                               float* tau, float* T, plnerf_stream_t stream) {
+    int rc = check_common(raw, z, near, far, rays_d, R, S, mode, color_mode);
+    if (rc) return rc;
+    if (!rgb_map || !disp_map || !acc_map || !depth_map) return PLNERF_EINVAL;
+    if (R == 0) return PLNERF_OK;
+    QuadArgs a{};
+    a.raw = raw; a.z = z; a.near = near; a.far = far; a.rays_d = rays_d; a.noise = noise;
+    a.R = R; a.S = S; a.color_mode = color_mode; a.white_bkgd = white_bkgd; a.farcolorfix = farcolorfix;
+    a.rgb_map = rgb_map; a.disp_map = disp_map; a.acc_map = acc_map; a.depth_map = depth_map;
+    a.weights = weights; a.tau = tau; a.T = T;
+    a.lds_stride = ((5 * S + 4) + 3) & ~3;
+    const size_t lds = (size_t)WAVES * a.lds_stride * sizeof(float);
+    dim3 grid((R + WAVES - 1) / WAVES), block(WAVES * 64);
+    hipStream_t st = (hipStream_t)stream;
+    if (lds > 160 * 1024) return PLNERF_ERANGE;
+    if (lds > 64 * 1024) {
+        if (mode == PLNERF_MODE_LINEAR)
+            (void)hipFuncSetAttribute((const void*)quad_fwd_kernel<PLNERF_MODE_LINEAR>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else
+            (void)hipFuncSetAttribute((const void*)quad_fwd_kernel<PLNERF_MODE_CONSTANT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    if (mode == PLNERF_MODE_LINEAR)
+        hipLaunchKernelGGL(quad_fwd_kernel<PLNERF_MODE_LINEAR>, grid, block, lds, st, a);
+    else
+        hipLaunchKernelGGL(quad_fwd_kernel<PLNERF_MODE_CONSTANT>, grid, block, lds, st, a);
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}
+
+extern "C" int plnerf_quad_bwd(const float* raw, const float* z, const float* near, const float* far,
+                               const float* rays_d, const float* noise, int R, int S, int mode,
+                               int color_mode, int white_bkgd, int farcolorfix, const float* g_rgb,
+                               const float* g_depth, const float* g_acc, const float* g_weights,
+                               float* g_raw, plnerf_stream_t stream) {
+    int rc = check_common(raw, z, near, far, rays_d, R, S, mode, color_mode);
+    if (rc) return rc;
+    if (!g_rgb || !g_raw) return PLNERF_EINVAL;
+    if (R == 0) return PLNERF_OK;
+    QuadArgs a{};
+    a.raw = raw; a.z = z; a.near = near; a.far = far; a.rays_d = rays_d; a.noise = noise;
+    a.R = R; a.S = S; a.color_mode = color_mode; a.white_bkgd = white_bkgd; a.farcolorfix = farcolorfix;
+    a.g_rgb = g_rgb; a.g_depth = g_depth; a.g_acc = g_acc; a.g_weights = g_weights; a.g_raw = g_raw;
+    a.lds_stride = ((5 * S + 4 + 4 * (S + 2)) + 3) & ~3;
+    const size_t lds = (size_t)WAVES * a.lds_stride * sizeof(float);
+    dim3 grid((R + WAVES - 1) / WAVES), block(WAVES * 64);
+    hipStream_t st = (hipStream_t)stream;
+    if (lds > 160 * 1024) return PLNERF_ERANGE;
+    if (lds > 64 * 1024) {
+        // opt in to the large dynamic-LDS carve-out (S > ~400)
+        if (mode == PLNERF_MODE_LINEAR)
+            (void)hipFuncSetAttribute((const void*)quad_bwd_kernel<PLNERF_MODE_LINEAR>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else
+            (void)hipFuncSetAttribute((const void*)quad_bwd_kernel<PLNERF_MODE_CONSTANT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    if (mode == PLNERF_MODE_LINEAR)
+        hipLaunchKernelGGL(quad_bwd_kernel<PLNERF_MODE_LINEAR>, grid, block, lds, st, a);
+    else
+        hipLaunchKernelGGL(quad_bwd_kernel<PLNERF_MODE_CONSTANT>, grid, block, lds, st, a);
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}

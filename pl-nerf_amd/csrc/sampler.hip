@@ -1,0 +1,327 @@
+// Hierarchical samplers and the per-ray merge sort.
+//
+//   plnerf_sample_const : sample_pdf                    (run_nerf_helpers.py:241-284)
+//   plnerf_sample_pl    : sample_pdf_reformulation      (run_nerf_helpers.py:364-445)
+//                         + pw_linear_sample_{in,de}creasing (:340-361)
+//   plnerf_merge_sort   : clamp + cat + sort            (run_plnerf.py:731-734)
+//
+// One wavefront per ray.  The ray's cdf / knots / tau / T rows are read once with
+// coalesced loads and kept in LDS; the cdf is a wave prefix scan; every lane then inverts
+// the cdf for its own u by bisection in LDS.  HBM-bound; algorithmic bytes per ray:
+// 4(4S+7+N)+4N (PL sampler), 8(S+N) (merge sort)  (SURVEY.md section 8d).
+//
+// Compiled with -ffp-contract=off: the reference evaluates every product and sum as a
+// separately rounded fp32 op (eager PyTorch), and the bit-exact index contract of
+// plnerf_sample_const depends on that.
+#include "common.h"
+
+using namespace plnerf;
+
+namespace {
+
+constexpr int WAVES = 4;
+
+// torch.searchsorted(cdf, u, right=True): the same upper-bound bisection as ATen's
+// (mid = start + ((end-start) >> 1); !(cdf[mid] > u) -> go right), so the result agrees
+// even on a cdf that is non-monotone by an ulp.
+__device__ __forceinline__ int upper_bound(const float* cdf, int len, float u) {
+    int start = 0, end = len;
+    while (start < end) {
+        const int mid = start + ((end - start) >> 1);
+        if (!(cdf[mid] > u)) start = mid + 1;
+        else end = mid;
+    }
+    return start;
+}
+
+// fp32 row sum with the association order of torch.sum's vectorised CPU kernel (8-lane
+// vectors, 4 interleaved accumulators, leftover vectors into accumulator 0,
+// ((a0+a1)+a2)+a3, then the scalar tail first and the 8 vector lanes after it).
+// Verified against torch 2.10 CPU for every n in {1..4, 8..510} (tests + DESIGN.md).
+// Lanes 0..7 of the wave play the 8 SIMD lanes; result is broadcast to the wave.
+__device__ __forceinline__ float torch_row_sum(const float* x, int n, int lane) {
+    const int nvec = n >> 3;
+    const int g4 = nvec & ~3;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (lane < 8) {
+        for (int v = 0; v < g4; v += 4) {
+            a0 = a0 + x[(v + 0) * 8 + lane];
+            a1 = a1 + x[(v + 1) * 8 + lane];
+            a2 = a2 + x[(v + 2) * 8 + lane];
+            a3 = a3 + x[(v + 3) * 8 + lane];
+        }
+        for (int v = g4; v < nvec; ++v) a0 = a0 + x[v * 8 + lane];
+        a0 = a0 + a1;
+        a0 = a0 + a2;
+        a0 = a0 + a3;
+    }
+    float total = 0.f;
+    for (int e = nvec * 8; e < n; ++e) total = total + x[e];   // uniform across lanes
+#pragma unroll
+    for (int l = 0; l < 8; ++l) total = total + __shfl(a0, l);
+    return total;
+}
+
+struct SampleConstArgs {
+    const float* bins;
+    const float* weights;
+    const float* u;
+    int u_row_stride;
+    int R, B, N;
+    int lds_stride;
+    float* samples;
+    int64_t* inds;
+};
+
+__global__ __launch_bounds__(256) void sample_const_kernel(SampleConstArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int ray = blockIdx.x * WAVES + wave;
+    const bool live = ray < a.R;
+    if (!live) ray = a.R - 1;
+    const int B = a.B, n = a.B - 1;
+    float* cdf = smem + wave * a.lds_stride;   // B entries
+    float* bins = cdf + B;                      // B entries
+    float* wv = bins + B;                       // n entries (weights + 1e-5)
+    for (int j = lane; j < B; j += 64) bins[j] = a.bins[(size_t)ray * B + j];
+    for (int j = lane; j < n; j += 64) wv[j] = a.weights[(size_t)ray * n + j] + 1e-5f;
+    __syncthreads();
+    const float total = torch_row_sum(wv, n, lane);
+    // cdf = [0, cumsum(pdf)]: fp64 running sum, each entry rounded to fp32
+    double carry = 0.0;
+    for (int base = 0; base < n; base += 64) {
+        const int j = base + lane;
+        const float pdf = (j < n) ? wv[j] / total : 0.0f;
+        const double incl = wave_incl_sum((double)pdf);
+        if (j < n) cdf[j + 1] = (float)(carry + incl);
+        carry = carry + __shfl(incl, 63);
+    }
+    if (lane == 0) cdf[0] = 0.0f;
+    __syncthreads();
+    if (!live) return;
+    const float* urow = a.u + (size_t)ray * a.u_row_stride;
+    for (int k = lane; k < a.N; k += 64) {
+        const float u = urow[k];
+        const int ind = upper_bound(cdf, B, u);
+        const int below = ind - 1 > 0 ? ind - 1 : 0;
+        const int above = ind < B - 1 ? ind : B - 1;
+        const float c0 = cdf[below], c1 = cdf[above];
+        float denom = c1 - c0;
+        if (denom < 1e-5f) denom = 1.0f;
+        const float t = (u - c0) / denom;
+        const float b0 = bins[below], b1 = bins[above];
+        a.samples[(size_t)ray * a.N + k] = b0 + t * (b1 - b0);
+        if (a.inds) a.inds[(size_t)ray * a.N + k] = (int64_t)ind;
+    }
+}
+
+struct SamplePlArgs {
+    const float* z;
+    const float* weights;
+    const float* tau;
+    const float* T;
+    const float* near;
+    const float* far;
+    const float* u;
+    int u_row_stride;
+    int R, S, N;
+    int lds_stride;
+    float zero_tol, eps;
+    float* samples;
+    float* T_below;
+    float* tau_below;
+    float* bin_below;
+    int64_t* inds;
+};
+
+// Closed-form inverse of T0 * exp(-(tau0 t + (tau1-tau0) t^2 / (2 (s1-s0)))) = 1-u on
+// one interval, with the reference's epsilon guards, op for op.
+__device__ __forceinline__ float invert_segment(float s0, float s1, float T0, float tau0, float tau1,
+                                                float u, float eps, bool rising) {
+    const float ln_term = -logf(tmax(eps, (1.0f - u) / tmax(eps, T0)));
+    const float span = tmax(eps, s1 - s0);
+    float t;
+    if (rising) {
+        const float disc = tau0 * tau0 + (2.0f * (tau1 - tau0) * ln_term) / span;
+        t = ((s1 - s0) * (-tau0 + sqrtf(tmax(eps, disc)))) / tmax(eps, tau1 - tau0);
+    } else {
+        const float disc = tau0 * tau0 - (2.0f * (tau0 - tau1) * ln_term) / span;
+        t = ((s1 - s0) * (tau0 - sqrtf(tmax(eps, disc)))) / tmax(eps, tau0 - tau1);
+    }
+    t = tmin(tmax(t, eps), s1 - s0);   // torch.clamp(t, eps, s1-s0)
+    return s0 + t;
+}
+
+__global__ __launch_bounds__(256) void sample_pl_kernel(SamplePlArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int ray = blockIdx.x * WAVES + wave;
+    const bool live = ray < a.R;
+    if (!live) ray = a.R - 1;
+    const int S = a.S, K = a.S + 2;            // K knots / cdf entries
+    float* cdf = smem + wave * a.lds_stride;
+    float* knots = cdf + K;
+    float* tau = knots + K;
+    float* Tr = tau + K;
+    for (int j = lane; j < K; j += 64) {
+        tau[j] = a.tau[(size_t)ray * K + j];
+        Tr[j] = a.T[(size_t)ray * K + j];
+        float kn;
+        if (j == 0) kn = a.near[ray];
+        else if (j == K - 1) kn = a.far[ray];
+        else kn = a.z[(size_t)ray * S + j - 1];
+        knots[j] = kn;
+    }
+    // cdf = [0, cumsum(weights)] (fp64 running sum), last entry forced to 1
+    double carry = 0.0;
+    const int n = S + 1;
+    for (int base = 0; base < n; base += 64) {
+        const int j = base + lane;
+        const float w = (j < n) ? a.weights[(size_t)ray * n + j] : 0.0f;
+        const double incl = wave_incl_sum((double)w);
+        if (j < n) cdf[j + 1] = (float)(carry + incl);
+        carry = carry + __shfl(incl, 63);
+    }
+    __syncthreads();
+    if (lane == 0) { cdf[0] = 0.0f; cdf[K - 1] = 1.0f; }
+    __syncthreads();
+    if (!live) return;
+    const float* urow = a.u + (size_t)ray * a.u_row_stride;
+    const float zt = a.zero_tol, eps = a.eps;
+    for (int k = lane; k < a.N; k += 64) {
+        const float u = urow[k];
+        const int ind = upper_bound(cdf, K, u);
+        const int below = ind - 1 > 0 ? ind - 1 : 0;
+        const int above = ind < K - 1 ? ind : K - 1;
+        const float s0 = knots[below], s1 = knots[above];
+        const float T0 = Tr[below];
+        const float tau0 = tau[below], tau1 = tau[above];
+        const int di = below < S ? below : S;               // H4: reference reads out of bounds at u == 1
+        const float d = tau[di + 1] - tau[di];
+        float out = (d < zt && d > -zt) ? s0 : -1.0f;
+        if (d >= zt) out = invert_segment(s0, s1, T0, tau0, tau1, u, eps, true);
+        if (d <= -zt) out = invert_segment(s0, s1, T0, tau0, tau1, u, eps, false);
+        if (out != out) out = s0;
+        const size_t o = (size_t)ray * a.N + k;
+        a.samples[o] = out;
+        if (a.T_below) a.T_below[o] = T0;
+        if (a.tau_below) a.tau_below[o] = tau0;
+        if (a.bin_below) a.bin_below[o] = s0;
+        if (a.inds) a.inds[o] = (int64_t)ind;
+    }
+}
+
+struct MergeArgs {
+    const float* z;
+    const float* z_new;
+    const float* near;
+    const float* far;
+    int R, S, N;
+    int lds_stride;
+    float* out;
+};
+
+// Total order on fp32 as torch.sort uses it for values: ascending, NaN last.
+__device__ __forceinline__ uint32_t sort_key(float f) {
+    if (f != f) return 0xFFFFFFFFu;
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// Rank sort: every element counts the elements ordered before it (ties by index) and
+// scatters itself to that slot.  n <= 1024 keys live in LDS; all compares are broadcast
+// LDS reads.  O(n^2/64) per lane is ~600 compares at n = 192, far below the HBM time of
+// the row it replaces a general sort for.
+__global__ __launch_bounds__(256) void merge_sort_kernel(MergeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int ray = blockIdx.x * WAVES + wave;
+    const bool live = ray < a.R;
+    if (!live) ray = a.R - 1;
+    const int S = a.S, N = a.N, n = S + N;
+    float* val = smem + wave * a.lds_stride;
+    uint32_t* key = reinterpret_cast<uint32_t*>(val + n);
+    const float lo = a.near[ray], hi = a.far[ray];
+    for (int j = lane; j < n; j += 64) {
+        float v;
+        if (j < S) v = a.z[(size_t)ray * S + j];
+        else v = tmin(tmax(a.z_new[(size_t)ray * N + (j - S)], lo), hi);
+        val[j] = v;
+        key[j] = sort_key(v);
+    }
+    __syncthreads();
+    if (!live) return;
+    for (int j = lane; j < n; j += 64) {
+        const uint32_t kj = key[j];
+        int rank = 0;
+        for (int i = 0; i < n; ++i) {
+            const uint32_t ki = key[i];
+            rank += (ki < kj || (ki == kj && i < j)) ? 1 : 0;
+        }
+        a.out[(size_t)ray * n + rank] = val[j];
+    }
+}
+
+inline int set_lds(const void* fn, size_t lds) {
+    if (lds > 160 * 1024) return PLNERF_ERANGE;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return PLNERF_OK;
+}
+
+}  // namespace
+
+extern "C" int plnerf_sample_const(const float* bins, const float* weights, const float* u,
+                                   int u_row_stride, int R, int B, int N, float* samples, int64_t* inds,
+                                   plnerf_stream_t stream) {
+    if (!bins || !weights || !u || !samples) return PLNERF_EINVAL;
+    if (R < 0 || B < 2 || N < 1 || (u_row_stride != 0 && u_row_stride != N)) return PLNERF_EINVAL;
+    if (B > PLNERF_MAX_SAMPLES + 2) return PLNERF_ERANGE;
+    if (R == 0) return PLNERF_OK;
+    SampleConstArgs a{bins, weights, u, u_row_stride, R, B, N, 0, samples, inds};
+    a.lds_stride = ((3 * B) + 3) & ~3;
+    const size_t lds = (size_t)WAVES * a.lds_stride * sizeof(float);
+    int rc = set_lds((const void*)sample_const_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sample_const_kernel, dim3((R + WAVES - 1) / WAVES), dim3(WAVES * 64), lds,
+                       (hipStream_t)stream, a);
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}
+
+extern "C" int plnerf_sample_pl(const float* z, const float* weights, const float* tau, const float* T,
+                                const float* near, const float* far, const float* u, int u_row_stride,
+                                int R, int S, int N, float zero_tol, float epsilon, float* samples,
+                                float* T_below, float* tau_below, float* bin_below, int64_t* inds,
+                                plnerf_stream_t stream) {
+    if (!z || !weights || !tau || !T || !near || !far || !u || !samples) return PLNERF_EINVAL;
+    if (R < 0 || S < 1 || N < 1 || (u_row_stride != 0 && u_row_stride != N)) return PLNERF_EINVAL;
+    if (S > PLNERF_MAX_SAMPLES) return PLNERF_ERANGE;
+    if (R == 0) return PLNERF_OK;
+    SamplePlArgs a{z, weights, tau, T, near, far, u, u_row_stride, R, S, N, 0, zero_tol, epsilon,
+                   samples, T_below, tau_below, bin_below, inds};
+    a.lds_stride = ((4 * (S + 2)) + 3) & ~3;
+    const size_t lds = (size_t)WAVES * a.lds_stride * sizeof(float);
+    int rc = set_lds((const void*)sample_pl_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sample_pl_kernel, dim3((R + WAVES - 1) / WAVES), dim3(WAVES * 64), lds,
+                       (hipStream_t)stream, a);
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}
+
+extern "C" int plnerf_merge_sort(const float* z, const float* z_new, const float* near, const float* far,
+                                 int R, int S, int N, float* out, plnerf_stream_t stream) {
+    if (!z || !z_new || !near || !far || !out) return PLNERF_EINVAL;
+    if (R < 0 || S < 0 || N < 0 || S + N < 1) return PLNERF_EINVAL;
+    if (S + N > 1024) return PLNERF_ERANGE;
+    if (R == 0) return PLNERF_OK;
+    MergeArgs a{z, z_new, near, far, R, S, N, 0, out};
+    a.lds_stride = ((2 * (S + N)) + 3) & ~3;
+    const size_t lds = (size_t)WAVES * a.lds_stride * sizeof(float);
+    int rc = set_lds((const void*)merge_sort_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(merge_sort_kernel, dim3((R + WAVES - 1) / WAVES), dim3(WAVES * 64), lds,
+                       (hipStream_t)stream, a);
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}

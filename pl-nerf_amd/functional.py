@@ -1,0 +1,235 @@
+"""torch.autograd glue around the HIP kernels: one Function per differentiable stage.
+
+PyTorch is plumbing here (device memory, streams, the autograd tape); every operation of
+the path itself runs in libplnerf_hip.so.
+"""
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+class KernelTimer:
+    """Optional per-launch timing with HIP events recorded on the launch stream (the stream
+    the kernels are enqueued on is torch's current stream).  bench.py installs one to measure
+    the dominant kernel inside the timed region; None (the default) costs nothing."""
+
+    def __init__(self):
+        self.events = {}
+
+    def bracket(self, name):
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        self.events.setdefault(name, []).append((s, e))
+        return s, e
+
+    def mean_ms(self, name, skip=0):
+        ev = self.events.get(name, [])[skip:]
+        if not ev:
+            return None
+        return sum(s.elapsed_time(e) for s, e in ev) / len(ev)
+
+    def count(self, name):
+        return len(self.events.get(name, []))
+
+
+KERNEL_TIMER = None
+
+
+class QuadratureFn(torch.autograd.Function):
+    """raw2outputs (run_plnerf.py:553-624) -> plnerf_quad_fwd / plnerf_quad_bwd.
+
+    Differentiable with respect to `raw` through rgb_map, disp_map, acc_map, weights and
+    depth_map.  tau and T are returned for the sampler only and are not differentiable
+    (on the reference path their sole consumer is detached, run_plnerf.py:728)."""
+
+    @staticmethod
+    def forward(ctx, raw, z, near, far, rays_d, noise, mode, color_mode, white_bkgd, farcolorfix):
+        R, S = z.shape
+        dev = raw.device
+        raw_c, z_c = _f32c(raw), _f32c(z)
+        near_c, far_c = _f32c(near).reshape(-1), _f32c(far).reshape(-1)
+        d_c = _f32c(rays_d)
+        noise_c = None if noise is None else _f32c(noise)
+        linear = mode == "linear"
+        n = S + 1 if linear else S
+        rgb = torch.empty(R, 3, device=dev)
+        disp = torch.empty(R, device=dev)
+        acc = torch.empty(R, device=dev)
+        depth = torch.empty(R, device=dev)
+        w = torch.empty(R, n, device=dev)
+        tau = torch.empty(R, S + 2, device=dev) if linear else torch.empty(0, device=dev)
+        T = torch.empty(R, S + 2, device=dev) if linear else torch.empty(0, device=dev)
+        L.check(L.lib().plnerf_quad_fwd(
+            L.dptr(raw_c, "raw"), L.dptr(z_c, "z_vals"), L.dptr(near_c, "near"), L.dptr(far_c, "far"),
+            L.dptr(d_c, "rays_d"), L.dptr(noise_c, "noise"), R, S, L.MODE[mode], L.COLOR[color_mode],
+            int(bool(white_bkgd)), int(bool(farcolorfix)), L.dptr(rgb), L.dptr(disp), L.dptr(acc),
+            L.dptr(depth), L.dptr(w), L.dptr(tau) if linear else None, L.dptr(T) if linear else None,
+            L.stream()), "plnerf_quad_fwd")
+        ctx.save_for_backward(raw_c, z_c, near_c, far_c, d_c, noise_c if noise_c is not None else torch.empty(0),
+                              depth, acc)
+        ctx.cfg = (mode, color_mode, bool(white_bkgd), bool(farcolorfix), noise_c is not None)
+        ctx.mark_non_differentiable(tau, T)
+        ctx.set_materialize_grads(False)
+        return rgb, disp, acc, w, depth, tau, T
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_w, g_depth, g_tau, g_T):
+        raw_c, z_c, near_c, far_c, d_c, noise_c, depth, acc = ctx.saved_tensors
+        mode, color_mode, white_bkgd, farcolorfix, has_noise = ctx.cfg
+        R, S = z_c.shape
+        dev = raw_c.device
+        g_rgb = torch.zeros(R, 3, device=dev) if g_rgb is None else _f32c(g_rgb)
+        g_depth = None if g_depth is None else _f32c(g_depth)
+        g_acc = None if g_acc is None else _f32c(g_acc)
+        if g_disp is not None:
+            # disp = 1 / max(1e-10, depth/acc)  (run_plnerf.py:617): fold into depth / acc
+            ratio = depth / acc
+            live = (ratio > 1e-10).to(torch.float32) * _f32c(g_disp)
+            gd = -live * acc / (depth * depth)
+            ga = live / depth
+            gd = torch.where(torch.isfinite(gd), gd, torch.zeros_like(gd))
+            ga = torch.where(torch.isfinite(ga), ga, torch.zeros_like(ga))
+            g_depth = gd if g_depth is None else g_depth + gd
+            g_acc = ga if g_acc is None else g_acc + ga
+        g_w = None if g_w is None else _f32c(g_w)
+        g_raw = torch.empty(R, S, 4, device=dev)
+        L.check(L.lib().plnerf_quad_bwd(
+            L.dptr(raw_c), L.dptr(z_c), L.dptr(near_c), L.dptr(far_c), L.dptr(d_c),
+            L.dptr(noise_c) if has_noise else None, R, S, L.MODE[mode], L.COLOR[color_mode],
+            int(white_bkgd), int(farcolorfix), L.dptr(g_rgb), L.dptr(g_depth), L.dptr(g_acc), L.dptr(g_w),
+            L.dptr(g_raw), L.stream()), "plnerf_quad_bwd")
+        return g_raw, None, None, None, None, None, None, None, None, None
+
+
+class MlpFn(torch.autograd.Function):
+    """Embedder + NeRF.forward (run_nerf_helpers.py:24-54, 105-128) -> plnerf_mlp_fwd /
+    plnerf_mlp_bwd.  Gradients flow to the 24 parameter tensors only (the sample positions
+    do not depend on parameters on this path)."""
+
+    @staticmethod
+    def forward(ctx, pts, viewdirs, embedded, spr, net, *params):
+        prec = L.PRECISION[net.precision]
+        packed = net.packed_weights()
+        if embedded is not None:
+            emb_c = _f32c(embedded)
+            n_rows, dev = emb_c.shape[0], emb_c.device
+            pts_c = vd_c = None
+        else:
+            pts_c, vd_c = _f32c(pts), _f32c(viewdirs)
+            n_rows, dev = pts_c.shape[0], pts_c.device
+            emb_c = None
+        raw = torch.empty(n_rows, 4, device=dev)
+        need_grad = any(ctx.needs_input_grad[5:])
+        saved = None
+        if need_grad and n_rows > 0:
+            nbytes = L.lib().plnerf_mlp_saved_bytes(n_rows, prec)
+            saved = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+        timer = KERNEL_TIMER
+        if timer is not None:
+            ev = timer.bracket(f"mlp_fwd[{n_rows}]")
+            ev[0].record()
+        L.check(L.lib().plnerf_mlp_fwd(
+            L.dptr(packed, "packed"), prec, L.dptr(pts_c, "pts"), L.dptr(vd_c, "viewdirs"),
+            L.dptr(emb_c, "embedded"), n_rows, int(spr), L.dptr(raw), L.dptr(saved), L.stream()),
+            "plnerf_mlp_fwd")
+        if timer is not None:
+            ev[1].record()
+        ctx.net, ctx.prec, ctx.n_rows = net, prec, n_rows
+        ctx.saved_acts = saved
+        ctx.packed = packed
+        ctx.param_shapes = [p.shape for p in params]
+        return raw
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        n_rows, prec = ctx.n_rows, ctx.prec
+        dev = g_raw.device
+        grads = [torch.empty(s, device=dev, dtype=torch.float32) for s in ctx.param_shapes]
+        if n_rows == 0:
+            return (None,) * 5 + tuple(torch.zeros_like(g) for g in grads)
+        g = _f32c(g_raw)
+        ws = torch.empty(L.lib().plnerf_mlp_bwd_workspace_bytes(n_rows, prec) // 4, device=dev,
+                         dtype=torch.float32)
+        timer = KERNEL_TIMER
+        if timer is not None:
+            ev = timer.bracket(f"mlp_bwd[{n_rows}]")
+            ev[0].record()
+        L.check(L.lib().plnerf_mlp_bwd(
+            L.dptr(ctx.packed), prec, L.dptr(g, "g_raw"), n_rows, L.dptr(ctx.saved_acts), L.dptr(ws),
+            L.ptr_table(grads, "grads"), L.stream()), "plnerf_mlp_bwd")
+        if timer is not None:
+            ev[1].record()
+        ctx.saved_acts = None
+        return (None,) * 5 + tuple(grads)
+
+
+def sample_const(bins, weights, u, want_inds=False):
+    """plnerf_sample_const: bins [R,B], weights [R,B-1], u [R,N] or shared [N]."""
+    R, B = bins.shape
+    N = u.shape[-1]
+    dev = bins.device
+    bins_c, w_c, u_c = _f32c(bins), _f32c(weights), _f32c(u)
+    stride = N if u_c.dim() == 2 else 0
+    out = torch.empty(R, N, device=dev)
+    inds = torch.empty(R, N, device=dev, dtype=torch.int64) if want_inds else None
+    L.check(L.lib().plnerf_sample_const(
+        L.dptr(bins_c, "bins"), L.dptr(w_c, "weights"), L.dptr(u_c, "u"), stride, R, B, N, L.dptr(out),
+        L.dptr(inds, "inds", torch.int64), L.stream()), "plnerf_sample_const")
+    return (out, inds) if want_inds else out
+
+
+def sample_pl(z, weights, tau, T, near, far, u, zero_tol, eps, want_extras=False, want_inds=False):
+    """plnerf_sample_pl; returns samples or (samples, T_below, tau_below, bin_below[, inds])."""
+    R, S = z.shape
+    N = u.shape[-1]
+    dev = z.device
+    z_c, w_c, tau_c, T_c = _f32c(z), _f32c(weights), _f32c(tau), _f32c(T)
+    near_c, far_c, u_c = _f32c(near).reshape(-1), _f32c(far).reshape(-1), _f32c(u)
+    stride = N if u_c.dim() == 2 else 0
+    out = torch.empty(R, N, device=dev)
+    Tb = torch.empty(R, N, device=dev) if want_extras else None
+    taub = torch.empty(R, N, device=dev) if want_extras else None
+    binb = torch.empty(R, N, device=dev) if want_extras else None
+    inds = torch.empty(R, N, device=dev, dtype=torch.int64) if want_inds else None
+    L.check(L.lib().plnerf_sample_pl(
+        L.dptr(z_c, "z_vals"), L.dptr(w_c, "weights"), L.dptr(tau_c, "tau"), L.dptr(T_c, "T"),
+        L.dptr(near_c, "near"), L.dptr(far_c, "far"), L.dptr(u_c, "u"), stride, R, S, N, float(zero_tol),
+        float(eps), L.dptr(out), L.dptr(Tb), L.dptr(taub), L.dptr(binb), L.dptr(inds, "inds", torch.int64),
+        L.stream()), "plnerf_sample_pl")
+    if want_extras:
+        return (out, Tb, taub, binb, inds) if want_inds else (out, Tb, taub, binb)
+    return (out, inds) if want_inds else out
+
+
+def merge_sort(z, z_new, near, far):
+    """plnerf_merge_sort: sort(cat([z, clamp(z_new, near, far)]))."""
+    R, S = z.shape
+    N = z_new.shape[-1]
+    out = torch.empty(R, S + N, device=z.device)
+    L.check(L.lib().plnerf_merge_sort(
+        L.dptr(_f32c(z), "z_vals"), L.dptr(_f32c(z_new), "z_samples"), L.dptr(_f32c(near).reshape(-1), "near"),
+        L.dptr(_f32c(far).reshape(-1), "far"), R, S, N, L.dptr(out), L.stream()), "plnerf_merge_sort")
+    return out
+
+
+_LINSPACE_CACHE = {}
+
+
+def cpu_linspace(n, device):
+    """torch.linspace(0, 1, n) as the reference's CPU path computes it (two-sided fma form),
+    uploaded once per (n, device) -- so det=True draws are bit-identical to the oracle's."""
+    key = (int(n), str(device))
+    if key not in _LINSPACE_CACHE:
+        _LINSPACE_CACHE[key] = torch.linspace(0.0, 1.0, steps=int(n), device="cpu").to(device)
+    return _LINSPACE_CACHE[key]
+
+
+def numpy_uniform(shape, device):
+    """The reference's pytest=True draw: np.random.seed(0); np.random.rand(*shape) -> fp32."""
+    np.random.seed(0)
+    return torch.Tensor(np.random.rand(*shape)).to(device)

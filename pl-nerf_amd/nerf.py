@@ -1,0 +1,146 @@
+"""Embedder / get_embedder / NeRF with the reference's interface
+(run_nerf_helpers.py:24-72, 76-128), backed by the fused HIP MLP.
+
+`NeRF` keeps the reference's module tree, so `state_dict()` keys/shapes and
+`.parameters()` order are identical and reference checkpoints load unchanged
+(run_plnerf.py:454-471, 1324-1332).
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .functional import MlpFn
+
+# The one architecture the HIP kernels are specialised for: the reference's defaults
+# (run_plnerf.py:784-825), used by every config under configs/.
+SUPPORTED = dict(D=8, W=256, input_ch=63, input_ch_views=27, skips=[4], use_viewdirs=True)
+
+
+class Embedder:
+    """gamma(x) = [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)]
+    (run_nerf_helpers.py:24-54).  Calling the object evaluates the encoding with torch
+    ops (generic path, any device); the fused MLP kernel recognises Embedder instances and
+    computes the encoding in its own prologue instead, so on the hot path this __call__
+    never runs."""
+
+    def __init__(self, **kwargs):
+        self.kwargs = kwargs
+        self.input_dims = kwargs["input_dims"]
+        self.include_input = kwargs["include_input"]
+        self.num_freqs = kwargs["num_freqs"]
+        self.max_freq_log2 = kwargs["max_freq_log2"]
+        self.log_sampling = kwargs["log_sampling"]
+        self.periodic_fns = kwargs["periodic_fns"]
+        if self.log_sampling:
+            self.freq_bands = [float(2.0 ** f) for f in
+                               torch.linspace(0.0, self.max_freq_log2, steps=self.num_freqs).tolist()]
+        else:
+            self.freq_bands = torch.linspace(2.0 ** 0.0, 2.0 ** self.max_freq_log2,
+                                             steps=self.num_freqs).tolist()
+        self.out_dim = self.input_dims * ((1 if self.include_input else 0) +
+                                          self.num_freqs * len(self.periodic_fns))
+
+    def is_standard(self, n_freqs):
+        return (self.input_dims == 3 and self.include_input and self.log_sampling and
+                self.num_freqs == n_freqs and self.max_freq_log2 == n_freqs - 1 and
+                list(self.periodic_fns) == [torch.sin, torch.cos])
+
+    def embed(self, inputs):
+        blocks = [inputs] if self.include_input else []
+        for f in self.freq_bands:
+            for fn in self.periodic_fns:
+                blocks.append(fn(inputs * f))
+        return torch.cat(blocks, -1)
+
+    __call__ = embed
+
+
+def get_embedder(multires, i=0):
+    """(embed_fn, out_dim) -- run_nerf_helpers.py:57-72.  i == -1 selects the identity."""
+    if i == -1:
+        return nn.Identity(), 3
+    emb = Embedder(include_input=True, input_dims=3, max_freq_log2=multires - 1, num_freqs=multires,
+                   log_sampling=True, periodic_fns=[torch.sin, torch.cos])
+    return emb, emb.out_dim
+
+
+class NeRF(nn.Module):
+    """The reference MLP (run_nerf_helpers.py:76-128).  forward(x) takes the already
+    embedded input [N, input_ch + input_ch_views] like the reference and runs the fused
+    HIP kernel; `precision` selects the contraction arithmetic ("fp32" = exact fp32 MFMA)."""
+
+    def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False,
+                 precision="fp32"):
+        super().__init__()
+        self.D, self.W = D, W
+        self.input_ch, self.input_ch_views = input_ch, input_ch_views
+        self.skips = skips
+        self.use_viewdirs = use_viewdirs
+        self.precision = precision
+        self.pts_linears = nn.ModuleList(
+            [nn.Linear(input_ch, W)] +
+            [nn.Linear(W + input_ch, W) if i in skips else nn.Linear(W, W) for i in range(D - 1)])
+        self.views_linears = nn.ModuleList([nn.Linear(input_ch_views + W, W // 2)])
+        if use_viewdirs:
+            self.feature_linear = nn.Linear(W, W)
+            self.alpha_linear = nn.Linear(W, 1)
+            self.rgb_linear = nn.Linear(W // 2, 3)
+        else:
+            self.output_linear = nn.Linear(W, output_ch)
+        self._packed = None
+        self._packed_key = None
+
+    # -- HIP plumbing ---------------------------------------------------------------
+    def is_supported(self):
+        return (self.D == SUPPORTED["D"] and self.W == SUPPORTED["W"] and
+                self.input_ch == SUPPORTED["input_ch"] and
+                self.input_ch_views == SUPPORTED["input_ch_views"] and
+                list(self.skips) == SUPPORTED["skips"] and self.use_viewdirs)
+
+    def _require_supported(self):
+        if not self.is_supported():
+            raise NotImplementedError(
+                "plnerf_amd's HIP MLP is specialised for the reference's default architecture "
+                f"{SUPPORTED}; got D={self.D}, W={self.W}, input_ch={self.input_ch}, "
+                f"input_ch_views={self.input_ch_views}, skips={self.skips}, "
+                f"use_viewdirs={self.use_viewdirs}.  There is no generic/CPU fallback.")
+
+    def param_list(self):
+        """The 24 parameter tensors in state_dict order (the C ABI's `params[24]`)."""
+        return list(self.parameters())
+
+    def packed_weights(self):
+        """Weights re-laid-out in MFMA fragment order (plnerf_mlp_pack_weights); cached and
+        re-packed whenever a parameter was modified in place (optimizer step, load_state_dict)."""
+        self._require_supported()
+        params = self.param_list()
+        key = (self.precision,) + tuple((p.data_ptr(), p._version) for p in params)
+        if self._packed is None or self._packed_key != key:
+            prec = L.PRECISION[self.precision]
+            nbytes = L.lib().plnerf_mlp_packed_bytes(prec)
+            if nbytes == 0:
+                raise NotImplementedError(f"precision mode {self.precision!r} is not built")
+            dev = params[0].device
+            flat = [p.detach() for p in params]
+            if self._packed is None or self._packed.device != dev or self._packed.numel() * 4 != nbytes:
+                self._packed = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+            L.check(L.lib().plnerf_mlp_pack_weights(L.ptr_table(flat), prec, L.dptr(self._packed), L.stream()),
+                    "plnerf_mlp_pack_weights")
+            self._packed_key = key
+        return self._packed
+
+    # -- reference interface --------------------------------------------------------
+    def forward(self, x):
+        self._require_supported()
+        lead = x.shape[:-1]
+        flat = x.reshape(-1, x.shape[-1])
+        out = MlpFn.apply(None, None, flat, 1, self, *self.param_list())
+        return out.reshape(*lead, 4)
+
+    def query(self, pts, viewdirs):
+        """Fused entry: pts [R,S,3], viewdirs [R,3] -> raw [R,S,4]; the encoding happens in
+        the kernel prologue (what run_network does on the hot path)."""
+        self._require_supported()
+        R, S = pts.shape[0], pts.shape[1]
+        out = MlpFn.apply(pts.reshape(-1, 3), viewdirs, None, S, self, *self.param_list())
+        return out.reshape(R, S, 4)

@@ -1,0 +1,334 @@
+"""The render operator surface of run_plnerf.py, on the HIP path.
+
+Same names, arguments and return structures as the reference (file:line cited per
+function), so a caller of the reference's `create_nerf` / `render` / `render_rays` can
+switch to this module unchanged.  Everything numerical happens in libplnerf_hip.so via
+`functional.py`; torch is used for allocation, the random draws and the autograd tape.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import functional as Fn
+from .nerf import NeRF, Embedder, get_embedder
+from .rays import get_rays, ndc_rays
+
+DEBUG = False
+MAX_ROWS_PER_LAUNCH = 1 << 21   # MLP rows per kernel launch when activations are saved (~21 GB fp32)
+
+
+def batchify(fn, chunk):
+    """run_plnerf.py:68-75."""
+    if chunk is None:
+        return fn
+
+    def ret(inputs):
+        return torch.cat([fn(inputs[i:i + chunk]) for i in range(0, inputs.shape[0], chunk)], 0)
+    return ret
+
+
+def _fusable(fn, embed_fn, embeddirs_fn, viewdirs):
+    return (isinstance(fn, NeRF) and fn.is_supported() and viewdirs is not None and
+            isinstance(embed_fn, Embedder) and embed_fn.is_standard(10) and
+            isinstance(embeddirs_fn, Embedder) and embeddirs_fn.is_standard(4))
+
+
+def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64):
+    """run_plnerf.py:78-92: encode sample positions / view directions and apply the MLP.
+
+    Hot path (the reference's default encoders + network): one fused kernel per launch --
+    encoding in the prologue, direction encoded per ray.  `netchunk` "does not affect final
+    results" in the reference; here rows are only split to bound the saved-activation
+    buffer.  Any other encoder/network combination takes the generic route below and still
+    ends in the HIP MLP through NeRF.forward."""
+    if _fusable(fn, embed_fn, embeddirs_fn, viewdirs):
+        R, S = inputs.shape[0], inputs.shape[1]
+        rays_per_launch = max(1, MAX_ROWS_PER_LAUNCH // max(S, 1))
+        if R <= rays_per_launch:
+            return fn.query(inputs, viewdirs)
+        outs = [fn.query(inputs[i:i + rays_per_launch], viewdirs[i:i + rays_per_launch])
+                for i in range(0, R, rays_per_launch)]
+        return torch.cat(outs, 0)
+    inputs_flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
+    embedded = embed_fn(inputs_flat)
+    if viewdirs is not None:
+        input_dirs = viewdirs[:, None].expand(inputs.shape)
+        embedded = torch.cat([embedded, embeddirs_fn(torch.reshape(input_dirs, [-1, input_dirs.shape[-1]]))], -1)
+    outputs_flat = batchify(fn, netchunk)(embedded)
+    return torch.reshape(outputs_flat, list(inputs.shape[:-1]) + [outputs_flat.shape[-1]])
+
+
+def compute_weights(raw, z_vals, rays_d, noise=0.):
+    """run_plnerf.py:504-513 (piecewise-constant opacity)."""
+    near = z_vals[..., :1]
+    noise_t = _noise_tensor(noise, raw)
+    return Fn.QuadratureFn.apply(raw, z_vals, near, near, rays_d, noise_t, "constant", "midpoint", False, False)[3]
+
+
+def compute_weights_piecewise_linear(raw, z_vals, near, far, rays_d, noise=0., return_tau=False):
+    """run_plnerf.py:516-550."""
+    noise_t = _noise_tensor(noise, raw)
+    out = Fn.QuadratureFn.apply(raw, z_vals, near, far, rays_d, noise_t, "linear", "midpoint", False, False)
+    if return_tau:
+        return out[3], out[5], out[6]
+    return out[3]
+
+
+def _noise_tensor(noise, raw):
+    if isinstance(noise, torch.Tensor):
+        return noise.to(raw.device)
+    if noise == 0.:
+        return None
+    return torch.full(raw.shape[:-1], float(noise), device=raw.device)
+
+
+def raw2outputs(raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std=0, pytest=False,
+                white_bkgd=False, farcolorfix=False):
+    """run_plnerf.py:553-624.  Returns (rgb_map, disp_map, acc_map, weights, depth_map, tau, T)
+    with tau = T = None in constant mode."""
+    if mode not in ("linear", "constant"):
+        raise ValueError(f"mode must be 'linear' or 'constant', got {mode!r}")
+    if mode == "linear" and color_mode not in ("midpoint", "left"):
+        raise ValueError("Color mode unimplemented, please select left or midpoint.")
+    noise = None
+    if raw_noise_std > 0.:
+        shape = list(raw[..., 3].shape)
+        if pytest:   # the reference's deterministic draw is UNIFORM (run_plnerf.py:573-576)
+            noise = Fn.numpy_uniform(shape, raw.device) * raw_noise_std
+        else:
+            noise = torch.randn(shape, device=raw.device) * raw_noise_std
+    cm = color_mode if mode == "linear" else "midpoint"
+    rgb, disp, acc, w, depth, tau, T = Fn.QuadratureFn.apply(raw, z_vals, near, far, rays_d, noise, mode, cm,
+                                                             white_bkgd, farcolorfix)
+    if mode == "constant":
+        tau, T = None, None
+    return rgb, disp, acc, w, depth, tau, T
+
+
+def _draw_u(prefix_shape, n, det, pytest, device):
+    if pytest:   # run_nerf_helpers.py:256-264
+        if det:
+            return torch.Tensor(np.linspace(0., 1., n)).to(device)
+        return Fn.numpy_uniform(list(prefix_shape) + [n], device)
+    if det:
+        return Fn.cpu_linspace(n, device)
+    return torch.rand(list(prefix_shape) + [n], device=device)
+
+
+def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
+    """run_nerf_helpers.py:241-284."""
+    u = _draw_u(bins.shape[:-1], N_samples, det, pytest, bins.device)
+    return Fn.sample_const(bins, weights, u)
+
+
+def sample_pdf_reformulation(bins, weights, tau, T, near, far, N_samples, det=False, pytest=False,
+                             quad_solution_v2=False, zero_threshold=1e-4, epsilon_=1e-3):
+    """run_nerf_helpers.py:364-445.  Returns (samples, T_below, tau_below, bin_below).
+    quad_solution_v2 is accepted and ignored, as in the reference."""
+    u = _draw_u(bins.shape[:-1], N_samples, det, pytest, bins.device)
+    return Fn.sample_pl(bins, weights, tau, T, near, far, u, zero_threshold, epsilon_, want_extras=True)
+
+
+def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_mode, retraw=False,
+                lindisp=False, perturb=0., N_importance=0, network_fine=None, white_bkgd=False,
+                raw_noise_std=0., verbose=False, pytest=False, quad_solution_v2=False, zero_tol=1e-4,
+                epsilon=1e-3, farcolorfix=False, constant_init=False):
+    """Volumetric rendering of a ray batch -- run_plnerf.py:627-758.
+
+    ray_batch [R, 8 or 11] = origin(3) direction(3) near far [unit view direction(3)].
+    Returns the reference's dict: rgb_map, disp_map, acc_map, depth_map (+ raw if retraw;
+    + rgb0, disp0, depth0, acc0, z_std if N_importance > 0)."""
+    dev = ray_batch.device
+    N_rays = ray_batch.shape[0]
+    rays_o, rays_d = ray_batch[:, 0:3], ray_batch[:, 3:6]
+    viewdirs = ray_batch[:, -3:] if ray_batch.shape[-1] > 8 else None
+    bounds = torch.reshape(ray_batch[..., 6:8], [-1, 1, 2])
+    near, far = bounds[..., 0], bounds[..., 1]
+
+    t_vals = Fn.cpu_linspace(N_samples, dev)
+    if not lindisp:
+        z_vals = near * (1. - t_vals) + far * t_vals
+    else:
+        z_vals = 1. / (1. / near * (1. - t_vals) + 1. / far * t_vals)
+    z_vals = z_vals.expand([N_rays, N_samples])
+
+    if perturb > 0.:
+        mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+        upper = torch.cat([mids, z_vals[..., -1:]], -1)
+        lower = torch.cat([z_vals[..., :1], mids], -1)
+        if pytest:
+            t_rand = Fn.numpy_uniform(list(z_vals.shape), dev)
+        else:
+            t_rand = torch.rand(z_vals.shape, device=dev)
+        z_vals = lower + (upper - lower) * t_rand
+
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+
+    if constant_init:   # run_plnerf.py:710-711: overrides the mode for the whole call
+        mode = "constant"
+
+    raw = network_query_fn(pts, viewdirs, network_fn)
+    rgb_map, disp_map, acc_map, weights, depth_map, tau, T = raw2outputs(
+        raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std, pytest=pytest, white_bkgd=white_bkgd,
+        farcolorfix=farcolorfix)
+
+    if N_importance > 0:
+        rgb_map_0, disp_map_0, acc_map_0, depth_map_0 = rgb_map, disp_map, acc_map, depth_map
+        if mode == "linear":
+            z_samples, _, _, _ = sample_pdf_reformulation(
+                z_vals, weights, tau, T, near, far, N_importance, det=(perturb == 0.), pytest=pytest,
+                quad_solution_v2=quad_solution_v2, zero_threshold=zero_tol, epsilon_=epsilon)
+        elif mode == "constant":
+            z_vals_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+            z_samples = sample_pdf(z_vals_mid, weights[..., 1:-1], N_importance, det=(perturb == 0.),
+                                   pytest=pytest)
+        z_samples = z_samples.detach()
+        # clamp + cat + sort (run_plnerf.py:731-734) in one kernel; z_samples clamped for z_std
+        z_vals = Fn.merge_sort(z_vals, z_samples, near, far)
+        z_samples = torch.clamp(z_samples, near, far)
+        pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+
+        run_fn = network_fn if network_fine is None else network_fine
+        raw = network_query_fn(pts, viewdirs, run_fn)
+        rgb_map, disp_map, acc_map, weights, depth_map, tau, T = raw2outputs(
+            raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std, pytest=pytest,
+            white_bkgd=white_bkgd, farcolorfix=farcolorfix)
+
+    ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map, 'depth_map': depth_map}
+    if retraw:
+        ret['raw'] = raw
+    if N_importance > 0:
+        ret['rgb0'] = rgb_map_0
+        ret['disp0'] = disp_map_0
+        ret['depth0'] = depth_map_0
+        ret['acc0'] = acc_map_0
+        ret['z_std'] = torch.std(z_samples, dim=-1, unbiased=False)
+
+    if DEBUG:
+        for k in ret:
+            if torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any():
+                print(f"! [Numerical Error] {k} contains nan or inf.")
+    return ret
+
+
+def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
+    """run_plnerf.py:95-107."""
+    all_ret = {}
+    for i in range(0, rays_flat.shape[0], chunk):
+        ret = render_rays(rays_flat[i:i + chunk], **kwargs)
+        for k in ret:
+            all_ret.setdefault(k, []).append(ret[k])
+    return {k: torch.cat(all_ret[k], 0) for k in all_ret}
+
+
+def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
+           c2w_staticcam=None, **kwargs):
+    """run_plnerf.py:110-175.  Returns [rgb_map, disp_map, acc_map, extras]."""
+    if c2w is not None:
+        rays_o, rays_d = get_rays(H, W, K, c2w)
+    else:
+        rays_o, rays_d = rays
+
+    if use_viewdirs:
+        viewdirs = rays_d
+        if c2w_staticcam is not None:
+            rays_o, rays_d = get_rays(H, W, K, c2w_staticcam)
+        viewdirs = viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True)
+        viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
+
+    sh = rays_d.shape
+    if ndc:
+        rays_o, rays_d = ndc_rays(H, W, K[0][0], 1., rays_o, rays_d)
+
+    rays_o = torch.reshape(rays_o, [-1, 3]).float()
+    rays_d = torch.reshape(rays_d, [-1, 3]).float()
+    near, far = near * torch.ones_like(rays_d[..., :1]), far * torch.ones_like(rays_d[..., :1])
+    rays = torch.cat([rays_o, rays_d, near, far], -1)
+    if use_viewdirs:
+        rays = torch.cat([rays, viewdirs], -1)
+
+    all_ret = batchify_rays(rays, chunk, **kwargs)
+    for k in all_ret:
+        all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
+
+    k_extract = ['rgb_map', 'disp_map', 'acc_map']
+    ret_list = [all_ret[k] for k in k_extract]
+    ret_dict = {k: all_ret[k] for k in all_ret if k not in k_extract}
+    return ret_list + [ret_dict]
+
+
+def create_nerf(args, device=None):
+    """run_plnerf.py:417-502: (render_kwargs_train, render_kwargs_test, start, grad_vars,
+    optimizer, optimizer_coarse).  `device` (extension) defaults to cuda:<current>; optional
+    `args.precision` picks the MLP arithmetic ("fp32" default)."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() \
+            else torch.device("cpu")
+    precision = getattr(args, "precision", "fp32")
+    embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
+    input_ch_views = 0
+    embeddirs_fn = None
+    if args.use_viewdirs:
+        embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
+    output_ch = 5 if args.N_importance > 0 else 4
+    skips = [4]
+    model = NeRF(D=args.netdepth, W=args.netwidth, input_ch=input_ch, output_ch=output_ch, skips=skips,
+                 input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs, precision=precision).to(device)
+    coarse_grad_vars = list(model.parameters())
+    grad_vars = coarse_grad_vars
+
+    model_fine = None
+    if args.N_importance > 0:
+        model_fine = NeRF(D=args.netdepth_fine, W=args.netwidth_fine, input_ch=input_ch, output_ch=output_ch,
+                          skips=skips, input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs,
+                          precision=precision).to(device)
+        grad_vars = list(model_fine.parameters())
+
+    def network_query_fn(inputs, viewdirs, network_fn):
+        return run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
+                           netchunk=args.netchunk)
+
+    # `optimizer` drives the fine network, `optimizer_coarse` the coarse one (:438, :446-447)
+    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    optimizer_coarse = torch.optim.Adam(params=coarse_grad_vars, lr=args.coarse_lrate, betas=(0.9, 0.999))
+
+    start = 0
+    if args.ft_path is not None and args.ft_path != 'None':
+        ckpts = [args.ft_path]
+    else:
+        ckdir = os.path.join(args.ckpt_dir, args.expname)
+        ckpts = [os.path.join(ckdir, f) for f in sorted(os.listdir(ckdir)) if 'tar' in f]
+    print('Found ckpts', ckpts)
+    if len(ckpts) > 0 and not args.no_reload:
+        ckpt_path = ckpts[-1]
+        print('Reloading from', ckpt_path)
+        ckpt = torch.load(ckpt_path, map_location=device)
+        start = ckpt['global_step']
+        optimizer.load_state_dict(ckpt['optimizer_state_dict'])
+        model.load_state_dict(ckpt['network_fn_state_dict'])
+        if model_fine is not None:
+            model_fine.load_state_dict(ckpt['network_fine_state_dict'])
+
+    render_kwargs_train = {
+        'network_query_fn': network_query_fn,
+        'perturb': args.perturb,
+        'N_importance': args.N_importance,
+        'network_fine': model_fine,
+        'N_samples': args.N_samples,
+        'network_fn': model,
+        'use_viewdirs': args.use_viewdirs,
+        'white_bkgd': args.white_bkgd,
+        'raw_noise_std': args.raw_noise_std,
+        'mode': args.mode,
+        'color_mode': args.color_mode,
+    }
+    if args.dataset != 'llff' or args.no_ndc:
+        print('Not ndc!')
+        render_kwargs_train['ndc'] = False
+        render_kwargs_train['lindisp'] = args.lindisp
+
+    render_kwargs_test = {k: render_kwargs_train[k] for k in render_kwargs_train}
+    render_kwargs_test['perturb'] = True
+    render_kwargs_test['raw_noise_std'] = 0.
+    return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer, optimizer_coarse

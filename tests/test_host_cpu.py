@@ -1,0 +1,150 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol the header
+declares; host-side logic; the data-parallel path on world_size-2 gloo."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as ge
+    if not os.path.exists(os.path.join(ROOT, "pl-nerf_amd", "libplnerf_hip.so")):
+        ge.build()
+    import plnerf_amd
+    return plnerf_amd
+
+
+def test_library_exports_every_declared_symbol(built):
+    import ctypes
+    from plnerf_amd import _lib
+    header = open(os.path.join(ROOT, "include", "plnerf_hip.h")).read()
+    declared = set(re.findall(r"\b(plnerf_[a-z0-9_]+)\s*\(", header))
+    declared.discard("plnerf_stream_t")
+    assert declared, "no declarations parsed"
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(handle, name), f"{name} declared in plnerf_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    assert built.library_version() == 100
+    assert _lib.lib().plnerf_error_string(-3).decode().startswith("size outside")
+
+
+def test_buffer_size_queries(built):
+    from plnerf_amd import _lib
+    L = _lib.lib()
+    assert L.plnerf_mlp_packed_bytes(0) > 595844 * 4          # padded fwd + bwd layouts
+    assert L.plnerf_mlp_saved_bytes(1000, 0) == 1000 * 2528 * 4
+    assert L.plnerf_mlp_bwd_workspace_bytes(1000, 0) > 1000 * 2432 * 4
+    assert L.plnerf_mlp_packed_bytes(7) == 0
+
+
+def test_no_cpu_fallback(built):
+    net = built.NeRF(input_ch=63, input_ch_views=27, use_viewdirs=True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(3, 90))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        built.raw2outputs(torch.zeros(2, 4, 4), torch.zeros(2, 4), torch.zeros(2, 1), torch.ones(2, 1),
+                          torch.ones(2, 3), "linear", "midpoint")
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "pl-nerf_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+\S*oracle", src, re.M), f"{fn} imports the oracle"
+            assert "plnerf_oracle" not in src and "importlib" not in src, f"{fn} reaches for the oracle"
+
+
+def test_module_interface_matches_reference(built):
+    """state_dict keys / shapes / parameter order of the drop-in NeRF (checkpoint compatibility,
+    run_plnerf.py:454-471) and the get_embedder contract."""
+    from oracle import plnerf_oracle as orc
+    net = built.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == \
+        [(k, tuple(s)) for k, s in orc.param_shapes()]
+    assert [tuple(p.shape) for p in net.parameters()] == [tuple(s) for _, s in orc.param_shapes()]
+    net.load_state_dict(orc.closed_form_state_dict(0))
+    emb, ch = built.get_embedder(10, 0)
+    assert ch == 63 and emb.is_standard(10)
+    x = torch.randn(5, 3)
+    assert torch.equal(emb(x), orc.positional_encoding(x, 10))
+    ident, ch = built.get_embedder(10, -1)
+    assert ch == 3 and torch.equal(ident(x), x)
+
+
+def test_rays_match_golden(built, golden):
+    g = golden("g7_rays")
+    H, W, f = int(g["H"]), int(g["W"]), float(g["focal"])
+    K = [[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]]
+    o, d = built.get_rays(H, W, K, torch.from_numpy(g["c2w"]))
+    assert torch.equal(o, torch.from_numpy(g["rays_o"])) and torch.equal(d, torch.from_numpy(g["rays_d"]))
+    o2, d2 = built.ndc_rays(H, W, f, 1.0, o, d)
+    assert torch.allclose(o2, torch.from_numpy(g["ndc_o"]), atol=1e-6, rtol=1e-6)
+    assert torch.allclose(d2, torch.from_numpy(g["ndc_d"]), atol=1e-6, rtol=1e-6)
+
+
+def test_shard_rays():
+    from plnerf_amd import dp
+    spans = [dp.shard_rays(32768, r, 8) for r in range(8)]
+    assert spans[0] == (0, 4096) and spans[-1] == (28672, 32768)
+    assert all(spans[i][1] == spans[i + 1][0] for i in range(7))
+    with pytest.raises(ValueError):
+        dp.shard_rays(1000, 0, 3)
+
+
+_DP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import plnerf_amd
+from plnerf_amd import dp
+rank, world, _ = dp.init_from_env(backend="gloo")
+torch.manual_seed(1234 + rank)               # deliberately different init per rank
+nets = [torch.nn.Linear(7, 5), torch.nn.Linear(5, 3)]
+dp.broadcast_parameters(nets, src=0)
+w0 = [p.detach().clone() for n in nets for p in n.parameters()]
+gathered = [None] * world
+dist.all_gather_object(gathered, [w.tolist() for w in w0])
+assert gathered[0] == gathered[1], "replicas differ after broadcast"
+# global batch of 8 rows, split 4/4; the loss is a mean over rows like img2mse
+g = torch.Generator().manual_seed(0)
+X, Y = torch.randn(8, 7, generator=g), torch.randn(8, 3, generator=g)
+lo, hi = dp.shard_rays(8, rank, world)
+bucket = dp.GradientBucket(nets)
+loss = ((nets[1](torch.relu(nets[0](X[lo:hi]))) - Y[lo:hi]) ** 2).mean()
+loss.backward()
+bucket.allreduce_mean()
+# reference: the full batch on one process
+ref = [torch.nn.Linear(7, 5), torch.nn.Linear(5, 3)]
+for r, n in zip(ref, nets):
+    r.load_state_dict(n.state_dict())
+((ref[1](torch.relu(ref[0](X))) - Y) ** 2).mean().backward()
+for n, r in zip(nets, ref):
+    for p, q in zip(n.parameters(), r.parameters()):
+        assert torch.allclose(p.grad, q.grad, atol=1e-6), (rank, (p.grad - q.grad).abs().max())
+print(f"rank {rank} ok")
+'''
+
+
+def test_data_parallel_gradient_allreduce_gloo(tmp_path):
+    """world_size 2 on CPU/gloo: after the bucketed all-reduce every rank holds the gradient of
+    the full (unsharded) batch, and replicas start bit-identical."""
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_DP_WORKER)
+    port = 29600 + (os.getpid() % 300)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank} failed:\n{out}"
+        assert f"rank {rank} ok" in out
