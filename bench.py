@@ -44,7 +44,8 @@ def parse():
     ap.add_argument("--n-importance", type=int, default=128)
     ap.add_argument("--precision", default="fp32", choices=["fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=256)
+    ap.add_argument("--cpu-rays", type=int, default=1024)
+    ap.add_argument("--cpu-threads", type=int, default=16)
     return ap.parse_args()
 
 
@@ -61,7 +62,10 @@ def cpu_baseline(a):
     """The oracle's training step on the host cores, bounded sample (1 warm-up + 2 steps)."""
     from oracle import plnerf_oracle as orc
     n = a.cpu_rays
-    threads = os.cpu_count() or 1
+    # 16 threads is the fastest setting on the GPU box's 256-thread host for this workload
+    # (profiles/r01_cpu_oracle_thread_sweep.txt: 8 -> 314, 16 -> 339, 32 -> 289, 64 -> 161,
+    # 128 -> 71 rays/s; more threads only add oversubscription on these small GEMMs)
+    threads = min(a.cpu_threads, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     batch, target = orc.synthetic_blender_rays(n, seed=0)
     sd_c, sd_f = orc.closed_form_state_dict(0), orc.closed_form_state_dict(1)
@@ -70,7 +74,7 @@ def cpu_baseline(a):
     state = {}
     orc.train_step(sd_c, sd_f, batch, target, kw, adam_state=state)
     t0 = time.perf_counter()
-    reps = 2
+    reps = 3
     for _ in range(reps):
         orc.train_step(sd_c, sd_f, batch, target, kw, adam_state=state)
     dt = (time.perf_counter() - t0) / reps
@@ -158,7 +162,7 @@ def main():
                                    f"N_samples={a.n_samples}, N_importance={a.n_importance}, mode=linear/midpoint, "
                                    f"white_bkgd, perturb=1; full step = render + backward + grad all-reduce + 2xAdam",
                        "global_rays": R * world, "precision": a.precision, "parallelism": f"dp{world}",
-                       "final_loss": float(loss)},
+                       "final_loss": float(loss.detach())},
             "roofline": {
                 "bound": "mfma", "kernel": "mlp_fwd_f32_kernel (fine network, fused PE+12-layer MLP forward)",
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": (ach / peak) if ach else None,

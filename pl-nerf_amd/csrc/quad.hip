@@ -291,8 +291,8 @@ __global__ __launch_bounds__(256) void quad_bwd_kernel(QuadArgs a) {
 
 int check_common(const float* raw, const float* z, const float* near, const float* far,
                  const float* rays_d, int R, int S, int mode, int color_mode) {
-    if (!raw || !z || !near || !far || !rays_d) return PLNERF_EINVAL;
     if (R < 0 || S < 2) return PLNERF_EINVAL;
+    if (R > 0 && (!raw || !z || !near || !far || !rays_d)) return PLNERF_EINVAL;
     if (S > PLNERF_MAX_SAMPLES) return PLNERF_ERANGE;
     if (mode != PLNERF_MODE_LINEAR && mode != PLNERF_MODE_CONSTANT) return PLNERF_EINVAL;
     if (color_mode != PLNERF_COLOR_MIDPOINT && color_mode != PLNERF_COLOR_LEFT) return PLNERF_EINVAL;
@@ -308,8 +308,8 @@ extern "C" int plnerf_quad_fwd(const float* raw, const float* z, const float* ne
                                float* tau, float* T, plnerf_stream_t stream) {
     int rc = check_common(raw, z, near, far, rays_d, R, S, mode, color_mode);
     if (rc) return rc;
-    if (!rgb_map || !disp_map || !acc_map || !depth_map) return PLNERF_EINVAL;
     if (R == 0) return PLNERF_OK;
+    if (!rgb_map || !disp_map || !acc_map || !depth_map) return PLNERF_EINVAL;
     QuadArgs a{};
     a.raw = raw; a.z = z; a.near = near; a.far = far; a.rays_d = rays_d; a.noise = noise;
     a.R = R; a.S = S; a.color_mode = color_mode; a.white_bkgd = white_bkgd; a.farcolorfix = farcolorfix;
@@ -343,8 +343,8 @@ extern "C" int plnerf_quad_bwd(const float* raw, const float* z, const float* ne
                                float* g_raw, plnerf_stream_t stream) {
     int rc = check_common(raw, z, near, far, rays_d, R, S, mode, color_mode);
     if (rc) return rc;
-    if (!g_rgb || !g_raw) return PLNERF_EINVAL;
     if (R == 0) return PLNERF_OK;
+    if (!g_rgb || !g_raw) return PLNERF_EINVAL;
     QuadArgs a{};
     a.raw = raw; a.z = z; a.near = near; a.far = far; a.rays_d = rays_d; a.noise = noise;
     a.R = R; a.S = S; a.color_mode = color_mode; a.white_bkgd = white_bkgd; a.farcolorfix = farcolorfix;

@@ -64,12 +64,13 @@ class QuadratureFn(torch.autograd.Function):
         w = torch.empty(R, n, device=dev)
         tau = torch.empty(R, S + 2, device=dev) if linear else torch.empty(0, device=dev)
         T = torch.empty(R, S + 2, device=dev) if linear else torch.empty(0, device=dev)
-        L.check(L.lib().plnerf_quad_fwd(
-            L.dptr(raw_c, "raw"), L.dptr(z_c, "z_vals"), L.dptr(near_c, "near"), L.dptr(far_c, "far"),
-            L.dptr(d_c, "rays_d"), L.dptr(noise_c, "noise"), R, S, L.MODE[mode], L.COLOR[color_mode],
-            int(bool(white_bkgd)), int(bool(farcolorfix)), L.dptr(rgb), L.dptr(disp), L.dptr(acc),
-            L.dptr(depth), L.dptr(w), L.dptr(tau) if linear else None, L.dptr(T) if linear else None,
-            L.stream()), "plnerf_quad_fwd")
+        if R > 0:
+            L.check(L.lib().plnerf_quad_fwd(
+              L.dptr(raw_c, "raw"), L.dptr(z_c, "z_vals"), L.dptr(near_c, "near"), L.dptr(far_c, "far"),
+              L.dptr(d_c, "rays_d"), L.dptr(noise_c, "noise"), R, S, L.MODE[mode], L.COLOR[color_mode],
+              int(bool(white_bkgd)), int(bool(farcolorfix)), L.dptr(rgb), L.dptr(disp), L.dptr(acc),
+              L.dptr(depth), L.dptr(w), L.dptr(tau) if linear else None, L.dptr(T) if linear else None,
+              L.stream()), "plnerf_quad_fwd")
         ctx.save_for_backward(raw_c, z_c, near_c, far_c, d_c, noise_c if noise_c is not None else torch.empty(0),
                               depth, acc)
         ctx.cfg = (mode, color_mode, bool(white_bkgd), bool(farcolorfix), noise_c is not None)
@@ -98,11 +99,12 @@ class QuadratureFn(torch.autograd.Function):
             g_acc = ga if g_acc is None else g_acc + ga
         g_w = None if g_w is None else _f32c(g_w)
         g_raw = torch.empty(R, S, 4, device=dev)
-        L.check(L.lib().plnerf_quad_bwd(
-            L.dptr(raw_c), L.dptr(z_c), L.dptr(near_c), L.dptr(far_c), L.dptr(d_c),
-            L.dptr(noise_c) if has_noise else None, R, S, L.MODE[mode], L.COLOR[color_mode],
-            int(white_bkgd), int(farcolorfix), L.dptr(g_rgb), L.dptr(g_depth), L.dptr(g_acc), L.dptr(g_w),
-            L.dptr(g_raw), L.stream()), "plnerf_quad_bwd")
+        if R > 0:
+            L.check(L.lib().plnerf_quad_bwd(
+              L.dptr(raw_c), L.dptr(z_c), L.dptr(near_c), L.dptr(far_c), L.dptr(d_c),
+              L.dptr(noise_c) if has_noise else None, R, S, L.MODE[mode], L.COLOR[color_mode],
+              int(white_bkgd), int(farcolorfix), L.dptr(g_rgb), L.dptr(g_depth), L.dptr(g_acc), L.dptr(g_w),
+              L.dptr(g_raw), L.stream()), "plnerf_quad_bwd")
         return g_raw, None, None, None, None, None, None, None, None, None
 
 
@@ -177,9 +179,10 @@ def sample_const(bins, weights, u, want_inds=False):
     stride = N if u_c.dim() == 2 else 0
     out = torch.empty(R, N, device=dev)
     inds = torch.empty(R, N, device=dev, dtype=torch.int64) if want_inds else None
-    L.check(L.lib().plnerf_sample_const(
-        L.dptr(bins_c, "bins"), L.dptr(w_c, "weights"), L.dptr(u_c, "u"), stride, R, B, N, L.dptr(out),
-        L.dptr(inds, "inds", torch.int64), L.stream()), "plnerf_sample_const")
+    if R > 0:
+        L.check(L.lib().plnerf_sample_const(
+            L.dptr(bins_c, "bins"), L.dptr(w_c, "weights"), L.dptr(u_c, "u"), stride, R, B, N, L.dptr(out),
+            L.dptr(inds, "inds", torch.int64), L.stream()), "plnerf_sample_const")
     return (out, inds) if want_inds else out
 
 
@@ -196,11 +199,12 @@ def sample_pl(z, weights, tau, T, near, far, u, zero_tol, eps, want_extras=False
     taub = torch.empty(R, N, device=dev) if want_extras else None
     binb = torch.empty(R, N, device=dev) if want_extras else None
     inds = torch.empty(R, N, device=dev, dtype=torch.int64) if want_inds else None
-    L.check(L.lib().plnerf_sample_pl(
-        L.dptr(z_c, "z_vals"), L.dptr(w_c, "weights"), L.dptr(tau_c, "tau"), L.dptr(T_c, "T"),
-        L.dptr(near_c, "near"), L.dptr(far_c, "far"), L.dptr(u_c, "u"), stride, R, S, N, float(zero_tol),
-        float(eps), L.dptr(out), L.dptr(Tb), L.dptr(taub), L.dptr(binb), L.dptr(inds, "inds", torch.int64),
-        L.stream()), "plnerf_sample_pl")
+    if R > 0:
+        L.check(L.lib().plnerf_sample_pl(
+            L.dptr(z_c, "z_vals"), L.dptr(w_c, "weights"), L.dptr(tau_c, "tau"), L.dptr(T_c, "T"),
+            L.dptr(near_c, "near"), L.dptr(far_c, "far"), L.dptr(u_c, "u"), stride, R, S, N, float(zero_tol),
+            float(eps), L.dptr(out), L.dptr(Tb), L.dptr(taub), L.dptr(binb),
+            L.dptr(inds, "inds", torch.int64), L.stream()), "plnerf_sample_pl")
     if want_extras:
         return (out, Tb, taub, binb, inds) if want_inds else (out, Tb, taub, binb)
     return (out, inds) if want_inds else out
@@ -211,9 +215,15 @@ def merge_sort(z, z_new, near, far):
     R, S = z.shape
     N = z_new.shape[-1]
     out = torch.empty(R, S + N, device=z.device)
+    if R == 0:
+        return out
+    # keep every (possibly copied) operand alive until the launch is enqueued: a temporary
+    # freed mid-expression would hand its block to the next temporary
+    z_c, zn_c = _f32c(z), _f32c(z_new)
+    near_c, far_c = _f32c(near).reshape(-1), _f32c(far).reshape(-1)
     L.check(L.lib().plnerf_merge_sort(
-        L.dptr(_f32c(z), "z_vals"), L.dptr(_f32c(z_new), "z_samples"), L.dptr(_f32c(near).reshape(-1), "near"),
-        L.dptr(_f32c(far).reshape(-1), "far"), R, S, N, L.dptr(out), L.stream()), "plnerf_merge_sort")
+        L.dptr(z_c, "z_vals"), L.dptr(zn_c, "z_samples"), L.dptr(near_c, "near"), L.dptr(far_c, "far"),
+        R, S, N, L.dptr(out), L.stream()), "plnerf_merge_sort")
     return out
 
 
