@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--rays", type=int, default=4096, help="N_rand per GPU")
     ap.add_argument("--n-samples", type=int, default=64)
     ap.add_argument("--n-importance", type=int, default=128)
-    ap.add_argument("--precision", default="fp32", choices=["fp32"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -157,14 +157,14 @@ def main():
             "metric": "training rays/sec (coarse+fine, 64+128 samples)",
             "value": R * world * a.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"fp32": "f32"}[a.precision], "data": "synthetic",
+            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (3-term bf16 split, f32 accumulate; weight gradients f32)", "bf16": "bf16 (f32 accumulate; weight gradients f32)"}[a.precision], "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: 800x800 Blender-style rays, N_rand={R}/GPU, "
                                    f"N_samples={a.n_samples}, N_importance={a.n_importance}, mode=linear/midpoint, "
                                    f"white_bkgd, perturb=1; full step = render + backward + grad all-reduce + 2xAdam",
                        "global_rays": R * world, "precision": a.precision, "parallelism": f"dp{world}",
                        "final_loss": float(loss.detach())},
             "roofline": {
-                "bound": "mfma", "kernel": "mlp_fwd_f32_kernel (fine network, fused PE+12-layer MLP forward)",
+                "bound": "mfma", "kernel": ("mlp_fwd_f32_kernel" if a.precision == "fp32" else "mlp_fwd_bf16_kernel") + " (fine network, fused PE+12-layer MLP forward)",
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": (ach / peak) if ach else None,
                 "traffic": None, "launch_ms": fwd_ms, "rows_per_launch": rows_fine,
                 "flop_per_row": FWD_FLOP_PER_ROW,

@@ -1,0 +1,76 @@
+// MLP entry points of the C ABI (include/plnerf_hip.h): argument validation and dispatch on
+// the precision mode.  Kernels live in mlp_f32.hip (exact fp32 MFMA; also the shared
+// weight-gradient stage) and mlp_bf16.hip (bf16 / 3-term bf16 split MFMA).
+#include "common.h"
+#include "mlp_internal.h"
+#include "mlp_layout.h"
+
+using namespace plnerf;
+
+namespace {
+inline int ns_of(int precision) {
+    return precision == PLNERF_PREC_BF16 ? 1 : precision == PLNERF_PREC_BF16X3 ? 2 : 0;
+}
+inline bool known(int precision) {
+    return precision == PLNERF_PREC_FP32 || precision == PLNERF_PREC_BF16 || precision == PLNERF_PREC_BF16X3;
+}
+}  // namespace
+
+extern "C" size_t plnerf_mlp_packed_bytes(int precision) {
+    if (precision == PLNERF_PREC_FP32) return impl::f32_packed_bytes();
+    if (ns_of(precision)) return impl::bf16_packed_bytes(ns_of(precision));
+    return 0;
+}
+
+extern "C" int plnerf_mlp_pack_weights(const float* const* params, int precision, void* packed,
+                                       plnerf_stream_t stream) {
+    if (!params || !packed) return PLNERF_EINVAL;
+    if (!known(precision)) return PLNERF_ENOSYS;
+    for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i)
+        if (!params[i]) return PLNERF_EINVAL;
+    if (precision == PLNERF_PREC_FP32) return impl::f32_pack(params, packed, (hipStream_t)stream);
+    return impl::bf16_pack(params, ns_of(precision), packed, (hipStream_t)stream);
+}
+
+extern "C" size_t plnerf_mlp_saved_bytes(int n_rows, int precision) {
+    if (!known(precision) || n_rows < 0) return 0;
+    return (size_t)lay::SAVED_PER_ROW * (size_t)n_rows * sizeof(float);
+}
+
+extern "C" size_t plnerf_mlp_bwd_workspace_bytes(int n_rows, int precision) {
+    if (!known(precision) || n_rows < 0) return 0;
+    return ((size_t)lay::DZ_PER_ROW * (size_t)n_rows + (size_t)lay::MAX_SPLITS * lay::PART_PER_SPLIT +
+            (size_t)lay::MAX_HEAD_WGS * lay::HEAD_PART) * sizeof(float);
+}
+
+extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pts, const float* viewdirs,
+                              const float* embedded, int n_rows, int samples_per_ray, float* raw_out,
+                              void* saved, plnerf_stream_t stream) {
+    if (!known(precision)) return PLNERF_ENOSYS;
+    if (n_rows < 0) return PLNERF_EINVAL;
+    if (n_rows == 0) return PLNERF_OK;
+    if (!packed || !raw_out) return PLNERF_EINVAL;
+    if (!embedded && (!pts || !viewdirs || samples_per_ray < 1)) return PLNERF_EINVAL;
+    if (precision == PLNERF_PREC_FP32)
+        return impl::f32_fwd(packed, pts, viewdirs, embedded, n_rows, samples_per_ray, raw_out, saved,
+                             (hipStream_t)stream);
+    return impl::bf16_fwd(packed, ns_of(precision), pts, viewdirs, embedded, n_rows, samples_per_ray, raw_out,
+                          saved, (hipStream_t)stream);
+}
+
+extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, int n_rows,
+                              const void* saved, void* workspace, float* const* grads,
+                              plnerf_stream_t stream) {
+    if (!known(precision)) return PLNERF_ENOSYS;
+    if (!packed || !g_raw || !saved || !workspace || !grads || n_rows < 1) return PLNERF_EINVAL;
+    for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i)
+        if (!grads[i]) return PLNERF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    float* dz = (float*)workspace;
+    int rc;
+    if (precision == PLNERF_PREC_FP32) rc = impl::f32_dgrad(packed, g_raw, n_rows, (const float*)saved, dz, st);
+    else rc = impl::bf16_dgrad(packed, ns_of(precision), g_raw, n_rows, (const float*)saved, dz, st);
+    if (rc) return rc;
+    // weight gradients over the fp32 planes; the big 256x256 jobs use the mode's MFMA type
+    return impl::f32_wgrad(g_raw, n_rows, (const float*)saved, dz, grads, ns_of(precision), st);
+}

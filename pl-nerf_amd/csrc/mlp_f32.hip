@@ -29,7 +29,9 @@
 // the reference's CPU GEMM, i.e. fp32 round-off (~1e-7 relative), well inside the 1e-5
 // parity bound.
 #include "common.h"
+#include "mlp_internal.h"
 #include "mlp_layout.h"
+#include "mlp_pack_src.h"
 
 using namespace plnerf;
 using namespace plnerf::lay;
@@ -39,8 +41,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-struct ParamPtrs { const float* p[PLNERF_N_PARAM_TENSORS]; };
-struct GradPtrs { float* p[PLNERF_N_PARAM_TENSORS]; };
 
 constexpr int LDA = 260;  // activation tile row stride (floats): == 4 mod 64 -> conflict-free b128 reads
 constexpr int LDP = 68;   // xyz-encoding tile row stride
@@ -49,34 +49,6 @@ constexpr int LDD = 36;   // direction-encoding tile row stride
 // ------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ float fwd_src(const ParamPtrs& P, int g, int k, int j) {
-    switch (g) {
-        case G_L0: return k < XYZ_CH ? P.p[0][j * XYZ_CH + k] : 0.0f;
-        case G_L5:
-            if (k < PE_K) return k < XYZ_CH ? P.p[10][j * (W + XYZ_CH) + k] : 0.0f;
-            return P.p[10][j * (W + XYZ_CH) + XYZ_CH + (k - PE_K)];
-        case G_FEAT: return P.p[P_WF][j * W + k];
-        case G_VIEWS:
-            if (k < W) return P.p[P_WV][j * (W + DIR_CH) + k];
-            return (k - W) < DIR_CH ? P.p[P_WV][j * (W + DIR_CH) + k] : 0.0f;
-        default: return P.p[2 * g][j * W + k];  // G_L1..G_L4, G_L6, G_L7: layer index == g
-    }
-}
-
-__device__ __forceinline__ float bwd_src(const ParamPtrs& P, int g, int o, int i) {
-    switch (g) {
-        case D_VIEWS: return P.p[P_WV][o * (W + DIR_CH) + i];
-        case D_FEAT: return P.p[P_WF][o * W + i];
-        case D_L5: return P.p[10][o * (W + XYZ_CH) + XYZ_CH + i];
-        case D_L7: return P.p[14][o * W + i];
-        case D_L6: return P.p[12][o * W + i];
-        case D_L4: return P.p[8][o * W + i];
-        case D_L3: return P.p[6][o * W + i];
-        case D_L2: return P.p[4][o * W + i];
-        default: return P.p[2][o * W + i];  // D_L1
-    }
-}
-
 __global__ void pack_f32_kernel(ParamPtrs P, float* __restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= PACKED_FLOATS) return;
@@ -581,6 +553,104 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradArgs a) {
     }
 }
 
+// The same TN GEMM on v_mfma_f32_32x32x16_bf16 for the bf16 / bf16x3 modes.  The operands are
+// still the fp32 [row][feature] planes: a lane builds its k-contiguous fragment (8 consecutive
+// rows of one feature column) from 8 coalesced dword loads and splits it into bf16 hi (+ lo) in
+// registers, so no transposed copy of the activations is ever stored.  One load buffer per
+// operand: fragments are built from it, then the next 16 rows are requested into the same
+// registers and arrive while this step's NO*NI*(1|3) MFMAs run.
+// 8 waves as 4(o) x 2(i), each 64(o) x 128(i): a 256 x 256 workgroup tile reads every plane once.
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+
+template <int NS>
+__device__ __forceinline__ void split_frag(const float (&v)[8], wbf16x8& hi, wbf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        hi[e] = (__bf16)v[e];
+        if (NS == 2) lo[e] = (__bf16)(v[e] - (float)hi[e]);
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(512) void wgrad_bf16_kernel(WgradArgs a) {
+    constexpr int NO = 2, NI = 4, WI = 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const WJob job = a.jobs[a.tile_job[blockIdx.x]];
+    const int wo = wave / WI, wi = wave % WI;
+    const int o_base = a.tile_o0[blockIdx.x] + wo * NO * 32;
+    const int i_base = wi * NI * 32;
+    const bool o_live = o_base < job.O;          // view layer: O = 128, upper o-waves idle
+    const int split = blockIdx.y;
+    const int m_begin = split * a.rows_per_split;
+    const int m_end = min(a.n_rows, m_begin + a.rows_per_split);
+    const int g8 = 8 * (lane >> 5), ll = lane & 31;
+    const float* Ap = job.A + (o_live ? o_base : 0) + ll;
+    const float* Bp = job.B + i_base + ll;
+    f32x16 acc[NO][NI];
+    zero_acc(acc);
+    float bsum[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) bsum[o] = 0.0f;
+    float av[NO][8], bv[NI][8];
+    auto load = [&](int m) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int mm = m + g8 + e;
+            const bool ok = mm < m_end;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) av[o][e] = ok ? Ap[(size_t)mm * job.lda + o * 32] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) bv[i][e] = ok ? Bp[(size_t)mm * job.ldb + i * 32] : 0.0f;
+        }
+    };
+    if (m_begin < m_end) load(m_begin);
+    for (int m = m_begin; m < m_end; m += 16) {
+        wbf16x8 ah[NO], al[NO], bh[NI], bl[NI];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            split_frag<NS>(av[o], ah[o], al[o]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum[o] += av[o][e];
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) split_frag<NS>(bv[i], bh[i], bl[i]);
+        if (m + 16 < m_end) load(m + 16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int o = 0; o < NO; ++o)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                acc[o][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[o], bh[i], acc[o][i], 0, 0, 0);
+                if (NS == 2) {
+                    acc[o][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[o], bh[i], acc[o][i], 0, 0, 0);
+                    acc[o][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[o], bl[i], acc[o][i], 0, 0, 0);
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!o_live) return;
+    float* part = a.part + (size_t)split * PART_PER_SPLIT;
+    float* cpart = part + job.part_off;
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int orow = o_base + o * 32 + frag_row(r, lane);
+                const int icol = i_base + i * 32 + ll;
+                cpart[(size_t)orow * job.I + icol] = acc[o][i][r];
+            }
+    if (job.bias_off >= 0 && wi == 0) {
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            const float b = bsum[o] + __shfl_xor(bsum[o], 32);
+            if (lane < 32) part[job.bias_off + o_base + o * 32 + ll] = b;
+        }
+    }
+}
+
 // sigma / rgb heads: dW_alpha = sum_m g_sigma h7, dW_rgb[c] = sum_m g_c hv, and their biases
 struct HeadArgs {
     const float* g_raw;
@@ -715,52 +785,32 @@ inline int head_wgs_for(int n_rows) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------
-// C ABI
+// launchers (called from mlp_api.hip)
 // ------------------------------------------------------------------------------------
-extern "C" size_t plnerf_mlp_packed_bytes(int precision) {
-    if (precision == PLNERF_PREC_FP32) return (size_t)PACKED_FLOATS * sizeof(float);
-    return 0;
-}
+namespace plnerf {
+namespace impl {
 
-extern "C" int plnerf_mlp_pack_weights(const float* const* params, int precision, void* packed,
-                                       plnerf_stream_t stream) {
-    if (!params || !packed) return PLNERF_EINVAL;
-    if (precision != PLNERF_PREC_FP32) return PLNERF_ENOSYS;
+size_t f32_packed_bytes() { return (size_t)PACKED_FLOATS * sizeof(float); }
+
+int f32_pack(const float* const* params, void* packed, hipStream_t st) {
     ParamPtrs P;
     for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i) {
         if (!params[i]) return PLNERF_EINVAL;
         P.p[i] = params[i];
     }
     const int threads = 256, blocks = (PACKED_FLOATS + threads - 1) / threads;
-    hipLaunchKernelGGL(pack_f32_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, P, (float*)packed);
+    hipLaunchKernelGGL(pack_f32_kernel, dim3(blocks), dim3(threads), 0, st, P, (float*)packed);
     PLNERF_CHECK_LAUNCH();
     return PLNERF_OK;
 }
 
-extern "C" size_t plnerf_mlp_saved_bytes(int n_rows, int precision) {
-    if (precision != PLNERF_PREC_FP32 || n_rows < 0) return 0;
-    return (size_t)SAVED_PER_ROW * (size_t)n_rows * sizeof(float);
-}
-
-extern "C" size_t plnerf_mlp_bwd_workspace_bytes(int n_rows, int precision) {
-    if (precision != PLNERF_PREC_FP32 || n_rows < 0) return 0;
-    return ((size_t)DZ_PER_ROW * (size_t)n_rows + (size_t)MAX_SPLITS * PART_PER_SPLIT +
-            (size_t)MAX_HEAD_WGS * HEAD_PART) * sizeof(float);
-}
-
-extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pts, const float* viewdirs,
-                              const float* embedded, int n_rows, int samples_per_ray, float* raw_out,
-                              void* saved, plnerf_stream_t stream) {
-    if (precision != PLNERF_PREC_FP32) return PLNERF_ENOSYS;
-    if (!packed || !raw_out || n_rows < 0) return PLNERF_EINVAL;
-    if (!embedded && (!pts || !viewdirs || samples_per_ray < 1)) return PLNERF_EINVAL;
-    if (n_rows == 0) return PLNERF_OK;
+int f32_fwd(const void* packed, const float* pts, const float* viewdirs, const float* embedded, int n_rows,
+            int samples_per_ray, float* raw_out, void* saved, hipStream_t st) {
     constexpr int NI = 2, TM = 32 * NI;
     FwdArgs a{(const float*)packed, pts, viewdirs, embedded, n_rows, samples_per_ray < 1 ? 1 : samples_per_ray,
               raw_out, (float*)saved};
     const size_t lds = (size_t)TM * (LDA + LDP + LDD) * sizeof(float);
     dim3 grid((n_rows + TM - 1) / TM), block(256);
-    hipStream_t st = (hipStream_t)stream;
     if (saved) {
         (void)hipFuncSetAttribute((const void*)mlp_fwd_f32_kernel<NI, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -774,29 +824,24 @@ extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pt
     return PLNERF_OK;
 }
 
-extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, int n_rows,
-                              const void* saved, void* workspace, float* const* grads,
-                              plnerf_stream_t stream) {
-    if (precision != PLNERF_PREC_FP32) return PLNERF_ENOSYS;
-    if (!packed || !g_raw || !saved || !workspace || !grads || n_rows < 1) return PLNERF_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
+int f32_dgrad(const void* packed, const float* g_raw, int n_rows, const float* saved, float* dz, hipStream_t st) {
+    constexpr int NI = 2, TM = 32 * NI;
+    BwdArgs a{(const float*)packed, g_raw, n_rows, saved, dz};
+    const size_t lds = (size_t)(TM * LDA + TM * 4) * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)mlp_bwd_f32_kernel<NI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL((mlp_bwd_f32_kernel<NI>), dim3((n_rows + TM - 1) / TM), dim3(256), lds, st, a);
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}
+
+// Weight gradients from the fp32 planes (saved activations + dz planes written by any of the
+// dgrad kernels): split-K partials, head reductions, deterministic final sum into grads[24].
+int f32_wgrad(const float* g_raw, int n_rows, const float* sv, float* dz, float* const* grads, int ns,
+              hipStream_t st) {
     const size_t N = (size_t)n_rows;
-    const float* sv = (const float*)saved;
-    float* dz = (float*)workspace;
     float* part = dz + (size_t)DZ_PER_ROW * N;
     float* head_part = part + (size_t)MAX_SPLITS * PART_PER_SPLIT;
-
-    // 1. dgrad chain
-    {
-        constexpr int NI = 2, TM = 32 * NI;
-        BwdArgs a{(const float*)packed, g_raw, n_rows, sv, dz};
-        const size_t lds = (size_t)(TM * LDA + TM * 4) * sizeof(float);
-        (void)hipFuncSetAttribute((const void*)mlp_bwd_f32_kernel<NI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        hipLaunchKernelGGL((mlp_bwd_f32_kernel<NI>), dim3((n_rows + TM - 1) / TM), dim3(256), lds, st, a);
-        PLNERF_CHECK_LAUNCH();
-    }
-    // 2. weight gradients (split-K partials)
     const int splits = splits_for(n_rows);
     int rps = (n_rows + splits - 1) / splits;
     rps = (rps + 15) & ~15;
@@ -826,14 +871,16 @@ extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_
             jb.lda = W; jb.ldb = W; jb.O = W; jb.I = W;
             jb.part_off = PART_MAIN + j * W * W;
             a.tile_job[nt] = j; a.tile_o0[nt++] = 0;
-            a.tile_job[nt] = j; a.tile_o0[nt++] = 128;
+            if (ns == 0) { a.tile_job[nt] = j; a.tile_o0[nt++] = 128; }   // f32 kernel: 128-row o tiles
         }
         WJob& jv = a.jobs[8];
         jv.A = dzv_plane; jv.lda = HV; jv.B = splane(SV_FEAT); jv.ldb = W; jv.O = HV; jv.I = W;
         jv.part_off = PART_VMAIN; jv.bias_off = PART_BIAS + 9 * W;
         a.tile_job[nt] = 8; a.tile_o0[nt++] = 0;
         a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
-        hipLaunchKernelGGL((wgrad_f32_kernel<2, 2, 2, 4, 4>), dim3(nt, splits), dim3(256), 0, st, a);
+        if (ns == 0) hipLaunchKernelGGL((wgrad_f32_kernel<2, 2, 2, 4, 4>), dim3(nt, splits), dim3(256), 0, st, a);
+        else if (ns == 1) hipLaunchKernelGGL(wgrad_bf16_kernel<1>, dim3(nt, splits), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL(wgrad_bf16_kernel<2>, dim3(nt, splits), dim3(512), 0, st, a);
         PLNERF_CHECK_LAUNCH();
     }
     {
@@ -862,7 +909,6 @@ extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_
         hipLaunchKernelGGL(wgrad_head_kernel, dim3(n_head), dim3(256), 0, st, a);
         PLNERF_CHECK_LAUNCH();
     }
-    // 3. deterministic reduction into the 24 gradient tensors
     {
         ReduceArgs a{};
         a.part = part; a.head_part = head_part; a.splits = splits; a.n_head = n_head;
@@ -876,6 +922,9 @@ extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_
     }
     return PLNERF_OK;
 }
+
+}  // namespace impl
+}  // namespace plnerf
 
 extern "C" int plnerf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                                 int64_t n, float lr, float beta1, float beta2, float eps, int step,

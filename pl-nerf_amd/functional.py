@@ -114,7 +114,7 @@ class MlpFn(torch.autograd.Function):
     do not depend on parameters on this path)."""
 
     @staticmethod
-    def forward(ctx, pts, viewdirs, embedded, spr, net, *params):
+    def forward(ctx, pts, viewdirs, embedded, spr, net, want_grad, *params):
         prec = L.PRECISION[net.precision]
         packed = net.packed_weights()
         if embedded is not None:
@@ -126,7 +126,8 @@ class MlpFn(torch.autograd.Function):
             n_rows, dev = pts_c.shape[0], pts_c.device
             emb_c = None
         raw = torch.empty(n_rows, 4, device=dev)
-        need_grad = any(ctx.needs_input_grad[5:])
+        # grad mode is always off inside Function.forward: the caller samples torch.is_grad_enabled()
+        need_grad = bool(want_grad) and any(ctx.needs_input_grad[6:])
         saved = None
         if need_grad and n_rows > 0:
             nbytes = L.lib().plnerf_mlp_saved_bytes(n_rows, prec)
@@ -151,9 +152,11 @@ class MlpFn(torch.autograd.Function):
     def backward(ctx, g_raw):
         n_rows, prec = ctx.n_rows, ctx.prec
         dev = g_raw.device
+        if ctx.saved_acts is None and n_rows > 0:
+            raise RuntimeError("plnerf_amd: backward through an MLP forward that ran without saved state")
         grads = [torch.empty(s, device=dev, dtype=torch.float32) for s in ctx.param_shapes]
         if n_rows == 0:
-            return (None,) * 5 + tuple(torch.zeros_like(g) for g in grads)
+            return (None,) * 6 + tuple(torch.zeros_like(g) for g in grads)
         g = _f32c(g_raw)
         ws = torch.empty(L.lib().plnerf_mlp_bwd_workspace_bytes(n_rows, prec) // 4, device=dev,
                          dtype=torch.float32)
@@ -167,7 +170,7 @@ class MlpFn(torch.autograd.Function):
         if timer is not None:
             ev[1].record()
         ctx.saved_acts = None
-        return (None,) * 5 + tuple(grads)
+        return (None,) * 6 + tuple(grads)
 
 
 def sample_const(bins, weights, u, want_inds=False):

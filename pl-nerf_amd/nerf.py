@@ -134,7 +134,7 @@ class NeRF(nn.Module):
         self._require_supported()
         lead = x.shape[:-1]
         flat = x.reshape(-1, x.shape[-1])
-        out = MlpFn.apply(None, None, flat, 1, self, *self.param_list())
+        out = MlpFn.apply(None, None, flat, 1, self, torch.is_grad_enabled(), *self.param_list())
         return out.reshape(*lead, 4)
 
     def query(self, pts, viewdirs):
@@ -142,5 +142,5 @@ class NeRF(nn.Module):
         the kernel prologue (what run_network does on the hot path)."""
         self._require_supported()
         R, S = pts.shape[0], pts.shape[1]
-        out = MlpFn.apply(pts.reshape(-1, 3), viewdirs, None, S, self, *self.param_list())
+        out = MlpFn.apply(pts.reshape(-1, 3), viewdirs, None, S, self, torch.is_grad_enabled(), *self.param_list())
         return out.reshape(R, S, 4)

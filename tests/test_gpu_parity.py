@@ -280,6 +280,100 @@ def test_mlp_fwd_bwd_vs_oracle(P, R, S):
         assert err <= 2e-5 * max(scale, 1e-3) + 1e-7, f"grad {name}: max err {err:.3e} vs scale {scale:.3e}"
 
 
+@pytest.mark.parametrize("precision,fwd_tol,grad_tol", [("bf16x3", 1e-5, 1e-4), ("bf16", 5e-3, 5e-2)])
+def test_mlp_bf16_modes(P, golden, precision, fwd_tol, grad_tol):
+    """The bf16-MFMA modes: bf16x3 (3-term split) must hold the 1e-5 forward bound on the golden
+    vectors (G1) like fp32 does; plain bf16 is the throughput mode and is only held to 5e-3."""
+    gd = golden("g1_mlp")
+    pts, vd = g(T(gd["pts"])), g(T(gd["viewdirs"]))
+    for tag, sharp in (("plain", False), ("sharp", True)):
+        net = make_net(P, orc.closed_form_state_dict(0, sharp), precision)
+        with torch.no_grad():
+            raw = net.query(pts, vd)
+            raw_emb = net(g(T(gd["embedded"])))
+        e1, e2 = maxdiff(raw, T(gd[f"raw_{tag}"])), maxdiff(raw_emb, T(gd[f"raw_from_embedded_{tag}"]))
+        print(f"{precision} g1 {tag}: max err fused={e1:.3e} embedded={e2:.3e}")
+        assert e1 <= fwd_tol and e2 <= fwd_tol
+    # forward + all 24 gradients, two tile shapes (incl. a ragged tail).  ReLU makes the gradient
+    # discontinuous: a pre-activation within the forward's rounding error of zero can flip its mask
+    # and move a gradient entry by O(1e-2).  So the cotangent is zeroed on samples that have any
+    # pre-activation within `amb` of zero in an fp64 evaluation -- on the remaining samples every mode
+    # takes the same ReLU branches as the oracle and the comparison is sharp.
+    amb = 5e-5 if precision == "bf16x3" else 0.0     # plain bf16: no sharp comparison possible
+    for R, S in ((5, 64), (7, 101)):
+        gen = torch.Generator().manual_seed(R * 100 + S)
+        ptsr = (torch.rand(R, S, 3, generator=gen) * 2 - 1) * 2.5
+        vdr = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
+        cot = torch.randn(R, S, 4, generator=gen)
+        sd = orc.closed_form_state_dict(3, False)
+        keep = ~ambiguous_rows(sd, ptsr, vdr, amb)
+        cot = cot * keep.reshape(R, S, 1)
+        sd_o = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        raw_o = orc.query_network(sd_o, ptsr, vdr)
+        (raw_o * cot).sum().backward()
+        net = make_net(P, sd, precision)
+        raw_h = net.query(g(ptsr), g(vdr))
+        assert maxdiff(raw_h, raw_o) <= fwd_tol, f"{precision} fwd R={R} S={S}: {maxdiff(raw_h, raw_o):.3e}"
+        (raw_h * g(cot)).sum().backward()
+        worst, worst_cos = 0.0, 1.0
+        for name, prm in net.named_parameters():
+            ref = sd_o[name].grad
+            worst = max(worst, maxdiff(prm.grad, ref) / max(float(ref.abs().max()), 1e-3))
+            worst_cos = min(worst_cos, float(torch.nn.functional.cosine_similarity(
+                prm.grad.detach().cpu().reshape(1, -1).double(), ref.reshape(1, -1).double())))
+        print(f"{precision} R={R} S={S}: {int(keep.sum())}/{keep.numel()} unambiguous samples, "
+              f"fwd err {maxdiff(raw_h, raw_o):.3e}, worst grad err/max|g| {worst:.3e}, worst cosine {worst_cos:.6f}")
+        if precision == "bf16x3":
+            assert worst <= grad_tol
+        else:   # bf16 flips ReLU branches near zero: hold direction, not entries
+            assert worst_cos >= 0.99
+
+
+def ambiguous_rows(sd, pts, vd, eps):
+    """Samples with some ReLU pre-activation within eps of zero (fp64 evaluation of the oracle net)."""
+    sd64 = {k: v.double() for k, v in sd.items()}
+    R, S = pts.shape[:2]
+    emb = torch.cat([orc.positional_encoding(pts.reshape(-1, 3).double(), 10),
+                     orc.positional_encoding(vd.double()[:, None].expand(R, S, 3).reshape(-1, 3), 4)], -1)
+    enc_xyz, enc_dir = emb[:, :63], emb[:, 63:]
+    h, bad = enc_xyz, torch.zeros(R * S, dtype=torch.bool)
+    for i in range(8):
+        pre = torch.nn.functional.linear(h, sd64[f"pts_linears.{i}.weight"], sd64[f"pts_linears.{i}.bias"])
+        bad |= (pre.abs() < eps).any(-1)
+        h = torch.relu(pre)
+        if i == 4:
+            h = torch.cat([enc_xyz, h], -1)
+    feat = torch.nn.functional.linear(h, sd64["feature_linear.weight"], sd64["feature_linear.bias"])
+    pre = torch.nn.functional.linear(torch.cat([feat, enc_dir], -1), sd64["views_linears.0.weight"],
+                                     sd64["views_linears.0.bias"])
+    bad |= (pre.abs() < eps).any(-1)
+    return bad
+
+
+def test_render_rays_golden_bf16x3(P, golden):
+    """End-to-end render on the golden rays in bf16x3 mode (reported; rgb asserted at 1e-4)."""
+    gd = golden("g5_render_rays")
+    emb_fn, _ = P.get_embedder(10, 0)
+    embd_fn, _ = P.get_embedder(4, 0)
+    for c in (0, 1):
+        p = f"c{c}_"
+        o, d, near, far = _g5_batch(gd, p)
+        net_c = make_net(P, orc.closed_form_state_dict(0, True), "bf16x3")
+        net_f = make_net(P, orc.closed_form_state_dict(1, True), "bf16x3")
+        qfn = lambda inputs, viewdirs, fn: P.run_network(inputs, viewdirs, fn, emb_fn, embd_fn)
+        kw = dict(network_query_fn=qfn, perturb=1.0, N_importance=int(gd[p + "N_importance"]), network_fine=net_f,
+                  N_samples=int(gd[p + "N_samples"]), network_fn=net_c, white_bkgd=True, raw_noise_std=0.0,
+                  mode="linear", color_mode="midpoint")
+        K = [[1111.111, 0, 400], [0, 1111.111, 400], [0, 0, 1]]
+        with torch.no_grad():
+            rgb, disp, acc, extras = P.render(800, 800, K, chunk=32768, rays=(g(o), g(d)), ndc=False, near=near,
+                                              far=far, use_viewdirs=True, retraw=True, pytest=True, **kw)
+        print(f"bf16x3 g5 case {c}: rgb0 err {maxdiff(extras['rgb0'], T(gd[p + 'rgb0'])):.3e}, "
+              f"rgb err {maxdiff(rgb, T(gd[p + 'rgb_map'])):.3e}, depth err {maxdiff(extras['depth_map'], T(gd[p + 'depth_map'])):.3e}")
+        assert_close(extras["rgb0"], gd[p + "rgb0"], atol=2e-5, rtol=2e-5, what="bf16x3 rgb0")
+        assert_close(rgb, gd[p + "rgb_map"], atol=1e-4, rtol=1e-4, what="bf16x3 rgb_map")
+
+
 def test_mlp_embedded_path_grads(P):
     gen = torch.Generator().manual_seed(17)
     N = 100
