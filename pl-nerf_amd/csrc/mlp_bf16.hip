@@ -247,7 +247,8 @@ __device__ __forceinline__ void load8(const __bf16* p0, const int plane_stride, 
 template <int NS, int WIDTH>
 __device__ __forceinline__ void tile_to_plane(const __bf16* tile, const int ld, const int plane_stride,
                                               float* __restrict__ plane, const int row0, const int rows_valid,
-                                              const int rows, const int tid) {
+                                              const int rows, const int tid,
+                                              unsigned char* __restrict__ mask_plane = nullptr) {
     constexpr int CPR = WIDTH / 8;   // 8-element chunks per row
     for (int idx = tid; idx < rows * CPR; idx += NTHREADS) {
         const int s = idx / CPR, c = idx - s * CPR;
@@ -257,6 +258,12 @@ __device__ __forceinline__ void tile_to_plane(const __bf16* tile, const int ld, 
         float4* dst = reinterpret_cast<float4*>(plane + (size_t)(row0 + s) * WIDTH + c * 8);
         dst[0] = make_float4(v[0], v[1], v[2], v[3]);
         dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+        if (mask_plane) {   // relu'(h) as one bit per activation, for the dgrad kernel
+            unsigned m = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m |= (v[e] > 0.0f ? 1u : 0u) << e;
+            mask_plane[(size_t)(row0 + s) * CPR + c] = (unsigned char)m;
+        }
     }
 }
 
@@ -384,6 +391,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_bf16_kernel(FwdArgs a) {
     const __bf16* dpe_lane = dpe + b_off * BLDD + b_k;
     f32x16 acc[NT];
 #define PLANE(p) (a.saved + (size_t)(p) * W * N)
+#define MASKP(p) (reinterpret_cast<unsigned char*>(a.saved + (size_t)SV_FLOATS * N) + (size_t)(p) * (W / 8) * N)
 #define WB(g, KS, ks0) wblock<NS>(a.packed, true, fwd_off(g), KS, wave, ks0)
 
     // Weight fragments of the NEXT GEMM are requested before the barrier + epilogue of the current
@@ -397,7 +405,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_bf16_kernel(FwdArgs a) {
     __syncthreads();
     store_act<NS, NT, true>(acc, act, ACT_PLANE, wave * 32, 0, lane);
     __syncthreads();
-    if (SAVE) tile_to_plane<NS, W>(act, BLDA, ACT_PLANE, PLANE(0), row0, rows_valid, TM, tid);
+    if (SAVE) tile_to_plane<NS, W>(act, BLDA, ACT_PLANE, PLANE(0), row0, rows_valid, TM, tid, MASKP(0));
     // L1..L4
 #pragma unroll 1
     for (int l = 1; l <= 4; ++l) {
@@ -413,7 +421,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_bf16_kernel(FwdArgs a) {
         __syncthreads();
         store_act<NS, NT, true>(acc, act, ACT_PLANE, wave * 32, 0, lane);
         __syncthreads();
-        if (SAVE) tile_to_plane<NS, W>(act, BLDA, ACT_PLANE, PLANE(l), row0, rows_valid, TM, tid);
+        if (SAVE) tile_to_plane<NS, W>(act, BLDA, ACT_PLANE, PLANE(l), row0, rows_valid, TM, tid, MASKP(l));
     }
     // L5 = [encoding | h4]
     init_acc(acc, hd + H_BIAS + 5 * W, wave * 32, lane);
@@ -426,7 +434,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_bf16_kernel(FwdArgs a) {
     __syncthreads();
     store_act<NS, NT, true>(acc, act, ACT_PLANE, wave * 32, 0, lane);
     __syncthreads();
-    if (SAVE) tile_to_plane<NS, W>(act, BLDA, ACT_PLANE, PLANE(5), row0, rows_valid, TM, tid);
+    if (SAVE) tile_to_plane<NS, W>(act, BLDA, ACT_PLANE, PLANE(5), row0, rows_valid, TM, tid, MASKP(5));
     // L6, L7
 #pragma unroll 1
     for (int l = 6; l <= 7; ++l) {
@@ -437,7 +445,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_bf16_kernel(FwdArgs a) {
         __syncthreads();
         store_act<NS, NT, true>(acc, act, ACT_PLANE, wave * 32, 0, lane);
         __syncthreads();
-        if (SAVE) tile_to_plane<NS, W>(act, BLDA, ACT_PLANE, PLANE(l), row0, rows_valid, TM, tid);
+        if (SAVE) tile_to_plane<NS, W>(act, BLDA, ACT_PLANE, PLANE(l), row0, rows_valid, TM, tid, MASKP(l));
     }
     // sigma head: TPR threads per sample, 8-feature chunks interleaved across them
     const int hrow = tid / TPR, hq = tid % TPR;
@@ -477,7 +485,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_bf16_kernel(FwdArgs a) {
         __syncthreads();
         store_act<NS, NTV, true>(accv, act, ACT_PLANE, vft * 32, vs0, lane);
         __syncthreads();
-        if (SAVE) tile_to_plane<NS, HV>(act, BLDA, ACT_PLANE, a.saved + (size_t)SV_HV_OFF * N, row0, rows_valid, TM, tid);
+        if (SAVE) tile_to_plane<NS, HV>(act, BLDA, ACT_PLANE, a.saved + (size_t)SV_HV_OFF * N, row0, rows_valid, TM, tid, MASKP(8));
     }
     // rgb head
     {
@@ -510,6 +518,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_bf16_kernel(FwdArgs a) {
         }
     }
 #undef PLANE
+#undef MASKP
 #undef WB
 }
 
@@ -525,19 +534,12 @@ struct BwdArgs {
 };
 
 // relu mask of a saved activation plane -> one bit per (sample, feature) in LDS
-__device__ __forceinline__ void build_mask(unsigned char* maskb, const float* __restrict__ plane, const int row0,
-                                           const int rows_valid, const int rows, const int tid) {
-    for (int idx = tid; idx < rows * 32; idx += NTHREADS) {
-        const int s = idx >> 5, c = idx & 31;
-        unsigned m = 0;
-        if (s < rows_valid) {
-            const float4* src = reinterpret_cast<const float4*>(plane + (size_t)(row0 + s) * W + c * 8);
-            const float4 x = src[0], y = src[1];
-            m = (x.x > 0.f) | ((x.y > 0.f) << 1) | ((x.z > 0.f) << 2) | ((x.w > 0.f) << 3) | ((y.x > 0.f) << 4) |
-                ((y.y > 0.f) << 5) | ((y.z > 0.f) << 6) | ((y.w > 0.f) << 7);
-        }
-        maskb[idx] = (unsigned char)m;
-    }
+__device__ __forceinline__ void build_mask(unsigned char* maskb, const unsigned char* __restrict__ mask_plane,
+                                           const int row0, const int rows_valid, const int rows, const int tid) {
+    // the tile's rows are contiguous in the mask plane: a straight 32 B/row copy, 4 bytes per thread
+    const unsigned* src = reinterpret_cast<const unsigned*>(mask_plane + (size_t)row0 * 32);
+    unsigned* dst = reinterpret_cast<unsigned*>(maskb);
+    for (int idx = tid; idx < rows * 8; idx += NTHREADS) dst[idx] = (idx >> 3) < rows_valid ? src[idx] : 0u;
 }
 
 template <int NS, int NT, bool MASK, bool ALPHA>
@@ -582,6 +584,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_bf16_kernel(BwdArgs a) {
     const int rot = (int)(blockIdx.x >> 3);   // consecutive blocks of one XCD (b, b+8, ...) get consecutive rotations
 #define SPLANE(p) (a.saved + (size_t)(p) * W * N)
 #define DPLANE(p) (a.dz + (size_t)(p) * W * N)
+#define MASKP(p) (reinterpret_cast<const unsigned char*>(a.saved + (size_t)SV_FLOATS * N) + (size_t)(p) * (W / 8) * N)
 
     for (int row = tid; row < TM; row += NTHREADS) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -592,17 +595,12 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_bf16_kernel(BwdArgs a) {
     // dz_view = (g_rgb W_rgb) * relu'(hv): 8 features per thread-iteration, coalesced planes
     {
         const float* wr = hd + H_WR;
-        const float* hv_plane = a.saved + (size_t)SV_HV_OFF * N;
+        const unsigned char* hv_mask = MASKP(8);
         float* dzv_plane = a.dz + (size_t)DZ_V_OFF * N;
         for (int idx = tid; idx < TM * (HV / 8); idx += NTHREADS) {
             const int s = idx >> 4, c = idx & 15;
             const bool ok = s < rows_valid;
-            float h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok) {
-                const float4* src = reinterpret_cast<const float4*>(hv_plane + (size_t)(row0 + s) * HV + c * 8);
-                const float4 x = src[0], y = src[1];
-                h[0] = x.x; h[1] = x.y; h[2] = x.z; h[3] = x.w; h[4] = y.x; h[5] = y.y; h[6] = y.z; h[7] = y.w;
-            }
+            const unsigned hm = ok ? hv_mask[(size_t)(row0 + s) * (HV / 8) + c] : 0u;
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -610,7 +608,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_bf16_kernel(BwdArgs a) {
                 float t = gr[s * 4 + 0] * wr[i];
                 t = fmaf(gr[s * 4 + 1], wr[HV + i], t);
                 t = fmaf(gr[s * 4 + 2], wr[2 * HV + i], t);
-                v[e] = h[e] > 0.0f ? t : 0.0f;
+                v[e] = ((hm >> e) & 1u) ? t : 0.0f;
             }
             float lo4[4] = {v[0], v[1], v[2], v[3]}, hi4[4] = {v[4], v[5], v[6], v[7]};
             split4<NS>(lo4, g + (size_t)s * BLDA + c * 8, G_PLANE);
@@ -637,7 +635,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_bf16_kernel(BwdArgs a) {
     store_dz<NS, NT, false, false>(acc, g, G_PLANE, gr, nullptr, nullptr, wave * 32, lane);
     __syncthreads();
     tile_to_plane<NS, W>(g, BLDA, G_PLANE, DPLANE(DZ_FEAT), row0, rows_valid, TM, tid);
-    build_mask(maskb, SPLANE(7), row0, rows_valid, TM, tid);
+    build_mask(maskb, MASKP(7), row0, rows_valid, TM, tid);
     // d h7 = dz_feature . W_f + g_sigma w_alpha, masked by h7
     zero_acc(acc);
     mma_bf16<NS, NT, 16>(acc, wq, wp, g_lane, BLDA, G_PLANE, rot, lane);
@@ -649,7 +647,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_bf16_kernel(BwdArgs a) {
     tile_to_plane<NS, W>(g, BLDA, G_PLANE, DPLANE(7), row0, rows_valid, TM, tid);
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {
-        build_mask(maskb, SPLANE(l - 1), row0, rows_valid, TM, tid);
+        build_mask(maskb, MASKP(l - 1), row0, rows_valid, TM, tid);
         zero_acc(acc);
         mma_bf16<NS, NT, 16>(acc, wq, wp, g_lane, BLDA, G_PLANE, rot, lane);
         if (l > 1) {
@@ -663,6 +661,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_bwd_bf16_kernel(BwdArgs a) {
     }
 #undef SPLANE
 #undef DPLANE
+#undef MASKP
 }
 
 template <int NS>

@@ -571,22 +571,23 @@ __device__ __forceinline__ void split_frag(const float (&v)[8], wbf16x8& hi, wbf
     }
 }
 
-template <int NS>
+template <int NS, int NI>
 __global__ __launch_bounds__(512) void wgrad_bf16_kernel(WgradArgs a) {
-    constexpr int NO = 2, NI = 4, WI = 2;
+    constexpr int NO = 2, WI = 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const WJob job = a.jobs[a.tile_job[blockIdx.x]];
     const int wo = wave / WI, wi = wave % WI;
     const int o_base = a.tile_o0[blockIdx.x] + wo * NO * 32;
     const int i_base = wi * NI * 32;
-    const bool o_live = o_base < job.O;          // view layer: O = 128, upper o-waves idle
+    const bool o_live = o_base < job.O && i_base < job.I;   // O = 128 / I = 32 jobs: surplus waves idle
     const int split = blockIdx.y;
     const int m_begin = split * a.rows_per_split;
     const int m_end = min(a.n_rows, m_begin + a.rows_per_split);
     const int g8 = 8 * (lane >> 5), ll = lane & 31;
     const float* Ap = job.A + (o_live ? o_base : 0) + ll;
-    const float* Bp = job.B + i_base + ll;
+    const float* Bp = job.B + (o_live ? i_base : 0) + ll;
+    if (!o_live) return;
     f32x16 acc[NO][NI];
     zero_acc(acc);
     float bsum[NO];
@@ -616,7 +617,6 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) split_frag<NS>(bv[i], bh[i], bl[i]);
         if (m + 16 < m_end) load(m + 16);
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int o = 0; o < NO; ++o)
 #pragma unroll
@@ -627,9 +627,7 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(WgradArgs a) {
                     acc[o][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[o], bl[i], acc[o][i], 0, 0, 0);
                 }
             }
-        __builtin_amdgcn_sched_barrier(0);
     }
-    if (!o_live) return;
     float* part = a.part + (size_t)split * PART_PER_SPLIT;
     float* cpart = part + job.part_off;
 #pragma unroll
@@ -879,28 +877,42 @@ int f32_wgrad(const float* g_raw, int n_rows, const float* sv, float* dz, float*
         a.tile_job[nt] = 8; a.tile_o0[nt++] = 0;
         a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
         if (ns == 0) hipLaunchKernelGGL((wgrad_f32_kernel<2, 2, 2, 4, 4>), dim3(nt, splits), dim3(256), 0, st, a);
-        else if (ns == 1) hipLaunchKernelGGL(wgrad_bf16_kernel<1>, dim3(nt, splits), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL(wgrad_bf16_kernel<2>, dim3(nt, splits), dim3(512), 0, st, a);
+        else if (ns == 1) hipLaunchKernelGGL((wgrad_bf16_kernel<1, 4>), dim3(nt, splits), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((wgrad_bf16_kernel<2, 4>), dim3(nt, splits), dim3(512), 0, st, a);
         PLNERF_CHECK_LAUNCH();
     }
-    {
-        // encoding parts: 256(o) x 64(i)
+    if (ns == 0) {
+        {
+            // encoding parts: 256(o) x 64(i)
+            WgradArgs a{};
+            a.jobs[0] = WJob{dplane(0), pe_plane, W, PE_K, W, PE_K, PART_PE0, PART_BIAS + 0 * W};
+            a.jobs[1] = WJob{dplane(5), pe_plane, W, PE_K, W, PE_K, PART_PE5, -1};
+            a.tile_job[0] = 0; a.tile_o0[0] = 0;
+            a.tile_job[1] = 1; a.tile_o0[1] = 0;
+            a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
+            hipLaunchKernelGGL((wgrad_f32_kernel<4, 1, 2, 2, 4>), dim3(2, splits), dim3(256), 0, st, a);
+            PLNERF_CHECK_LAUNCH();
+        }
+        {
+            // view layer, direction-encoding part: 128(o) x 32(i)
+            WgradArgs a{};
+            a.jobs[0] = WJob{dzv_plane, dpe_plane, HV, DPE_K, HV, DPE_K, PART_VDIR, -1};
+            a.tile_job[0] = 0; a.tile_o0[0] = 0;
+            a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
+            hipLaunchKernelGGL((wgrad_f32_kernel<4, 1, 1, 1, 8>), dim3(1, splits), dim3(256), 0, st, a);
+            PLNERF_CHECK_LAUNCH();
+        }
+    } else {
+        // the three thin jobs (encoding columns of L0 / L5, direction columns of the view layer) on the
+        // bf16-MFMA kernel with 32-wide i slabs
         WgradArgs a{};
         a.jobs[0] = WJob{dplane(0), pe_plane, W, PE_K, W, PE_K, PART_PE0, PART_BIAS + 0 * W};
         a.jobs[1] = WJob{dplane(5), pe_plane, W, PE_K, W, PE_K, PART_PE5, -1};
-        a.tile_job[0] = 0; a.tile_o0[0] = 0;
-        a.tile_job[1] = 1; a.tile_o0[1] = 0;
+        a.jobs[2] = WJob{dzv_plane, dpe_plane, HV, DPE_K, HV, DPE_K, PART_VDIR, -1};
+        for (int t = 0; t < 3; ++t) { a.tile_job[t] = t; a.tile_o0[t] = 0; }
         a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
-        hipLaunchKernelGGL((wgrad_f32_kernel<4, 1, 2, 2, 4>), dim3(2, splits), dim3(256), 0, st, a);
-        PLNERF_CHECK_LAUNCH();
-    }
-    {
-        // view layer, direction-encoding part: 128(o) x 32(i)
-        WgradArgs a{};
-        a.jobs[0] = WJob{dzv_plane, dpe_plane, HV, DPE_K, HV, DPE_K, PART_VDIR, -1};
-        a.tile_job[0] = 0; a.tile_o0[0] = 0;
-        a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
-        hipLaunchKernelGGL((wgrad_f32_kernel<4, 1, 1, 1, 8>), dim3(1, splits), dim3(256), 0, st, a);
+        if (ns == 1) hipLaunchKernelGGL((wgrad_bf16_kernel<1, 1>), dim3(3, splits), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((wgrad_bf16_kernel<2, 1>), dim3(3, splits), dim3(512), 0, st, a);
         PLNERF_CHECK_LAUNCH();
     }
     const int n_head = head_wgs_for(n_rows);
