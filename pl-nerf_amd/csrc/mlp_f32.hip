@@ -649,6 +649,166 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(WgradArgs a) {
     }
 }
 
+// LDS-staged version of the bf16-MFMA weight gradient (the one the launcher uses).  The register
+// version above spends ~14 VALU instructions per MFMA re-splitting every operand value in each of
+// the 2-4 waves that need it (measured: VALU-bound, 24 % MFMA busy).  Here a workgroup loads each
+// 16-row slab of dz / activations ONCE with coalesced 16-byte loads, splits each value ONCE into
+// bf16 hi (+ lo), and stores the slab row-major in LDS; waves then build their k-contiguous MFMA
+// fragments with ds_read_b64_tr_b16, the gfx950 transposing LDS read (lane = feature column,
+// 4 consecutive rows per read; row stride 576 B puts the 4 rows of a read on disjoint banks).
+// Stage k+1 is fetched into registers before stage k's MFMAs and converted/written after them;
+// one barrier per stage.
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+constexpr int TR_ROWS = 16;            // rows per stage = one MFMA k-step
+constexpr int TR_RS = 288;             // LDS row stride in bf16 elements (256 + 32): 576 B
+constexpr int TR_PLANE = TR_ROWS * TR_RS;
+
+__device__ __forceinline__ wbf16x8 tr_frag(const __bf16* plane, int lane, int col0) {
+    // 8 consecutive rows (k) of column col0 + (lane & 31), rows 8 * (lane >> 5) .. +7
+    const int lam = lane & 15, gam = lane >> 4;
+    const int row = 8 * (gam >> 1) + (lam >> 2), col = col0 + 16 * (gam & 1) + 4 * (lam & 3);
+    const __bf16* p = plane + row * TR_RS + col;
+    typedef __attribute__((address_space(3))) v4s16* lds_v4;
+    const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)p);
+    const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p + 4 * TR_RS));
+    union { v4s16 h[2]; wbf16x8 v; } u;
+    u.h[0] = lo;
+    u.h[1] = hi;
+    return u.v;
+}
+
+template <int NS, int NI>
+__global__ __launch_bounds__(512) void wgrad_tr_kernel(WgradArgs a) {
+    constexpr int NO = 2, WI = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // [buffer 2][operand A,B][plane NS][TR_ROWS][TR_RS]
+    __bf16* lds = reinterpret_cast<__bf16*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const WJob job = a.jobs[a.tile_job[blockIdx.x]];
+    const int wo = wave / WI, wi = wave % WI;
+    const int o_base = a.tile_o0[blockIdx.x] + wo * NO * 32;
+    const int i_base = wi * NI * 32;
+    const bool live = o_base < job.O && i_base < job.I;
+    const int split = blockIdx.y;
+    const int m_begin = split * a.rows_per_split;
+    const int m_end = min(a.n_rows, m_begin + a.rows_per_split);
+    const int a_f4 = job.O >> 2, b_f4 = job.I >> 2;      // float4 per row of each operand
+    // this thread's (row, float4) slots in the 16-row slab: up to 2 for A and 2 for B
+    int a_row[2], a_col[2], b_row[2], b_col[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = tid + 512 * j;
+        a_row[j] = q / a_f4; a_col[j] = (q - a_row[j] * a_f4) * 4;
+        b_row[j] = q / b_f4; b_col[j] = (q - b_row[j] * b_f4) * 4;
+    }
+    float4 ra[2], rb[2];
+    float4 bs[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    auto fetch = [&](int m) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_row[j] < TR_ROWS && m + a_row[j] < m_end)
+                ra[j] = *reinterpret_cast<const float4*>(job.A + (size_t)(m + a_row[j]) * job.lda + a_col[j]);
+            if (b_row[j] < TR_ROWS && m + b_row[j] < m_end)
+                rb[j] = *reinterpret_cast<const float4*>(job.B + (size_t)(m + b_row[j]) * job.ldb + b_col[j]);
+        }
+    };
+    auto put = [&](__bf16* dst, const float4& v) {   // dst = hi plane slot; lo plane is NS-1 planes later
+        const float x[4] = {v.x, v.y, v.z, v.w};
+        typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+        b4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = (__bf16)x[e];
+            l[e] = (__bf16)(x[e] - (float)h[e]);
+        }
+        *reinterpret_cast<b4*>(dst) = h;
+        if (NS == 2) *reinterpret_cast<b4*>(dst + TR_PLANE) = l;
+    };
+    auto stash = [&](int buf) {
+        __bf16* A0 = lds + (size_t)buf * 2 * NS * TR_PLANE;
+        __bf16* B0 = A0 + NS * TR_PLANE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (a_row[j] < TR_ROWS) {
+                put(A0 + a_row[j] * TR_RS + a_col[j], ra[j]);
+                bs[j].x += ra[j].x; bs[j].y += ra[j].y; bs[j].z += ra[j].z; bs[j].w += ra[j].w;
+            }
+            if (b_row[j] < TR_ROWS) put(B0 + b_row[j] * TR_RS + b_col[j], rb[j]);
+        }
+    };
+    f32x16 acc[NO][NI];
+    zero_acc(acc);
+    if (m_begin < m_end) {
+        fetch(m_begin);
+        stash(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int m = m_begin; m < m_end; m += TR_ROWS, buf ^= 1) {
+        const bool more = m + TR_ROWS < m_end;
+        if (more) fetch(m + TR_ROWS);
+        if (live) {
+            const __bf16* A0 = lds + (size_t)buf * 2 * NS * TR_PLANE;
+            const __bf16* B0 = A0 + NS * TR_PLANE;
+            wbf16x8 ah[NO], al[NO], bh[NI], bl[NI];
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                ah[o] = tr_frag(A0, lane, o_base + 32 * o);
+                if (NS == 2) al[o] = tr_frag(A0 + TR_PLANE, lane, o_base + 32 * o);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                bh[i] = tr_frag(B0, lane, i_base + 32 * i);
+                if (NS == 2) bl[i] = tr_frag(B0 + TR_PLANE, lane, i_base + 32 * i);
+            }
+#pragma unroll
+            for (int o = 0; o < NO; ++o)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    acc[o][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[o], bh[i], acc[o][i], 0, 0, 0);
+                    if (NS == 2) {
+                        acc[o][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[o], bh[i], acc[o][i], 0, 0, 0);
+                        acc[o][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[o], bl[i], acc[o][i], 0, 0, 0);
+                    }
+                }
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+    }
+    float* part = a.part + (size_t)split * PART_PER_SPLIT;
+    if (live) {
+        float* cpart = part + job.part_off;
+        const int ll = lane & 31;
+#pragma unroll
+        for (int o = 0; o < NO; ++o)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int orow = o_base + o * 32 + frag_row(r, lane);
+                    const int icol = i_base + i * 32 + ll;
+                    cpart[(size_t)orow * job.I + icol] = acc[o][i][r];
+                }
+    }
+    if (job.bias_off >= 0) {
+        // bias partial = column sums of the dz slab: every thread summed its (row-slot, 4 features)
+        float* red = reinterpret_cast<float*>(smem_raw);      // [slot 0..(512*2/a_f4)-1][O] -> reuse LDS
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (a_row[j] < TR_ROWS) *reinterpret_cast<float4*>(red + a_row[j] * job.O + a_col[j]) = bs[j];
+        __syncthreads();
+        for (int f = tid; f < job.O; f += 512) {
+            float sum = 0.0f;
+            for (int r = 0; r < TR_ROWS; ++r) sum += red[r * job.O + f];
+            part[job.bias_off + f] = sum;
+        }
+    }
+}
+
 // sigma / rgb heads: dW_alpha = sum_m g_sigma h7, dW_rgb[c] = sum_m g_c hv, and their biases
 struct HeadArgs {
     const float* g_raw;
@@ -877,8 +1037,18 @@ int f32_wgrad(const float* g_raw, int n_rows, const float* sv, float* dz, float*
         a.tile_job[nt] = 8; a.tile_o0[nt++] = 0;
         a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
         if (ns == 0) hipLaunchKernelGGL((wgrad_f32_kernel<2, 2, 2, 4, 4>), dim3(nt, splits), dim3(256), 0, st, a);
-        else if (ns == 1) hipLaunchKernelGGL((wgrad_bf16_kernel<1, 4>), dim3(nt, splits), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((wgrad_bf16_kernel<2, 4>), dim3(nt, splits), dim3(512), 0, st, a);
+        else {
+            const size_t lds = (size_t)2 * 2 * ns * TR_PLANE * sizeof(__bf16);   // 2 buffers x {A,B} x planes
+            if (ns == 1) {
+                (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel<1, 4>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL((wgrad_tr_kernel<1, 4>), dim3(nt, splits), dim3(512), lds, st, a);
+            } else {
+                (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel<2, 4>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL((wgrad_tr_kernel<2, 4>), dim3(nt, splits), dim3(512), lds, st, a);
+            }
+        }
         PLNERF_CHECK_LAUNCH();
     }
     if (ns == 0) {
@@ -911,8 +1081,16 @@ int f32_wgrad(const float* g_raw, int n_rows, const float* sv, float* dz, float*
         a.jobs[2] = WJob{dzv_plane, dpe_plane, HV, DPE_K, HV, DPE_K, PART_VDIR, -1};
         for (int t = 0; t < 3; ++t) { a.tile_job[t] = t; a.tile_o0[t] = 0; }
         a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
-        if (ns == 1) hipLaunchKernelGGL((wgrad_bf16_kernel<1, 1>), dim3(3, splits), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((wgrad_bf16_kernel<2, 1>), dim3(3, splits), dim3(512), 0, st, a);
+        const size_t lds = (size_t)2 * 2 * ns * TR_PLANE * sizeof(__bf16);
+        if (ns == 1) {
+            (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds);
+            hipLaunchKernelGGL((wgrad_tr_kernel<1, 1>), dim3(3, splits), dim3(512), lds, st, a);
+        } else {
+            (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds);
+            hipLaunchKernelGGL((wgrad_tr_kernel<2, 1>), dim3(3, splits), dim3(512), lds, st, a);
+        }
         PLNERF_CHECK_LAUNCH();
     }
     const int n_head = head_wgs_for(n_rows);
