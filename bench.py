@@ -154,6 +154,13 @@ def main():
         fwd_ms = timer.mean_ms(f"mlp_fwd[{rows_fine}]")
         bwd_ms = timer.mean_ms(f"mlp_bwd[{rows_fine}]")
         peak = PEAK_TFLOPS[a.precision]
+        traffic = None
+        try:   # measured offline with rocprofv3 --pmc (cannot be collected from inside this process)
+            t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json"))).get(a.precision)
+            if t and t["rows_per_launch"] == rows_fine:
+                traffic = t["bytes"]
+        except Exception:
+            traffic = None
         ach = rows_fine * FWD_FLOP_PER_ROW / (fwd_ms * 1e-3) / 1e12 if fwd_ms else None
         out = {
             "metric": "training rays/sec (coarse+fine, 64+128 samples)",
@@ -168,7 +175,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": ("mlp_fwd_f32_kernel" if a.precision == "fp32" else "mlp_fwd_bf16_kernel") + " (fine network, fused PE+12-layer MLP forward)",
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": (ach / peak) if ach else None,
-                "traffic": None, "launch_ms": fwd_ms, "rows_per_launch": rows_fine,
+                "traffic": traffic, "launch_ms": fwd_ms, "rows_per_launch": rows_fine,
                 "flop_per_row": FWD_FLOP_PER_ROW,
                 # MFMA work actually issued: bf16x3 spends 3 MFMAs per algorithmic product
                 "mfma_issue_frac": ((ach * {"fp32": 1, "bf16x3": 3, "bf16": 1}[a.precision] / peak) if ach else None),

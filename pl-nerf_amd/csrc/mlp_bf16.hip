@@ -567,8 +567,10 @@ __device__ __forceinline__ void store_dz(f32x16 (&acc)[NT], __bf16* g, const int
     }
 }
 
+// bf16x3: 128 VGPRs and 69 KB of LDS let two workgroups share a CU, so one's HBM phase (dz plane
+// write-back, mask fetch) overlaps the other's MFMA phase; bf16's 128-row tile needs the full file.
 template <int NS>
-__global__ __launch_bounds__(NTHREADS) void mlp_bwd_bf16_kernel(BwdArgs a) {
+__global__ __launch_bounds__(NTHREADS, NS == 2 ? 4 : 2) void mlp_bwd_bf16_kernel(BwdArgs a) {
     constexpr int TM = tile_rows(NS), NT = TM / 32;
     constexpr int G_PLANE = TM * BLDA;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

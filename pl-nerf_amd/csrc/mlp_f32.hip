@@ -828,10 +828,26 @@ __global__ __launch_bounds__(256) void wgrad_head_kernel(HeadArgs a) {
     float wa = 0.0f;                       // column tid of dW_alpha
     float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f; // column (tid & 127) of dW_rgb, rows of parity (tid >> 7)
     const int half = tid >> 7, ci = tid & 127;
-    for (int m = m_begin; m < m_end; ++m) {
+    // rows two at a time (this thread takes the row of its parity for the rgb part), unrolled so that
+    // ~16 independent loads are in flight per thread -- the loop is latency-, not bandwidth-bound otherwise
+    const int m_pairs = (m_end - m_begin) >> 1;
+#pragma unroll 8
+    for (int p = 0; p < m_pairs; ++p) {
+        const int m = m_begin + 2 * p;
+        const float4 g0 = g4[m], g1 = g4[m + 1];
+        wa = fmaf(g0.w, a.h7[(size_t)m * W + tid], wa);
+        wa = fmaf(g1.w, a.h7[(size_t)(m + 1) * W + tid], wa);
+        const float4 g = half ? g1 : g0;
+        const float h = a.hv[(size_t)(m + half) * HV + ci];
+        r0 = fmaf(g.x, h, r0);
+        r1 = fmaf(g.y, h, r1);
+        r2 = fmaf(g.z, h, r2);
+    }
+    if ((m_end - m_begin) & 1) {
+        const int m = m_end - 1;
         const float4 g = g4[m];
         wa = fmaf(g.w, a.h7[(size_t)m * W + tid], wa);
-        if (((m - m_begin) & 1) == half) {
+        if (half == 0) {
             const float h = a.hv[(size_t)m * HV + ci];
             r0 = fmaf(g.x, h, r0);
             r1 = fmaf(g.y, h, r1);
@@ -883,6 +899,7 @@ __global__ void wgrad_reduce_kernel(ReduceArgs a) {
         return;
     }
     float s = 0.0f;
+#pragma unroll 8
     for (int sp = 0; sp < a.splits; ++sp) s += a.part[(size_t)sp * PART_PER_SPLIT + idx];
     if (idx < PART_VMAIN) {
         const int job = idx >> 16, r = idx & 65535, o = r >> 8, i = r & 255;
