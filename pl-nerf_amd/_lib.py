@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libplnerf_hip.so")
+# PLNERF_HIP_LIB overrides the library path (kernel experiments: ablation builds under /tmp)
+LIB_PATH = os.environ.get("PLNERF_HIP_LIB") or os.path.join(_HERE, "libplnerf_hip.so")
 
 MODE = {"constant": 0, "linear": 1}
 COLOR = {"midpoint": 0, "left": 1}

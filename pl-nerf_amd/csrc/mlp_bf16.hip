@@ -20,6 +20,8 @@
 // bf16x3; 94 KB of LDS either way) and walks all 12 layers without leaving the CU.  For
 // training, each layer's activation tile is additionally copied LDS -> HBM as coalesced fp32
 // rows (the same plane layout as the fp32 mode), so the fp32-MFMA weight-gradient stage is shared.
+#include <type_traits>
+
 #include "common.h"
 #include "mlp_internal.h"
 #include "mlp_layout.h"
@@ -41,6 +43,10 @@ constexpr int BLDA = 264;   // bf16 elements per activation row (256 + 8): 528 B
 constexpr int BLDP = 72;    // xyz-encoding row (64 + 8)
 constexpr int BLDD = 40;    // direction-encoding row (32 + 8)
 constexpr int NTHREADS = 512;
+#ifndef PLNERF_ABLATE
+#define PLNERF_ABLATE 0   // timing experiments (results wrong): 1 cheap sincos, 2 no heads, 4 no epilogue,
+                          // 16 no LDS operand reads in the K loop, 32 no weight loads in the K loop
+#endif
 
 __host__ __device__ constexpr int tile_rows(int ns) { return ns == 1 ? 128 : 64; }
 
@@ -119,7 +125,68 @@ __device__ __forceinline__ const bf16x8* wblock(const void* packed, bool fwd, in
 // and sched_barrier pins "issue next loads, then this step's MFMAs" so the loads' latency
 // hides behind NT*(1|3) MFMAs per step; hipcc inserts the counted vmcnt/lgkmcnt waits.
 // ------------------------------------------------------------------------------------
-constexpr int WPF = 4;   // weight prefetch distance (k-steps)
+// Deferred write-back of the PREVIOUS layer's tile, interleaved into a 16-step K loop: the tile
+// (bf16 planes in LDS, also being read as this GEMM's B operand) is copied to its fp32 plane in HBM
+// (+ ReLU bit mask) a chunk at a time -- LDS reads in step 4c+1, convert + global stores in step
+// 4c+2 -- so the HBM write stream overlaps the MFMAs instead of following them.  Chunk = 8 features
+// of one sample; a 512-thread workgroup moves TM*32 chunks, i.e. TM/16 per thread = CPS per slot.
+struct NoSide {
+    static constexpr bool ACTIVE = false;
+    __device__ __forceinline__ void load(int) {}
+    __device__ __forceinline__ void store(int) {}
+};
+
+template <int NS, int TMROWS>
+struct PlaneCopy {
+    static constexpr bool ACTIVE = true;
+    static constexpr int CPS = TMROWS / 64;          // chunks per thread per slot (4 slots per K loop)
+    const __bf16* tile;                               // plane 0 of the LDS tile
+    int ld, plane_stride;
+    float* plane;                                     // fp32 [rows][256] destination (nullptr = nothing pending)
+    unsigned char* mask;                              // [rows][32] or nullptr
+    int row0, rows_valid, tid;
+    bf16x8 h[CPS], l[CPS];
+    __device__ __forceinline__ void load(int slot) {
+        if (!plane) return;
+#pragma unroll
+        for (int j = 0; j < CPS; ++j) {
+            const int idx = tid + NTHREADS * (slot * CPS + j);
+            const int s = idx >> 5, c = idx & 31;
+            const __bf16* src = tile + (size_t)s * ld + c * 8;
+            h[j] = *reinterpret_cast<const bf16x8*>(src);
+            if (NS == 2) l[j] = *reinterpret_cast<const bf16x8*>(src + plane_stride);
+        }
+    }
+    __device__ __forceinline__ void store(int slot) {
+        if (!plane) return;
+#pragma unroll
+        for (int j = 0; j < CPS; ++j) {
+            const int idx = tid + NTHREADS * (slot * CPS + j);
+            const int s = idx >> 5, c = idx & 31;
+            if (s >= rows_valid) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] = (float)h[j][e];
+                if (NS == 2) v[e] += (float)l[j][e];
+            }
+            float4* dst = reinterpret_cast<float4*>(plane + (size_t)(row0 + s) * W + c * 8);
+            dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+            dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+            if (mask) {
+                unsigned m = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m |= (v[e] > 0.0f ? 1u : 0u) << e;
+                mask[(size_t)(row0 + s) * 32 + c] = (unsigned char)m;
+            }
+        }
+    }
+};
+
+#ifndef PLNERF_WPF
+#define PLNERF_WPF 4
+#endif
+constexpr int WPF = PLNERF_WPF;   // weight prefetch distance (k-steps)
 
 template <int NS>
 struct WQueue {
@@ -143,10 +210,10 @@ __device__ __forceinline__ void wq_prime(WQueue<NS>& w, const bf16x8* __restrict
     }
 }
 
-template <int NS, int NT, int KC>
+template <int NS, int NT, int KC, class Side>
 __device__ __forceinline__ void mma_bf16(f32x16 (&acc)[NT], WQueue<NS>& w, const bf16x8* __restrict__ a,
                                          const __bf16* b_lane, const int ld, const int plane_stride,
-                                         const int rot, const int lane) {
+                                         const int rot, const int lane, Side& side) {
     static_assert((KC & (KC - 1)) == 0, "KC must be a power of two");
     constexpr int PF = KC < WPF ? KC : WPF;
     bf16x8 bq[2][NT][NS];
@@ -164,12 +231,12 @@ __device__ __forceinline__ void mma_bf16(f32x16 (&acc)[NT], WQueue<NS>& w, const
         // loop-invariant address registers: recompute them per step from an opaque copy of rot
         int rot_i = rot;
         asm volatile("" : "+s"(rot_i));
-        if (i + PF < KC) {
+        if (i + PF < KC && !(PLNERF_ABLATE & 32)) {
             const int ks = (i + PF + rot_i) & (KC - 1);
 #pragma unroll
             for (int s = 0; s < NS; ++s) w.q[(i + PF) % (PF + 1)][s] = a[(ks * NS + s) * 64 + lane];
         }
-        if (i + 1 < KC) {
+        if (i + 1 < KC && !(PLNERF_ABLATE & 16)) {
             const __bf16* b1 = b_lane + ((i + 1 + rot_i) & (KC - 1)) * 16;
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -177,6 +244,10 @@ __device__ __forceinline__ void mma_bf16(f32x16 (&acc)[NT], WQueue<NS>& w, const
                 for (int s = 0; s < NS; ++s)
                     bq[(i + 1) & 1][t][s] =
                         *reinterpret_cast<const bf16x8*>(b1 + s * plane_stride + (size_t)t * 32 * ld);
+        }
+        if (Side::ACTIVE && KC == 16) {
+            if ((i & 3) == 2) side.store(i >> 2);     // data requested one step ago has landed
+            if ((i & 3) == 1) side.load(i >> 2);
         }
         __builtin_amdgcn_sched_barrier(0);
         const bf16x8 ah = w.q[i % (PF + 1)][0];
@@ -284,6 +355,15 @@ struct FwdArgs {
 template <int NS, int NT, bool RELU>
 __device__ __forceinline__ void store_act(f32x16 (&acc)[NT], __bf16* act, const int plane_stride, const int f_base,
                                           const int s_base, const int lane) {
+    if (PLNERF_ABLATE & 4) {   // keep the accumulators alive, skip the conversion + LDS stores
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" ::"v"(acc[t]));
+#endif
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int s = s_base + t * 32 + (lane & 31);
@@ -341,6 +421,9 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_bf16_kernel(FwdArgs a) {
             dst[0] = h;
             if (NS == 2) dst[ps] = (__bf16)(v - (float)h);
         };
+#if PLNERF_ABLATE & 1
+#define sincosf(x, s, c) (*(s) = __sinf(x), *(c) = __cosf(x))
+#endif
         for (int e = tid; e < TM * 4; e += NTHREADS) {
             const int row = e % TM, q = e / TM;
             const int grow = min(row0 + row, a.n_rows - 1);
@@ -397,20 +480,30 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_bf16_kernel(FwdArgs a) {
     // Weight fragments of the NEXT GEMM are requested before the barrier + epilogue of the current
     // one (they do not depend on activations), so each K loop starts with its first blocks in flight.
     const bf16x8* wp;
+    // training: layer l's tile is written back to HBM during layer l+1's K loop (PlaneCopy)
+    NoSide noside;
+    typename std::conditional<SAVE, PlaneCopy<NS, TM>, NoSide>::type side;
+    auto pend = [&](float* plane, unsigned char* mask) {
+        if constexpr (SAVE) { side.plane = plane; side.mask = mask; }
+    };
+    if constexpr (SAVE) {
+        side.tile = act; side.ld = BLDA; side.plane_stride = ACT_PLANE; side.plane = nullptr; side.mask = nullptr;
+        side.row0 = row0; side.rows_valid = rows_valid; side.tid = tid;
+    }
     // L0
     init_acc(acc, hd + H_BIAS + 0 * W, wave * 32, lane);
-    mma_bf16<NS, NT, 4>(acc, wq, wp0, pe_lane, BLDP, PE_PLANE, rot, lane);
+    mma_bf16<NS, NT, 4>(acc, wq, wp0, pe_lane, BLDP, PE_PLANE, rot, lane, noside);
     wp = wblock<NS>(a.packed, true, fwd_off(G_L1), 16, wave, 0);
     wq_prime<NS, 16>(wq, wp, rot, lane);
     __syncthreads();
     store_act<NS, NT, true>(acc, act, ACT_PLANE, wave * 32, 0, lane);
     __syncthreads();
-    if (SAVE) tile_to_plane<NS, W>(act, BLDA, ACT_PLANE, PLANE(0), row0, rows_valid, TM, tid, MASKP(0));
+    if (SAVE) pend(PLANE(0), MASKP(0));
     // L1..L4
 #pragma unroll 1
     for (int l = 1; l <= 4; ++l) {
         init_acc(acc, hd + H_BIAS + l * W, wave * 32, lane);
-        mma_bf16<NS, NT, 16>(acc, wq, wp, act_lane, BLDA, ACT_PLANE, rot, lane);
+        mma_bf16<NS, NT, 16>(acc, wq, wp, act_lane, BLDA, ACT_PLANE, rot, lane, side);
         if (l < 4) {
             wp = wblock<NS>(a.packed, true, fwd_off(G_L1) + l * W * W, 16, wave, 0);
             wq_prime<NS, 16>(wq, wp, rot, lane);
@@ -421,31 +514,31 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_bf16_kernel(FwdArgs a) {
         __syncthreads();
         store_act<NS, NT, true>(acc, act, ACT_PLANE, wave * 32, 0, lane);
         __syncthreads();
-        if (SAVE) tile_to_plane<NS, W>(act, BLDA, ACT_PLANE, PLANE(l), row0, rows_valid, TM, tid, MASKP(l));
+        if (SAVE) pend(PLANE(l), MASKP(l));
     }
     // L5 = [encoding | h4]
     init_acc(acc, hd + H_BIAS + 5 * W, wave * 32, lane);
-    mma_bf16<NS, NT, 4>(acc, wq, wp, pe_lane, BLDP, PE_PLANE, rot, lane);
+    mma_bf16<NS, NT, 4>(acc, wq, wp, pe_lane, BLDP, PE_PLANE, rot, lane, noside);
     wp = WB(G_L5, 20, 4);
     wq_prime<NS, 16>(wq, wp, rot, lane);
-    mma_bf16<NS, NT, 16>(acc, wq, wp, act_lane, BLDA, ACT_PLANE, rot, lane);
+    mma_bf16<NS, NT, 16>(acc, wq, wp, act_lane, BLDA, ACT_PLANE, rot, lane, side);
     wp = wblock<NS>(a.packed, true, fwd_off(G_L6), 16, wave, 0);
     wq_prime<NS, 16>(wq, wp, rot, lane);
     __syncthreads();
     store_act<NS, NT, true>(acc, act, ACT_PLANE, wave * 32, 0, lane);
     __syncthreads();
-    if (SAVE) tile_to_plane<NS, W>(act, BLDA, ACT_PLANE, PLANE(5), row0, rows_valid, TM, tid, MASKP(5));
+    if (SAVE) pend(PLANE(5), MASKP(5));
     // L6, L7
 #pragma unroll 1
     for (int l = 6; l <= 7; ++l) {
         init_acc(acc, hd + H_BIAS + l * W, wave * 32, lane);
-        mma_bf16<NS, NT, 16>(acc, wq, wp, act_lane, BLDA, ACT_PLANE, rot, lane);
+        mma_bf16<NS, NT, 16>(acc, wq, wp, act_lane, BLDA, ACT_PLANE, rot, lane, side);
         wp = (l == 6) ? wblock<NS>(a.packed, true, fwd_off(G_L7), 16, wave, 0) : WB(G_FEAT, 16, 0);
         wq_prime<NS, 16>(wq, wp, rot, lane);
         __syncthreads();
         store_act<NS, NT, true>(acc, act, ACT_PLANE, wave * 32, 0, lane);
         __syncthreads();
-        if (SAVE) tile_to_plane<NS, W>(act, BLDA, ACT_PLANE, PLANE(l), row0, rows_valid, TM, tid, MASKP(l));
+        if (SAVE) pend(PLANE(l), MASKP(l));
     }
     // sigma head: TPR threads per sample, 8-feature chunks interleaved across them
     const int hrow = tid / TPR, hq = tid % TPR;
@@ -453,7 +546,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_bf16_kernel(FwdArgs a) {
     {
         const float* wa = hd + H_WA;
 #pragma unroll 1
-        for (int c = hq; c < W / 8; c += TPR) {
+        for (int c = hq; c < ((PLNERF_ABLATE & 2) ? 0 : W / 8); c += TPR) {
             float v[8];
             load8<NS>(act + (size_t)hrow * BLDA + c * 8, ACT_PLANE, v);
 #pragma unroll
@@ -467,21 +560,21 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_bf16_kernel(FwdArgs a) {
     constexpr int NTV = NT / 2;
     const int vft = wave & 3, vs0 = (wave >> 2) * (TM / 2);
     init_acc(acc, hd + H_BF, wave * 32, lane);
-    mma_bf16<NS, NT, 16>(acc, wq, wp, act_lane, BLDA, ACT_PLANE, rot, lane);
+    mma_bf16<NS, NT, 16>(acc, wq, wp, act_lane, BLDA, ACT_PLANE, rot, lane, side);
     wp = wblock<NS>(a.packed, true, fwd_off(G_VIEWS), 18, vft, 0);
     wq_prime<NS, 16>(wq, wp, rot, lane);
     __syncthreads();
     store_act<NS, NT, false>(acc, act, ACT_PLANE, wave * 32, 0, lane);
     __syncthreads();
-    if (SAVE) tile_to_plane<NS, W>(act, BLDA, ACT_PLANE, PLANE(SV_FEAT), row0, rows_valid, TM, tid);
+    if (SAVE) pend(PLANE(SV_FEAT), nullptr);
     // view layer: 4 feature tiles x 2 sample halves over the 8 waves
     {
         f32x16 accv[NTV];
         init_acc(accv, hd + H_BV, vft * 32, lane);
-        mma_bf16<NS, NTV, 16>(accv, wq, wp, act_lane + (size_t)vs0 * BLDA, BLDA, ACT_PLANE, rot, lane);
+        mma_bf16<NS, NTV, 16>(accv, wq, wp, act_lane + (size_t)vs0 * BLDA, BLDA, ACT_PLANE, rot, lane, side);
         wp = wblock<NS>(a.packed, true, fwd_off(G_VIEWS), 18, vft, 16);
         wq_prime<NS, 2>(wq, wp, rot, lane);
-        mma_bf16<NS, NTV, 2>(accv, wq, wp, dpe_lane + (size_t)vs0 * BLDD, BLDD, DPE_PLANE, rot, lane);
+        mma_bf16<NS, NTV, 2>(accv, wq, wp, dpe_lane + (size_t)vs0 * BLDD, BLDD, DPE_PLANE, rot, lane, noside);
         __syncthreads();
         store_act<NS, NTV, true>(accv, act, ACT_PLANE, vft * 32, vs0, lane);
         __syncthreads();
@@ -492,7 +585,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_bf16_kernel(FwdArgs a) {
         const float* wr = hd + H_WR;
         float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f;
 #pragma unroll 1
-        for (int c = hq; c < HV / 8; c += TPR) {
+        for (int c = hq; c < ((PLNERF_ABLATE & 2) ? 0 : HV / 8); c += TPR) {
             float v[8];
             load8<NS>(act + (size_t)hrow * BLDA + c * 8, ACT_PLANE, v);
 #pragma unroll
@@ -627,10 +720,14 @@ __global__ __launch_bounds__(NTHREADS, NS == 2 ? 4 : 2) void mlp_bwd_bf16_kernel
     f32x16 acc[NT];
     // d feature = dz_view . W_view[:, :256]  (K = 128)
     WQueue<NS> wq;
+    // (interleaving the dz write-back into the next K loop like the forward does costs ~16 VGPRs,
+    // which at the 128-register / 2-workgroups-per-CU operating point of bf16x3 turns into spills and
+    // measured 15 % slower; the second resident workgroup already overlaps the write-back)
+    NoSide noside;
     const bf16x8* wp = wblock<NS>(a.packed, false, bwd_off(D_VIEWS) - BWD, 8, wave, 0);
     wq_prime<NS, 8>(wq, wp, rot, lane);
     zero_acc(acc);
-    mma_bf16<NS, NT, 8>(acc, wq, wp, g_lane, BLDA, G_PLANE, rot, lane);
+    mma_bf16<NS, NT, 8>(acc, wq, wp, g_lane, BLDA, G_PLANE, rot, lane, noside);
     wp = wblock<NS>(a.packed, false, bwd_off(D_FEAT) - BWD, 16, wave, 0);
     wq_prime<NS, 16>(wq, wp, rot, lane);
     __syncthreads();
@@ -640,7 +737,7 @@ __global__ __launch_bounds__(NTHREADS, NS == 2 ? 4 : 2) void mlp_bwd_bf16_kernel
     build_mask(maskb, MASKP(7), row0, rows_valid, TM, tid);
     // d h7 = dz_feature . W_f + g_sigma w_alpha, masked by h7
     zero_acc(acc);
-    mma_bf16<NS, NT, 16>(acc, wq, wp, g_lane, BLDA, G_PLANE, rot, lane);
+    mma_bf16<NS, NT, 16>(acc, wq, wp, g_lane, BLDA, G_PLANE, rot, lane, noside);
     wp = wblock<NS>(a.packed, false, bwd_off(D_L7) - BWD, 16, wave, 0);
     wq_prime<NS, 16>(wq, wp, rot, lane);
     __syncthreads();
@@ -651,7 +748,7 @@ __global__ __launch_bounds__(NTHREADS, NS == 2 ? 4 : 2) void mlp_bwd_bf16_kernel
     for (int l = 7; l >= 1; --l) {
         build_mask(maskb, MASKP(l - 1), row0, rows_valid, TM, tid);
         zero_acc(acc);
-        mma_bf16<NS, NT, 16>(acc, wq, wp, g_lane, BLDA, G_PLANE, rot, lane);
+        mma_bf16<NS, NT, 16>(acc, wq, wp, g_lane, BLDA, G_PLANE, rot, lane, noside);
         if (l > 1) {
             wp = wblock<NS>(a.packed, false, bwd_off(D_L7) - BWD + (8 - l) * W * W, 16, wave, 0);
             wq_prime<NS, 16>(wq, wp, rot, lane);
