@@ -45,7 +45,8 @@ constexpr int BLDD = 40;    // direction-encoding row (32 + 8)
 constexpr int NTHREADS = 512;
 #ifndef PLNERF_ABLATE
 #define PLNERF_ABLATE 0   // timing experiments (results wrong): 1 cheap sincos, 2 no heads, 4 no epilogue,
-                          // 16 no LDS operand reads in the K loop, 32 no weight loads in the K loop
+                          // 16 no LDS operand reads in the K loop, 32 no weight loads in the K loop,
+                          // 64 pin load/MFMA phases with sched_barrier, 128 no k rotation (these two keep results right)
 #endif
 
 __host__ __device__ constexpr int tile_rows(int ns) { return ns == 1 ? 128 : 64; }
@@ -122,8 +123,9 @@ __device__ __forceinline__ const bf16x8* wblock(const void* packed, bool fwd, in
 // Software pipeline, KC k-steps fully unrolled (all indices static):
 //   weight fragments (global, L2-resident) are fetched PF steps ahead into a PF+1 slot ring,
 //   activation fragments (LDS) one step ahead into a 2-slot ring,
-// and sched_barrier pins "issue next loads, then this step's MFMAs" so the loads' latency
-// hides behind NT*(1|3) MFMAs per step; hipcc inserts the counted vmcnt/lgkmcnt waits.
+// The source order is "issue next loads, then this step's MFMAs"; hipcc schedules around it and
+// inserts the counted vmcnt/lgkmcnt waits.  (Pinning the two phases with sched_barrier(0) measured
+// 24 % SLOWER in bf16 and neutral in bf16x3, so it is off; PLNERF_ABLATE=64 re-enables it.)
 // ------------------------------------------------------------------------------------
 // Deferred write-back of the PREVIOUS layer's tile, interleaved into a 16-step K loop: the tile
 // (bf16 planes in LDS, also being read as this GEMM's B operand) is copied to its fp32 plane in HBM
@@ -249,7 +251,7 @@ __device__ __forceinline__ void mma_bf16(f32x16 (&acc)[NT], WQueue<NS>& w, const
             if ((i & 3) == 2) side.store(i >> 2);     // data requested one step ago has landed
             if ((i & 3) == 1) side.load(i >> 2);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (PLNERF_ABLATE & 64) __builtin_amdgcn_sched_barrier(0);
         const bf16x8 ah = w.q[i % (PF + 1)][0];
         const bf16x8 al = w.q[i % (PF + 1)][NS - 1];
 #pragma unroll
@@ -260,7 +262,7 @@ __device__ __forceinline__ void mma_bf16(f32x16 (&acc)[NT], WQueue<NS>& w, const
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bq[i & 1][t][NS - 1], acc[t], 0, 0, 0);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (PLNERF_ABLATE & 64) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_bf16_kernel(FwdArgs a) {
     const int rows_valid = min(TM, a.n_rows - row0);
     const size_t N = (size_t)a.n_rows;
     const float* hd = head(a.packed);
-    const int rot = (int)(blockIdx.x >> 3);   // consecutive blocks of one XCD (b, b+8, ...) get consecutive rotations
+    const int rot = (PLNERF_ABLATE & 128) ? 0 : (int)(blockIdx.x >> 3);   // consecutive blocks of one XCD (b, b+8, ...) get consecutive rotations
 
     // ---- prologue: encodings -> bf16 planes ---------------------------------------------
     if (a.embedded) {
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(NTHREADS, NS == 2 ? 4 : 2) void mlp_bwd_bf16_kernel
     const int rows_valid = min(TM, a.n_rows - row0);
     const size_t N = (size_t)a.n_rows;
     const float* hd = head(a.packed);
-    const int rot = (int)(blockIdx.x >> 3);   // consecutive blocks of one XCD (b, b+8, ...) get consecutive rotations
+    const int rot = (PLNERF_ABLATE & 128) ? 0 : (int)(blockIdx.x >> 3);   // consecutive blocks of one XCD (b, b+8, ...) get consecutive rotations
 #define SPLANE(p) (a.saved + (size_t)(p) * W * N)
 #define DPLANE(p) (a.dz + (size_t)(p) * W * N)
 #define MASKP(p) (reinterpret_cast<const unsigned char*>(a.saved + (size_t)SV_FLOATS * N) + (size_t)(p) * (W / 8) * N)
