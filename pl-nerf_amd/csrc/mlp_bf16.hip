@@ -492,83 +492,61 @@ __global__ __launch_bounds__(NTHREADS) void mlp_fwd_bf16_kernel(FwdArgs a) {
         side.tile = act; side.ld = BLDA; side.plane_stride = ACT_PLANE; side.plane = nullptr; side.mask = nullptr;
         side.row0 = row0; side.rows_valid = rows_valid; side.tid = tid;
     }
-    // L0
-    init_acc(acc, hd + H_BIAS + 0 * W, wave * 32, lane);
-    mma_bf16<NS, NT, 4>(acc, wq, wp0, pe_lane, BLDP, PE_PLANE, rot, lane, noside);
-    wp = wblock<NS>(a.packed, true, fwd_off(G_L1), 16, wave, 0);
-    wq_prime<NS, 16>(wq, wp, rot, lane);
-    __syncthreads();
-    store_act<NS, NT, true>(acc, act, ACT_PLANE, wave * 32, 0, lane);
-    __syncthreads();
-    if (SAVE) pend(PLANE(0), MASKP(0));
-    // L1..L4
-#pragma unroll 1
-    for (int l = 1; l <= 4; ++l) {
-        init_acc(acc, hd + H_BIAS + l * W, wave * 32, lane);
-        mma_bf16<NS, NT, 16>(acc, wq, wp, act_lane, BLDA, ACT_PLANE, rot, lane, side);
-        if (l < 4) {
-            wp = wblock<NS>(a.packed, true, fwd_off(G_L1) + l * W * W, 16, wave, 0);
-            wq_prime<NS, 16>(wq, wp, rot, lane);
-        } else {
-            wp = WB(G_L5, 20, 0);
-            wq_prime<NS, 4>(wq, wp, rot, lane);
-        }
-        __syncthreads();
-        store_act<NS, NT, true>(acc, act, ACT_PLANE, wave * 32, 0, lane);
-        __syncthreads();
-        if (SAVE) pend(PLANE(l), MASKP(l));
-    }
-    // L5 = [encoding | h4]
-    init_acc(acc, hd + H_BIAS + 5 * W, wave * 32, lane);
-    mma_bf16<NS, NT, 4>(acc, wq, wp, pe_lane, BLDP, PE_PLANE, rot, lane, noside);
-    wp = WB(G_L5, 20, 4);
-    wq_prime<NS, 16>(wq, wp, rot, lane);
-    mma_bf16<NS, NT, 16>(acc, wq, wp, act_lane, BLDA, ACT_PLANE, rot, lane, side);
-    wp = wblock<NS>(a.packed, true, fwd_off(G_L6), 16, wave, 0);
-    wq_prime<NS, 16>(wq, wp, rot, lane);
-    __syncthreads();
-    store_act<NS, NT, true>(acc, act, ACT_PLANE, wave * 32, 0, lane);
-    __syncthreads();
-    if (SAVE) pend(PLANE(5), MASKP(5));
-    // L6, L7
-#pragma unroll 1
-    for (int l = 6; l <= 7; ++l) {
-        init_acc(acc, hd + H_BIAS + l * W, wave * 32, lane);
-        mma_bf16<NS, NT, 16>(acc, wq, wp, act_lane, BLDA, ACT_PLANE, rot, lane, side);
-        wp = (l == 6) ? wblock<NS>(a.packed, true, fwd_off(G_L7), 16, wave, 0) : WB(G_FEAT, 16, 0);
-        wq_prime<NS, 16>(wq, wp, rot, lane);
-        __syncthreads();
-        store_act<NS, NT, true>(acc, act, ACT_PLANE, wave * 32, 0, lane);
-        __syncthreads();
-        if (SAVE) pend(PLANE(l), MASKP(l));
-    }
-    // sigma head: TPR threads per sample, 8-feature chunks interleaved across them
+    // L0..L7 and the feature layer as ONE loop body (l = 8 is the feature layer): an optional
+    // 4-step K range over the xyz encoding (L0, L5) followed by an optional 16-step range over the
+    // activation tile.  One copy of the code keeps registers and I-cache small.
     const int hrow = tid / TPR, hq = tid % TPR;
     float sigma = 0.0f;
-    {
-        const float* wa = hd + H_WA;
-#pragma unroll 1
-        for (int c = hq; c < ((PLNERF_ABLATE & 2) ? 0 : W / 8); c += TPR) {
-            float v[8];
-            load8<NS>(act + (size_t)hrow * BLDA + c * 8, ACT_PLANE, v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sigma = fmaf(v[e], wa[c * 8 + e], sigma);
-        }
-#pragma unroll
-        for (int d = 1; d < TPR; d <<= 1) sigma += __shfl_xor(sigma, d);
-        sigma += hd[H_BA];
-    }
-    // feature (no activation)
     constexpr int NTV = NT / 2;
     const int vft = wave & 3, vs0 = (wave >> 2) * (TM / 2);
-    init_acc(acc, hd + H_BF, wave * 32, lane);
-    mma_bf16<NS, NT, 16>(acc, wq, wp, act_lane, BLDA, ACT_PLANE, rot, lane, side);
-    wp = wblock<NS>(a.packed, true, fwd_off(G_VIEWS), 18, vft, 0);
-    wq_prime<NS, 16>(wq, wp, rot, lane);
-    __syncthreads();
-    store_act<NS, NT, false>(acc, act, ACT_PLANE, wave * 32, 0, lane);
-    __syncthreads();
-    if (SAVE) pend(PLANE(SV_FEAT), nullptr);
+    wp = wp0;
+#pragma unroll 1
+    for (int l = 0; l <= 8; ++l) {
+        const bool has_pe = (l == 0) || (l == 5);
+        const bool has_act = l > 0;
+        init_acc(acc, l < 8 ? hd + H_BIAS + l * W : hd + H_BF, wave * 32, lane);
+        if (has_pe) {
+            mma_bf16<NS, NT, 4>(acc, wq, wp, pe_lane, BLDP, PE_PLANE, rot, lane, noside);
+            if (has_act) {
+                wp = WB(G_L5, 20, 4);
+                wq_prime<NS, 16>(wq, wp, rot, lane);
+            }
+        }
+        if (has_act) mma_bf16<NS, NT, 16>(acc, wq, wp, act_lane, BLDA, ACT_PLANE, rot, lane, side);
+        // request the next GEMM's first weight blocks before the barrier + epilogue of this one
+        if (l == 4) {
+            wp = WB(G_L5, 20, 0);
+            wq_prime<NS, 4>(wq, wp, rot, lane);
+        } else if (l == 8) {
+            wp = wblock<NS>(a.packed, true, fwd_off(G_VIEWS), 18, vft, 0);
+            wq_prime<NS, 16>(wq, wp, rot, lane);
+        } else {
+            // packed order: L0 | L1..L4 | L5 | L6 L7 FEAT ; next = l + 1
+            const int nxt = l + 1;
+            const int woff = nxt <= 4 ? fwd_off(G_L1) + (nxt - 1) * W * W : fwd_off(G_L6) + (nxt - 6) * W * W;
+            wp = wblock<NS>(a.packed, true, woff, 16, wave, 0);
+            wq_prime<NS, 16>(wq, wp, rot, lane);
+        }
+        __syncthreads();
+        if (l < 8) store_act<NS, NT, true>(acc, act, ACT_PLANE, wave * 32, 0, lane);
+        else store_act<NS, NT, false>(acc, act, ACT_PLANE, wave * 32, 0, lane);
+        __syncthreads();
+        if (SAVE) pend(PLANE(l), l < 8 ? MASKP(l) : nullptr);
+        if (l == 7) {
+            // sigma head (reads h7): TPR threads per sample, 8-feature chunks interleaved across them
+            const float* wa = hd + H_WA;
+#pragma unroll 1
+            for (int c = hq; c < ((PLNERF_ABLATE & 2) ? 0 : W / 8); c += TPR) {
+                float v[8];
+                load8<NS>(act + (size_t)hrow * BLDA + c * 8, ACT_PLANE, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sigma = fmaf(v[e], wa[c * 8 + e], sigma);
+            }
+#pragma unroll
+            for (int d = 1; d < TPR; d <<= 1) sigma += __shfl_xor(sigma, d);
+            sigma += hd[H_BA];
+        }
+    }
     // view layer: 4 feature tiles x 2 sample halves over the 8 waves
     {
         f32x16 accv[NTV];
