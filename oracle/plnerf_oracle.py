@@ -439,6 +439,9 @@ def train_step(sd_coarse, sd_fine, ray_batch, target, render_kwargs, lr=5e-4, ad
             adam_state["opt_f"], adam_state["opt_c"] = opt_f, opt_c
     else:
         opt_f, opt_c = adam_state["opt_f"], adam_state["opt_c"]
+        for opt in (opt_f, opt_c):     # the caller's schedule (run_plnerf.py:1307-1315)
+            for group in opt.param_groups:
+                group["lr"] = lr
     ret = render_rays(ray_batch, sd_coarse, sd_fine, retraw=True, **render_kwargs)
     opt_f.zero_grad()
     opt_c.zero_grad()

@@ -564,3 +564,68 @@ def test_full_size_properties(P):
         full = net.query(pts, vd)
         half = torch.cat([net.query(pts[:300], vd[:300]), net.query(pts[300:], vd[300:])], 0)
     assert torch.equal(full, half)
+
+
+# ----------------------------------------------------------------------------- caller side (section 8f)
+def test_train_loop_matches_oracle_over_steps(P):
+    """TrainStep (run_plnerf.py:1283-1316: two Adams, LR decay, quirks) for 3 steps against the oracle's
+    loop on the same rays and the reference's deterministic draws: loss curve and final weights."""
+    import tempfile, os
+    from argparse import Namespace
+    d = tempfile.mkdtemp()
+    os.makedirs(os.path.join(d, "exp"))
+    args = Namespace(multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=128, N_samples=64,
+                     netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256, netchunk=65536, lrate=5e-4,
+                     coarse_lrate=5e-4, ft_path=None, ckpt_dir=d, expname="exp", no_reload=True, perturb=1.0,
+                     white_bkgd=True, raw_noise_std=0.0, mode="linear", color_mode="midpoint", dataset="blender",
+                     no_ndc=False, lindisp=False, lrate_decay=1, constant_init=0, chunk=32768, precision="fp32")
+    kw, _, start, _, opt, opt_c = P.create_nerf(args, device=dev())
+    sd_c, sd_f = orc.closed_form_state_dict(0, False), orc.closed_form_state_dict(1, False)
+    kw["network_fn"].load_state_dict(sd_c)
+    kw["network_fine"].load_state_dict(sd_f)
+    batch, target = orc.synthetic_blender_rays(48, seed=9)
+    rays = (g(batch[:, 0:3]), g(batch[:, 3:6]))
+    K = [[1111.111, 0, 400], [0, 1111.111, 400], [0, 0, 1]]
+    ts = P.TrainStep(args, dict(kw, pytest=True), opt, opt_c, start=start, distributed=False)
+    okw = dict(N_samples=64, N_importance=128, mode="linear", color_mode="midpoint", perturb=1.0, white_bkgd=True,
+               raw_noise_std=0.0, pytest=True)
+    state, lr = {}, 5e-4
+    for step in range(3):
+        ref_loss, _, _ = orc.train_step(sd_c, sd_f, batch, target, okw, lr=lr, adam_state=state)
+        loss, psnr = ts(800, 800, K, rays, g(target), near=2.0, far=6.0)
+        assert abs(float(loss) - float(ref_loss)) <= 2e-5 * max(1.0, float(ref_loss)), (step, float(loss), float(ref_loss))
+        lr = 5e-4 * 0.1 ** (step / 1000.0)            # the rate the reference installs after this step
+        assert abs(opt.param_groups[0]["lr"] - lr) < 1e-12 and abs(opt_c.param_groups[0]["lr"] - lr) < 1e-12
+    worst = 0.0
+    for net, sd in ((kw["network_fn"], sd_c), (kw["network_fine"], sd_f)):
+        for name, prm in net.named_parameters():
+            worst = max(worst, maxdiff(prm, sd[name]))
+    print(f"3 training steps: final loss {float(loss):.6f}, max |param - oracle| {worst:.3e}")
+    assert worst <= 2.5e-3       # Adam moves each weight ~lr per step; sign flips of ~0 gradients cost <= 2 lr / step
+
+
+def test_full_image_render_c2w(P):
+    """render(c2w=...) (run_plnerf.py:136-138, 95-107): every pixel of a small view, chunked, against the
+    oracle on the same rays with det sampling disabled (random draws injected through pytest=True)."""
+    H, W, f = 12, 16, 18.0
+    K = [[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]]
+    c2w = P.rays.pose_spherical(25.0, -30.0, 4.0)[:3, :4]
+    sd_c, sd_f = orc.closed_form_state_dict(0, True), orc.closed_form_state_dict(1, True)
+    emb_fn, _ = P.get_embedder(10, 0)
+    embd_fn, _ = P.get_embedder(4, 0)
+    qfn = lambda inputs, viewdirs, fn: P.run_network(inputs, viewdirs, fn, emb_fn, embd_fn)
+    kw = dict(network_query_fn=qfn, perturb=1.0, N_importance=64, network_fine=make_net(P, sd_f), N_samples=32,
+              network_fn=make_net(P, sd_c), white_bkgd=True, raw_noise_std=0.0, mode="linear", color_mode="midpoint")
+    with torch.no_grad():
+        rgb, disp, acc, extras = P.render(H, W, K, chunk=H * W, c2w=g(c2w), ndc=False, near=2.0, far=6.0,
+                                          use_viewdirs=True, pytest=True, **kw)
+        rgb_chunked = P.render(H, W, K, chunk=50, c2w=g(c2w), ndc=False, near=2.0, far=6.0, use_viewdirs=True,
+                               pytest=False, **dict(kw, perturb=0.0, mode="constant"))[0]
+    assert rgb.shape == (H, W, 3) and acc.shape == (H, W) and extras["depth_map"].shape == (H, W)
+    assert rgb_chunked.shape == (H, W, 3) and torch.isfinite(rgb_chunked).all()
+    o, dd = orc.get_rays(H, W, K, c2w)
+    batch = orc.pack_ray_batch(o, dd, 2.0, 6.0)
+    ref = orc.render_rays(batch, sd_c, sd_f, 32, "linear", "midpoint", perturb=1.0, N_importance=64,
+                          white_bkgd=True, pytest=True)
+    assert_close(rgb.reshape(-1, 3), ref["rgb_map"], atol=1e-4, rtol=1e-4, what="full-image rgb")
+    assert_close(extras["rgb0"].reshape(-1, 3), ref["rgb0"], what="full-image rgb0")

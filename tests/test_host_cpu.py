@@ -148,3 +148,61 @@ def test_data_parallel_gradient_allreduce_gloo(tmp_path):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {rank} failed:\n{out}"
         assert f"rank {rank} ok" in out
+
+
+def _args(ckpt_dir, **over):
+    from argparse import Namespace
+    a = dict(multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=128, N_samples=64, netdepth=8,
+             netwidth=256, netdepth_fine=8, netwidth_fine=256, netchunk=65536, lrate=5e-4, coarse_lrate=5e-4,
+             ft_path=None, ckpt_dir=ckpt_dir, expname="exp", no_reload=False, perturb=1.0, white_bkgd=True,
+             raw_noise_std=0.0, mode="linear", color_mode="midpoint", dataset="blender", no_ndc=False, lindisp=False,
+             lrate_decay=500, constant_init=1000, chunk=32768)
+    a.update(over)
+    return Namespace(**a)
+
+
+def test_checkpoint_wire_format_roundtrip(built, tmp_path, capsys):
+    """Checkpoints use the reference's dict keys / file naming (run_plnerf.py:1324-1332) and create_nerf
+    resumes from the newest '*tar*' in ckpt_dir/expname (454-471)."""
+    (tmp_path / "exp").mkdir()
+    args = _args(str(tmp_path))
+    cpu = torch.device("cpu")
+    kw, kw_test, start, grad_vars, opt, opt_c = built.create_nerf(args, device=cpu)
+    assert start == 0 and set(kw) >= {"network_query_fn", "perturb", "N_importance", "network_fine", "N_samples",
+                                      "network_fn", "white_bkgd", "raw_noise_std", "mode", "color_mode"}
+    assert kw_test["perturb"] is True and kw_test["raw_noise_std"] == 0.
+    assert grad_vars[0] is next(kw["network_fine"].parameters())          # `optimizer` drives the fine network
+    path = built.checkpoint_path(str(tmp_path), "exp", 1234)
+    built.save_checkpoint(path, 1234, kw["network_fn"], kw["network_fine"], opt)
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) == {"global_step", "network_fn_state_dict", "network_fine_state_dict", "optimizer_state_dict"}
+    assert list(ck["network_fn_state_dict"]) == [k for k, _ in __import__("oracle.plnerf_oracle", fromlist=["x"]).param_shapes()]
+    kw2, _, start2, _, _, _ = built.create_nerf(args, device=cpu)
+    assert start2 == 1234
+    for a, b in zip(kw["network_fine"].parameters(), kw2["network_fine"].parameters()):
+        assert torch.equal(a, b)
+    for a, b in zip(kw["network_fn"].parameters(), kw2["network_fn"].parameters()):
+        assert torch.equal(a, b)
+
+
+def test_select_rays_matches_get_rays(built):
+    H, W, f = 20, 30, 25.0
+    K = [[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]]
+    c2w = built.rays.pose_spherical(40.0, -30.0, 4.0)[:3, :4]
+    o, d = built.get_rays(H, W, K, c2w)
+    g = torch.Generator().manual_seed(3)
+    batch, rows, cols = built.select_rays(H, W, K, c2w, 50, generator=g)
+    assert len(set((rows * W + cols).tolist())) == 50                     # distinct pixels
+    assert torch.allclose(batch[1], d[rows, cols], atol=1e-6) and torch.equal(batch[0], o[rows, cols])
+    batch, rows, cols = built.select_rays(H, W, K, c2w, 30, generator=g, precrop=(5, 6))
+    assert rows.min() >= H // 2 - 5 and rows.max() < H // 2 + 5 and cols.min() >= W // 2 - 6 and cols.max() < W // 2 + 6
+
+
+def test_lr_schedule_matches_reference_quirk(built, tmp_path):
+    (tmp_path / "exp").mkdir()
+    args = _args(str(tmp_path), no_reload=True, lrate=5e-4, coarse_lrate=1e-4)
+    kw, _, start, _, opt, opt_c = built.create_nerf(args, device=torch.device("cpu"))
+    ts = built.TrainStep(args, kw, opt, opt_c, start=start, distributed=False)
+    ts.global_step = 2500
+    assert abs(ts.learning_rate() - 5e-4 * 0.1 ** (2500 / 500000)) < 1e-12
+    assert opt_c.param_groups[0]["lr"] == 1e-4        # until the first step; afterwards the fine rate (line 1315)
