@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and run the gradient all-reduce even with one rank (path check)")
     return ap.parse_args()
 
 
@@ -90,7 +92,7 @@ def main():
     a = parse()
     import plnerf_amd as P
     from plnerf_amd import dp, functional as Fn
-    rank, world, local = dp.init_from_env()
+    rank, world, local = dp.init_from_env(force=a.force_dist)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -104,7 +106,7 @@ def main():
     sys.stdout = _stdout
     nets = [kw["network_fn"], kw["network_fine"]]
     dp.broadcast_parameters(nets)
-    bucket = dp.GradientBucket(nets) if world > 1 else None
+    bucket = dp.GradientBucket(nets) if (world > 1 or a.force_dist) else None
 
     # every rank renders its own shard of the global batch: rays [rank*R, (rank+1)*R)
     R = a.rays
@@ -123,14 +125,14 @@ def main():
         loss = P.img2mse(rgb, target) + P.img2mse(extras["rgb0"], target)
         loss.backward()
         if bucket is not None:
-            bucket.allreduce_mean()
+            bucket.allreduce_mean(force=a.force_dist)
         opt.step()
         opt_c.step()
         return loss
 
     def sync():
-        if world > 1:
-            torch.distributed.barrier()
+        if world > 1 or a.force_dist:
+            torch.distributed.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
@@ -145,7 +147,7 @@ def main():
     dt = time.perf_counter() - t0
     Fn.KERNEL_TIMER = None
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if world > 1 or a.force_dist:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -187,7 +189,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -15,13 +15,14 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force=False):
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun's contract).
-    Returns (rank, world_size, local_rank).  No-op for a single process."""
+    Returns (rank, world_size, local_rank).  No-op for a single process unless `force`
+    (used to exercise the RCCL path on one GPU)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -59,6 +60,10 @@ class GradientBucket:
             off += p.numel()
 
     def gather(self):
+        """All .grad tensors -> the flat bucket, in ONE kernel (torch.cat into the buffer)."""
+        if all(p.grad is not None for p in self.params):
+            torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat)
+            return
         for p, v in zip(self.params, self.views):
             if p.grad is None:
                 v.zero_()
@@ -66,15 +71,15 @@ class GradientBucket:
                 v.copy_(p.grad)
 
     def scatter(self):
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+        """Flat bucket -> the .grad tensors, in one multi-tensor kernel."""
+        missing = [p for p in self.params if p.grad is None]
+        for p in missing:
+            p.grad = torch.empty_like(p)
+        torch._foreach_copy_([p.grad for p in self.params], self.views)
 
-    def allreduce_mean(self, group=None):
+    def allreduce_mean(self, group=None, force=False):
         world = dist.get_world_size(group) if dist.is_initialized() else 1
-        if world == 1:
+        if world == 1 and not (force and dist.is_initialized()):
             return
         self.gather()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)

@@ -88,7 +88,6 @@ class NeRF(nn.Module):
         else:
             self.output_linear = nn.Linear(W, output_ch)
         self._packed = None
-        self._packed_key = None
 
     # -- HIP plumbing ---------------------------------------------------------------
     def is_supported(self):
@@ -110,23 +109,22 @@ class NeRF(nn.Module):
         return list(self.parameters())
 
     def packed_weights(self):
-        """Weights re-laid-out in MFMA fragment order (plnerf_mlp_pack_weights); cached and
-        re-packed whenever a parameter was modified in place (optimizer step, load_state_dict)."""
+        """Weights re-laid-out in MFMA fragment order (plnerf_mlp_pack_weights).  Re-packed on EVERY
+        call: one ~10 us pass over 2.4 MB, negligible next to any forward -- and the only safe policy,
+        because in-place parameter updates are not reliably observable (fused/foreach optimizers do
+        not bump `Tensor._version`; a version-keyed cache silently served stale weights once)."""
         self._require_supported()
         params = self.param_list()
-        key = (self.precision,) + tuple((p.data_ptr(), p._version) for p in params)
-        if self._packed is None or self._packed_key != key:
-            prec = L.PRECISION[self.precision]
-            nbytes = L.lib().plnerf_mlp_packed_bytes(prec)
-            if nbytes == 0:
-                raise NotImplementedError(f"precision mode {self.precision!r} is not built")
-            dev = params[0].device
-            flat = [p.detach() for p in params]
-            if self._packed is None or self._packed.device != dev or self._packed.numel() * 4 != nbytes:
-                self._packed = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
-            L.check(L.lib().plnerf_mlp_pack_weights(L.ptr_table(flat), prec, L.dptr(self._packed), L.stream()),
-                    "plnerf_mlp_pack_weights")
-            self._packed_key = key
+        prec = L.PRECISION[self.precision]
+        nbytes = L.lib().plnerf_mlp_packed_bytes(prec)
+        if nbytes == 0:
+            raise NotImplementedError(f"precision mode {self.precision!r} is not built")
+        dev = params[0].device
+        flat = [p.detach() for p in params]
+        if self._packed is None or self._packed.device != dev or self._packed.numel() * 4 != nbytes:
+            self._packed = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+        L.check(L.lib().plnerf_mlp_pack_weights(L.ptr_table(flat), prec, L.dptr(self._packed), L.stream()),
+                "plnerf_mlp_pack_weights")
         return self._packed
 
     # -- reference interface --------------------------------------------------------

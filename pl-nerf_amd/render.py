@@ -290,8 +290,10 @@ def create_nerf(args, device=None):
                            netchunk=args.netchunk)
 
     # `optimizer` drives the fine network, `optimizer_coarse` the coarse one (:438, :446-447)
-    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
-    optimizer_coarse = torch.optim.Adam(params=coarse_grad_vars, lr=args.coarse_lrate, betas=(0.9, 0.999))
+    # same Adam as the reference; on the GPU its fused (single-kernel) implementation
+    fused = {"fused": True} if torch.device(device).type == "cuda" else {}
+    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999), **fused)
+    optimizer_coarse = torch.optim.Adam(params=coarse_grad_vars, lr=args.coarse_lrate, betas=(0.9, 0.999), **fused)
 
     start = 0
     if args.ft_path is not None and args.ft_path != 'None':
