@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 
 FWD_FLOP_PER_ROW = 1186816      # 2 x 593,408 MAC per network evaluation
 TRAIN_FLOP_PER_ROW = 3489024    # forward + wgrad + dgrad
-PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}   # MI355X_MICROARCH.md, dense
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "f16x3": 2500.0, "f16": 2500.0}   # MI355X_MICROARCH.md, dense
 
 
 def parse():
@@ -42,9 +42,11 @@ def parse():
     ap.add_argument("--rays", type=int, default=4096, help="N_rand per GPU")
     ap.add_argument("--n-samples", type=int, default=64)
     ap.add_argument("--n-importance", type=int, default=128)
-    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "bf16"],
-                    help="MLP arithmetic: bf16x3 (default) = 3-term bf16 split on the bf16 MFMA pipe, holds the 1e-5 "
-                         "parity bound; fp32 = exact fp32 MFMA; bf16 = plain bf16 operands (throughput only)")
+    ap.add_argument("--precision", default="f16x3", choices=["fp32", "bf16x3", "bf16", "f16x3", "f16"],
+                    help="MLP arithmetic: f16x3 (default) = 3-term IEEE-half split in the forward GEMMs + 3-term bf16 "
+                         "split in the backward GEMMs on the 16-bit MFMA pipe, holds the 1e-5 parity bound with ~7x "
+                         "margin; bf16x3 = bf16 split everywhere; fp32 = exact fp32 MFMA; bf16 / f16 = plain 16-bit "
+                         "operands (throughput only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -168,7 +170,7 @@ def main():
             "metric": "training rays/sec (coarse+fine, 64+128 samples)",
             "value": R * world * a.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (3-term bf16 split, f32 accumulate; weight gradients f32)", "bf16": "bf16 (f32 accumulate; weight gradients f32)"}[a.precision], "data": "synthetic",
+            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (3-term bf16 split, f32 accumulate)", "bf16": "bf16 (f32 accumulate)", "f16x3": "f16x3 (3-term f16 split, f32 accumulate)", "f16": "f16 (f32 accumulate)"}[a.precision], "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: 800x800 Blender-style rays, N_rand={R}/GPU, "
                                    f"N_samples={a.n_samples}, N_importance={a.n_importance}, mode=linear/midpoint, "
                                    f"white_bkgd, perturb=1; full step = render + backward + grad all-reduce + 2xAdam",
@@ -180,7 +182,7 @@ def main():
                 "traffic": traffic, "launch_ms": fwd_ms, "rows_per_launch": rows_fine,
                 "flop_per_row": FWD_FLOP_PER_ROW,
                 # MFMA work actually issued: bf16x3 spends 3 MFMAs per algorithmic product
-                "mfma_issue_frac": ((ach * {"fp32": 1, "bf16x3": 3, "bf16": 1}[a.precision] / peak) if ach else None),
+                "mfma_issue_frac": ((ach * {"fp32": 1, "bf16x3": 3, "bf16": 1, "f16x3": 3, "f16": 1}[a.precision] / peak) if ach else None),
                 "mlp_bwd_launch_ms": bwd_ms,
                 "train_mlp_tflops": (rows_fine * TRAIN_FLOP_PER_ROW / ((fwd_ms + bwd_ms) * 1e-3) / 1e12)
                 if (fwd_ms and bwd_ms) else None,

@@ -43,6 +43,11 @@ extern "C" {
 #define PLNERF_PREC_FP32 0   /* v_mfma_f32_32x32x2_f32: exact fp32 fma chains        */
 #define PLNERF_PREC_BF16X3 1 /* 3-term bf16 split on v_mfma_f32_32x32x16_bf16        */
 #define PLNERF_PREC_BF16 2   /* plain bf16 operands, fp32 accumulate                 */
+/* Hybrids: IEEE-half operands (11-bit mantissa) in the forward GEMMs, where every value is
+ * O(1); the backward GEMMs keep bf16 operands because pre-activation gradients span the
+ * fp32 exponent range and would flush to zero in half precision. */
+#define PLNERF_PREC_F16X3 3  /* fwd: 3-term f16 split (v_mfma_f32_32x32x16_f16); bwd: BF16X3 */
+#define PLNERF_PREC_F16 4    /* fwd: plain f16 operands; bwd: BF16                          */
 
 #define PLNERF_MAX_SAMPLES 1022 /* S+2 knots must fit the per-wave LDS row */
 

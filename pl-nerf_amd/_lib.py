@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PLNERF_HIP_LIB") or os.path.join(_HERE, "libplnerf_hi
 
 MODE = {"constant": 0, "linear": 1}
 COLOR = {"midpoint": 0, "left": 1}
-PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2}
+PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3, "f16": 4}
 N_PARAM_TENSORS = 24
 
 c_f = ctypes.c_void_p      # device pointer

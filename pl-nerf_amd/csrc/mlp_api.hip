@@ -9,11 +9,11 @@ using namespace plnerf;
 
 namespace {
 inline int ns_of(int precision) {
-    return precision == PLNERF_PREC_BF16 ? 1 : precision == PLNERF_PREC_BF16X3 ? 2 : 0;
+    return (precision == PLNERF_PREC_BF16 || precision == PLNERF_PREC_F16) ? 1
+           : (precision == PLNERF_PREC_BF16X3 || precision == PLNERF_PREC_F16X3) ? 2 : 0;
 }
-inline bool known(int precision) {
-    return precision == PLNERF_PREC_FP32 || precision == PLNERF_PREC_BF16 || precision == PLNERF_PREC_BF16X3;
-}
+inline int f16_of(int precision) { return precision == PLNERF_PREC_F16X3 || precision == PLNERF_PREC_F16; }
+inline bool known(int precision) { return precision >= PLNERF_PREC_FP32 && precision <= PLNERF_PREC_F16; }
 }  // namespace
 
 extern "C" size_t plnerf_mlp_packed_bytes(int precision) {
@@ -29,7 +29,7 @@ extern "C" int plnerf_mlp_pack_weights(const float* const* params, int precision
     for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i)
         if (!params[i]) return PLNERF_EINVAL;
     if (precision == PLNERF_PREC_FP32) return impl::f32_pack(params, packed, (hipStream_t)stream);
-    return impl::bf16_pack(params, ns_of(precision), packed, (hipStream_t)stream);
+    return impl::bf16_pack(params, ns_of(precision), f16_of(precision), packed, (hipStream_t)stream);
 }
 
 extern "C" size_t plnerf_mlp_saved_bytes(int n_rows, int precision) {
@@ -54,7 +54,7 @@ extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pt
     if (precision == PLNERF_PREC_FP32)
         return impl::f32_fwd(packed, pts, viewdirs, embedded, n_rows, samples_per_ray, raw_out, saved,
                              (hipStream_t)stream);
-    return impl::bf16_fwd(packed, ns_of(precision), pts, viewdirs, embedded, n_rows, samples_per_ray, raw_out,
+    return impl::bf16_fwd(packed, ns_of(precision), f16_of(precision), pts, viewdirs, embedded, n_rows, samples_per_ray, raw_out,
                           saved, (hipStream_t)stream);
 }
 
@@ -69,8 +69,8 @@ extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_
     float* dz = (float*)workspace;
     int rc;
     if (precision == PLNERF_PREC_FP32) rc = impl::f32_dgrad(packed, g_raw, n_rows, (const float*)saved, dz, st);
-    else rc = impl::bf16_dgrad(packed, ns_of(precision), g_raw, n_rows, (const float*)saved, dz, st);
+    else rc = impl::bf16_dgrad(packed, ns_of(precision), f16_of(precision), g_raw, n_rows, (const float*)saved, dz, st);
     if (rc) return rc;
     // weight gradients over the fp32 planes; the big 256x256 jobs use the mode's MFMA type
-    return impl::f32_wgrad(g_raw, n_rows, (const float*)saved, dz, grads, ns_of(precision), st);
+    return impl::f32_wgrad(g_raw, n_rows, (const float*)saved, dz, grads, ns_of(precision), 0, st);
 }

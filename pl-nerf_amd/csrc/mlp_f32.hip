@@ -660,29 +660,42 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(WgradArgs a) {
 // one barrier per stage.
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 constexpr int TR_ROWS = 16;            // rows per stage = one MFMA k-step
-constexpr int TR_RS = 288;             // LDS row stride in bf16 elements (256 + 32): 576 B
+constexpr int TR_RS = 288;             // LDS row stride in 16-bit elements (256 + 32): 576 B
 constexpr int TR_PLANE = TR_ROWS * TR_RS;
 
-__device__ __forceinline__ wbf16x8 tr_frag(const __bf16* plane, int lane, int col0) {
+// the 32x32x16 MFMA of the element type
+__device__ __forceinline__ f32x16 mfma16(__bf16 __attribute__((ext_vector_type(8))) a,
+                                         __bf16 __attribute__((ext_vector_type(8))) b, f32x16 c, int, int, int) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma16(_Float16 __attribute__((ext_vector_type(8))) a,
+                                         _Float16 __attribute__((ext_vector_type(8))) b, f32x16 c, int, int, int) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+template <typename T>
+__device__ __forceinline__ T __attribute__((ext_vector_type(8))) tr_frag(const T* plane, int lane, int col0) {
+    typedef T vec8 __attribute__((ext_vector_type(8)));
     // 8 consecutive rows (k) of column col0 + (lane & 31), rows 8 * (lane >> 5) .. +7
     const int lam = lane & 15, gam = lane >> 4;
     const int row = 8 * (gam >> 1) + (lam >> 2), col = col0 + 16 * (gam & 1) + 4 * (lam & 3);
-    const __bf16* p = plane + row * TR_RS + col;
+    const T* p = plane + row * TR_RS + col;
     typedef __attribute__((address_space(3))) v4s16* lds_v4;
     const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)p);
     const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p + 4 * TR_RS));
-    union { v4s16 h[2]; wbf16x8 v; } u;
+    union { v4s16 h[2]; vec8 v; } u;
     u.h[0] = lo;
     u.h[1] = hi;
     return u.v;
 }
 
-template <int NS, int NI>
+template <typename T, int NS, int NI>
 __global__ __launch_bounds__(512) void wgrad_tr_kernel(WgradArgs a) {
+    typedef T vec8 __attribute__((ext_vector_type(8)));
     constexpr int NO = 2, WI = 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // [buffer 2][operand A,B][plane NS][TR_ROWS][TR_RS]
-    __bf16* lds = reinterpret_cast<__bf16*>(smem_raw);
+    T* lds = reinterpret_cast<T*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const WJob job = a.jobs[a.tile_job[blockIdx.x]];
@@ -715,21 +728,21 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(WgradArgs a) {
                 rb[j] = *reinterpret_cast<const float4*>(job.B + (size_t)(m + b_row[j]) * job.ldb + b_col[j]);
         }
     };
-    auto put = [&](__bf16* dst, const float4& v) {   // dst = hi plane slot; lo plane is NS-1 planes later
+    auto put = [&](T* dst, const float4& v) {   // dst = hi plane slot; lo plane is NS-1 planes later
         const float x[4] = {v.x, v.y, v.z, v.w};
-        typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+        typedef T b4 __attribute__((ext_vector_type(4)));
         b4 h, l;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            h[e] = (__bf16)x[e];
-            l[e] = (__bf16)(x[e] - (float)h[e]);
+            h[e] = (T)x[e];
+            l[e] = (T)(x[e] - (float)h[e]);
         }
         *reinterpret_cast<b4*>(dst) = h;
         if (NS == 2) *reinterpret_cast<b4*>(dst + TR_PLANE) = l;
     };
     auto stash = [&](int buf) {
-        __bf16* A0 = lds + (size_t)buf * 2 * NS * TR_PLANE;
-        __bf16* B0 = A0 + NS * TR_PLANE;
+        T* A0 = lds + (size_t)buf * 2 * NS * TR_PLANE;
+        T* B0 = A0 + NS * TR_PLANE;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (a_row[j] < TR_ROWS) {
@@ -751,9 +764,9 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(WgradArgs a) {
         const bool more = m + TR_ROWS < m_end;
         if (more) fetch(m + TR_ROWS);
         if (live) {
-            const __bf16* A0 = lds + (size_t)buf * 2 * NS * TR_PLANE;
-            const __bf16* B0 = A0 + NS * TR_PLANE;
-            wbf16x8 ah[NO], al[NO], bh[NI], bl[NI];
+            const T* A0 = lds + (size_t)buf * 2 * NS * TR_PLANE;
+            const T* B0 = A0 + NS * TR_PLANE;
+            vec8 ah[NO], al[NO], bh[NI], bl[NI];
 #pragma unroll
             for (int o = 0; o < NO; ++o) {
                 ah[o] = tr_frag(A0, lane, o_base + 32 * o);
@@ -768,10 +781,10 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(WgradArgs a) {
             for (int o = 0; o < NO; ++o)
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
-                    acc[o][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[o], bh[i], acc[o][i], 0, 0, 0);
+                    acc[o][i] = mfma16(ah[o], bh[i], acc[o][i], 0, 0, 0);
                     if (NS == 2) {
-                        acc[o][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[o], bh[i], acc[o][i], 0, 0, 0);
-                        acc[o][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[o], bl[i], acc[o][i], 0, 0, 0);
+                        acc[o][i] = mfma16(al[o], bh[i], acc[o][i], 0, 0, 0);
+                        acc[o][i] = mfma16(ah[o], bl[i], acc[o][i], 0, 0, 0);
                     }
                 }
         }
@@ -944,6 +957,24 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     p[i] = p[i] - step_size * (mi / denom);
 }
 
+// launch wgrad_tr_kernel for (element type, planes)
+template <typename T, int NS, int NI>
+inline void launch_tr_one(dim3 grid, size_t lds, hipStream_t st, const WgradArgs& a) {
+    (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel<T, NS, NI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL((wgrad_tr_kernel<T, NS, NI>), grid, dim3(512), lds, st, a);
+}
+template <int NI>
+inline void launch_tr(int ns, int f16, dim3 grid, size_t lds, hipStream_t st, const WgradArgs& a) {
+    if (f16) {
+        if (ns == 1) launch_tr_one<_Float16, 1, NI>(grid, lds, st, a);
+        else launch_tr_one<_Float16, 2, NI>(grid, lds, st, a);
+    } else {
+        if (ns == 1) launch_tr_one<__bf16, 1, NI>(grid, lds, st, a);
+        else launch_tr_one<__bf16, 2, NI>(grid, lds, st, a);
+    }
+}
+
 inline int splits_for(int n_rows) {
     int s = (n_rows + 1023) / 1024;
     if (s < 1) s = 1;
@@ -1013,7 +1044,7 @@ int f32_dgrad(const void* packed, const float* g_raw, int n_rows, const float* s
 // Weight gradients from the fp32 planes (saved activations + dz planes written by any of the
 // dgrad kernels): split-K partials, head reductions, deterministic final sum into grads[24].
 int f32_wgrad(const float* g_raw, int n_rows, const float* sv, float* dz, float* const* grads, int ns,
-              hipStream_t st) {
+              int f16, hipStream_t st) {
     const size_t N = (size_t)n_rows;
     float* part = dz + (size_t)DZ_PER_ROW * N;
     float* head_part = part + (size_t)MAX_SPLITS * PART_PER_SPLIT;
@@ -1055,16 +1086,8 @@ int f32_wgrad(const float* g_raw, int n_rows, const float* sv, float* dz, float*
         a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
         if (ns == 0) hipLaunchKernelGGL((wgrad_f32_kernel<2, 2, 2, 4, 4>), dim3(nt, splits), dim3(256), 0, st, a);
         else {
-            const size_t lds = (size_t)2 * 2 * ns * TR_PLANE * sizeof(__bf16);   // 2 buffers x {A,B} x planes
-            if (ns == 1) {
-                (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel<1, 4>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL((wgrad_tr_kernel<1, 4>), dim3(nt, splits), dim3(512), lds, st, a);
-            } else {
-                (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel<2, 4>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL((wgrad_tr_kernel<2, 4>), dim3(nt, splits), dim3(512), lds, st, a);
-            }
+            const size_t lds = (size_t)2 * 2 * ns * TR_PLANE * 2;   // 2 buffers x {A,B} x planes, 16-bit elements
+            launch_tr<4>(ns, f16, dim3(nt, splits), lds, st, a);
         }
         PLNERF_CHECK_LAUNCH();
     }
@@ -1098,16 +1121,8 @@ int f32_wgrad(const float* g_raw, int n_rows, const float* sv, float* dz, float*
         a.jobs[2] = WJob{dzv_plane, dpe_plane, HV, DPE_K, HV, DPE_K, PART_VDIR, -1};
         for (int t = 0; t < 3; ++t) { a.tile_job[t] = t; a.tile_o0[t] = 0; }
         a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
-        const size_t lds = (size_t)2 * 2 * ns * TR_PLANE * sizeof(__bf16);
-        if (ns == 1) {
-            (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds);
-            hipLaunchKernelGGL((wgrad_tr_kernel<1, 1>), dim3(3, splits), dim3(512), lds, st, a);
-        } else {
-            (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds);
-            hipLaunchKernelGGL((wgrad_tr_kernel<2, 1>), dim3(3, splits), dim3(512), lds, st, a);
-        }
+        const size_t lds = (size_t)2 * 2 * ns * TR_PLANE * 2;
+        launch_tr<1>(ns, f16, dim3(3, splits), lds, st, a);
         PLNERF_CHECK_LAUNCH();
     }
     const int n_head = head_wgs_for(n_rows);

@@ -7,7 +7,7 @@ import torch
 import plnerf_amd as P
 
 FWD, TRAIN = 1186816, 3489024
-PEAK = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}
+PEAK = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "f16x3": 2500.0, "f16": 2500.0}
 ap = argparse.ArgumentParser()
 ap.add_argument("--rays", type=int, default=65536)
 ap.add_argument("--samples", type=int, default=192)
