@@ -23,6 +23,7 @@
 // bf16x3; 94 KB of LDS either way) and walks all 12 layers without leaving the CU.  For
 // training, each layer's activation tile is additionally copied LDS -> HBM as coalesced fp32
 // rows (the same plane layout as the fp32 mode), so the fp32-MFMA weight-gradient stage is shared.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -78,3 +79,10 @@ int bf16_dgrad(const void* packed, int ns, int f16, const float* g_raw, int n_ro
 
 }  // namespace impl
 }  // namespace plnerf
+
+#ifdef PLNERF_TRACE
+// profiling builds only (tools/trace_fwd.py): phase stamps of workgroup PLNERF_TRACE, bf16 element type
+extern "C" int plnerf_debug_trace(unsigned long long* out64) {
+    return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(plnerf_h16_bf16::g_trace), 64 * sizeof(unsigned long long));
+}
+#endif
