@@ -31,6 +31,8 @@ if ROOT not in sys.path:
 
 FWD_FLOP_PER_ROW = 1186816      # 2 x 593,408 MAC per network evaluation
 TRAIN_FLOP_PER_ROW = 3489024    # forward + wgrad + dgrad
+HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8 TB/s HBM3E
+FWD_TRAIN_BYTES_PER_ROW = 2596 * 4 + 12 + 16  # saved state (planes + masks) written, xyz read, raw written
 PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "f16x3": 2500.0, "f16": 2500.0}   # MI355X_MICROARCH.md, dense
 
 
@@ -166,6 +168,12 @@ def main():
         except Exception:
             traffic = None
         ach = rows_fine * FWD_FLOP_PER_ROW / (fwd_ms * 1e-3) / 1e12 if fwd_ms else None
+        # Which roofline binds the training forward: 1,186,816 FLOP against 10,412 algorithmic bytes per row
+        # (fp32 state planes 10,112 + relu masks 272 written, 12 read, 16 out) = 114 FLOP/B.  The ridge is
+        # 157.3 TF / 8 TB/s = 20 FLOP/B for fp32 MFMA (MFMA-bound) and 2.5 PF / 8 TB/s = 312 FLOP/B for the
+        # 16-bit MFMA modes (HBM-bound).
+        hbm_bound = a.precision != "fp32"
+        ach_gbs = rows_fine * FWD_TRAIN_BYTES_PER_ROW / (fwd_ms * 1e-3) / 1e9 if fwd_ms else None
         out = {
             "metric": "training rays/sec (coarse+fine, 64+128 samples)",
             "value": R * world * a.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": a.steps,
@@ -177,10 +185,14 @@ def main():
                        "global_rays": R * world, "precision": a.precision, "parallelism": f"dp{world}",
                        "final_loss": float(loss.detach())},
             "roofline": {
-                "bound": "mfma", "kernel": ("mlp_fwd_f32_kernel" if a.precision == "fp32" else "mlp_fwd_bf16_kernel") + " (fine network, fused PE+12-layer MLP forward)",
-                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": (ach / peak) if ach else None,
+                "bound": "hbm" if hbm_bound else "mfma",
+                "kernel": ("mlp_fwd_f32_kernel" if a.precision == "fp32" else "mlp_fwd_train_kernel") + " (fine network, fused PE+12-layer MLP forward, saves backward state)",
+                "achieved": ach_gbs if hbm_bound else ach, "peak": HBM_PEAK_GBS if hbm_bound else peak,
+                "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "frac": ((ach_gbs / HBM_PEAK_GBS) if hbm_bound else (ach / peak)) if ach else None,
                 "traffic": traffic, "launch_ms": fwd_ms, "rows_per_launch": rows_fine,
-                "flop_per_row": FWD_FLOP_PER_ROW,
+                "bytes_per_row": FWD_TRAIN_BYTES_PER_ROW, "flop_per_row": FWD_FLOP_PER_ROW,
+                "mfma_tflops": ach, "mfma_peak_tflops": peak,
                 # MFMA work actually issued: bf16x3 spends 3 MFMAs per algorithmic product
                 "mfma_issue_frac": ((ach * {"fp32": 1, "bf16x3": 3, "bf16": 1, "f16x3": 3, "f16": 1}[a.precision] / peak) if ach else None),
                 "mlp_bwd_launch_ms": bwd_ms,
