@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PLNERF_VERSION 100 /* major*10000 + minor*100 + patch */
+#define PLNERF_VERSION 200 /* major*10000 + minor*100 + patch */
 
 /* error codes */
 #define PLNERF_OK 0
@@ -81,13 +81,16 @@ int plnerf_quad_fwd(const float* raw, const float* z, const float* near, const f
 
 /* Backward of plnerf_quad_fwd with respect to `raw` (what autograd derives for the
  * reference at loss.backward(), run_plnerf.py:1300).  Upstream gradients g_rgb [R,3]
- * (required), g_depth [R], g_acc [R], g_weights [R,S+1|S] (each may be NULL = zero).
- * disp_map's gradient is folded into g_depth/g_acc by the caller.  g_raw [R,S,4]. */
+ * (required), g_depth [R], g_acc [R], g_weights [R,S+1|S], and -- linear mode only, for
+ * callers that differentiate through the sampler
+ * (depth_supervised_exps/run_nerf_sample_based_depth.py:923-934) -- g_tau, g_T [R,S+2]
+ * (each may be NULL = zero).  disp_map's gradient is folded into g_depth/g_acc by the
+ * caller.  g_raw [R,S,4]. */
 int plnerf_quad_bwd(const float* raw, const float* z, const float* near, const float* far,
                     const float* rays_d, const float* noise, int R, int S, int mode,
                     int color_mode, int white_bkgd, int farcolorfix, const float* g_rgb,
                     const float* g_depth, const float* g_acc, const float* g_weights,
-                    float* g_raw, plnerf_stream_t stream);
+                    const float* g_tau, const float* g_T, float* g_raw, plnerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Hierarchical samplers.  `u` holds the uniform draws: [R,N] when u_row_stride == N, or
@@ -112,6 +115,19 @@ int plnerf_sample_pl(const float* z, const float* weights, const float* tau, con
                      int R, int S, int N, float zero_tol, float epsilon, float* samples,
                      float* T_below, float* tau_below, float* bin_below, int64_t* inds,
                      plnerf_stream_t stream);
+
+/* Backward of plnerf_sample_pl with respect to tau and T (the sampler's only differentiable
+ * inputs: the interval search is piecewise constant in `weights`, and z / near / far are
+ * detached on the reference path).  This is what autograd derives for
+ * sample_pdf_reformulation_return_u (depth_supervised_exps/model/run_nerf_helpers.py:607-692
+ * with pw_linear_sample_increasing / _decreasing, :499-519) when `pred_hyp` carries the
+ * space-carving loss.  inds [R,N] is the index output of the forward call; g_samples [R,N].
+ * Outputs g_tau, g_T [R,S+2] are written (not accumulated); the per-knot sums run in
+ * sample order, so the result is deterministic. */
+int plnerf_sample_pl_bwd(const float* z, const float* tau, const float* T, const float* near,
+                         const float* far, const float* u, int u_row_stride, const int64_t* inds,
+                         const float* g_samples, int R, int S, int N, float zero_tol, float epsilon,
+                         float* g_tau, float* g_T, plnerf_stream_t stream);
 
 /* clamp(z_new, near, far) ++ z, sorted ascending per ray (run_plnerf.py:731-734).
  * z [R,S], z_new [R,N] -> out [R,S+N]; S+N <= 1024. */

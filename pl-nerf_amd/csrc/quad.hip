@@ -37,6 +37,8 @@ struct QuadArgs {
     const float* g_depth;
     const float* g_acc;
     const float* g_weights;
+    const float* g_tau;   // linear mode: upstream gradient of the returned tau [R,S+2] (or nullptr)
+    const float* g_T;     // linear mode: upstream gradient of the returned T   [R,S+2] (or nullptr)
     float* g_raw;
 };
 
@@ -176,6 +178,11 @@ __global__ __launch_bounds__(256) void quad_fwd_kernel(QuadArgs a) {
 // (division-free, so exact even when some e_k underflows to 0, like autograd's cumprod
 // backward).  X obeys the reverse recurrence X_k = G_{k+1}(1-e_{k+1}) + f_{k+1} X_{k+1},
 // evaluated as a wave scan over affine maps.
+// The returned transmittances T_m = prod_{j<m} f_j (m = 1..S+1) can carry their own upstream
+// gradient H_m (the depth-supervised variant differentiates through the sampler,
+// depth_supervised_exps/run_nerf_sample_based_depth.py:923-934): that adds T_k Y_k to dL/de_k with
+// Y_k = H_{k+1} + f_{k+1} Y_{k+1}, the same recurrence -- so H_m simply joins the additive term.
+// The returned tau[s+1] = relu(sigma_s + noise_s) passes its upstream gradient straight to sigma_s.
 template <int MODE>
 __global__ __launch_bounds__(256) void quad_bwd_kernel(QuadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -219,12 +226,15 @@ __global__ __launch_bounds__(256) void quad_bwd_kernel(QuadArgs a) {
                       gdep * elem_depth<MODE>(i, zk) + gacc;
             if (a.g_weights) G += a.g_weights[(size_t)ray * n + i];
             fv[i] = f;
-            av[i] = G * (1.0f - e);
+            av[i] = G * (1.0f - e) + ((MODE == PLNERF_MODE_LINEAR && a.g_T) ? a.g_T[(size_t)ray * (S + 2) + i] : 0.0f);
             wv[i] = (1.0f - e) * Ti;
             qv[i] = Ti;   // G_i and seg_i are recomputed in pass 2 (cheaper than two more LDS rows)
         }
     }
-    if (lane == 0) { fv[n] = 1.0f; av[n] = 0.0f; }
+    if (lane == 0) {
+        fv[n] = 1.0f;
+        av[n] = (MODE == PLNERF_MODE_LINEAR && a.g_T) ? a.g_T[(size_t)ray * (S + 2) + n] : 0.0f;
+    }
     __syncthreads();
 
     // pass 2: reverse affine scan.  Position p = n-1-i ascending <=> i descending;
@@ -266,6 +276,7 @@ __global__ __launch_bounds__(256) void quad_bwd_kernel(QuadArgs a) {
             float gtau, coef;
             if (MODE == PLNERF_MODE_LINEAR) {
                 gtau = -0.5f * (qv[s + 1] + qv[s]);
+                if (a.g_tau) gtau += a.g_tau[(size_t)ray * (S + 2) + s + 1];
                 if (a.color_mode == PLNERF_COLOR_MIDPOINT) {
                     coef = 0.5f * (wv[s] + wv[s + 1]);
                     if (s == 0) coef += 0.5f * wv[0];
@@ -340,15 +351,16 @@ extern "C" int plnerf_quad_bwd(const float* raw, const float* z, const float* ne
                                const float* rays_d, const float* noise, int R, int S, int mode,
                                int color_mode, int white_bkgd, int farcolorfix, const float* g_rgb,
                                const float* g_depth, const float* g_acc, const float* g_weights,
-                               float* g_raw, plnerf_stream_t stream) {
+                               const float* g_tau, const float* g_T, float* g_raw, plnerf_stream_t stream) {
     int rc = check_common(raw, z, near, far, rays_d, R, S, mode, color_mode);
     if (rc) return rc;
     if (R == 0) return PLNERF_OK;
     if (!g_rgb || !g_raw) return PLNERF_EINVAL;
+    if ((g_tau || g_T) && mode != PLNERF_MODE_LINEAR) return PLNERF_EINVAL;
     QuadArgs a{};
     a.raw = raw; a.z = z; a.near = near; a.far = far; a.rays_d = rays_d; a.noise = noise;
     a.R = R; a.S = S; a.color_mode = color_mode; a.white_bkgd = white_bkgd; a.farcolorfix = farcolorfix;
-    a.g_rgb = g_rgb; a.g_depth = g_depth; a.g_acc = g_acc; a.g_weights = g_weights; a.g_raw = g_raw;
+    a.g_rgb = g_rgb; a.g_depth = g_depth; a.g_acc = g_acc; a.g_weights = g_weights; a.g_tau = g_tau; a.g_T = g_T; a.g_raw = g_raw;
     a.lds_stride = ((5 * S + 4 + 4 * (S + 2)) + 3) & ~3;
     const size_t lds = (size_t)WAVES * a.lds_stride * sizeof(float);
     dim3 grid((R + WAVES - 1) / WAVES), block(WAVES * 64);

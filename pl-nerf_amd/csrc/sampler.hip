@@ -211,6 +211,118 @@ __global__ __launch_bounds__(256) void sample_pl_kernel(SamplePlArgs a) {
     }
 }
 
+
+struct SamplePlBwdArgs {
+    const float* z;
+    const float* tau;
+    const float* T;
+    const float* near;
+    const float* far;
+    const float* u;
+    int u_row_stride;
+    const int64_t* inds;
+    const float* g_samples;
+    int R, S, N;
+    int lds_stride;
+    float zero_tol, eps;
+    float* g_tau;
+    float* g_T;
+};
+
+// Gradient of invert_segment (above) with respect to (T0, tau0, tau1), following torch's rules for
+// the guards: max(eps, x) passes the gradient to x where x > eps, clamp(t, lo, hi) where
+// lo <= t <= hi.  Returns false when nothing flows (clamped).
+__device__ __forceinline__ bool invert_segment_grad(float s0, float s1, float T0, float tau0, float tau1,
+                                                    float u, float eps, bool rising, float g, float& g_T0,
+                                                    float& g_a, float& g_b) {
+    const float L = s1 - s0;
+    const float m0 = tmax(eps, T0);
+    const float ratio = (1.0f - u) / m0;
+    const float ln_term = -logf(tmax(eps, ratio));
+    const float span = tmax(eps, L);
+    const float disc = tau0 * tau0 + (rising ? (2.0f * (tau1 - tau0) * ln_term) / span
+                                             : -((2.0f * (tau0 - tau1) * ln_term) / span));
+    const float sq = sqrtf(tmax(eps, disc));
+    const float diff = rising ? tau1 - tau0 : tau0 - tau1;
+    const float den = tmax(eps, diff);
+    const float t_raw = rising ? (L * (-tau0 + sq)) / den : (L * (tau0 - sq)) / den;
+    g_T0 = g_a = g_b = 0.0f;
+    if (!(t_raw >= eps && t_raw <= L)) return false;
+    const float sgn = rising ? 1.0f : -1.0f;
+    const float g_sq = g * sgn * (L / den);
+    const float g_disc = disc > eps ? g_sq * (0.5f / sq) : 0.0f;
+    const float g_den = diff > eps ? -g * (t_raw / den) : 0.0f;      // d t_raw / d den = -t_raw / den
+    // direct terms, the denominator (d den / d tau0 = -sgn, d den / d tau1 = +sgn), the discriminant
+    g_a = g * (-sgn) * (L / den) - sgn * g_den + g_disc * (2.0f * tau0 - (2.0f * ln_term) / span);
+    g_b = sgn * g_den + g_disc * ((2.0f * ln_term) / span);
+    const float g_ln = g_disc * ((2.0f * (tau1 - tau0)) / span);
+    // ln_term = -log(max(eps, (1-u) / max(eps, T0)))
+    g_T0 = (ratio > eps && T0 > eps) ? g_ln / T0 : 0.0f;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void sample_pl_bwd_kernel(SamplePlBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int ray = blockIdx.x * WAVES + wave;
+    const bool live = ray < a.R;
+    if (!live) ray = a.R - 1;
+    const int S = a.S, K = a.S + 2, N = a.N;
+    float* knots = smem + wave * a.lds_stride;
+    float* tau = knots + K;
+    float* Tr = tau + K;
+    float* gT0 = Tr + K;          // per sample: gradient landing on T[below]
+    float* ga = gT0 + N;          //             on tau[below]
+    float* gb = ga + N;           //             on tau[above]
+    int* lo = reinterpret_cast<int*>(gb + N);   // below (above = min(below + 1, K - 1) unless clamped at 0)
+    int* hi = lo + N;
+    for (int j = lane; j < K; j += 64) {
+        tau[j] = a.tau[(size_t)ray * K + j];
+        Tr[j] = a.T[(size_t)ray * K + j];
+        float kn;
+        if (j == 0) kn = a.near[ray];
+        else if (j == K - 1) kn = a.far[ray];
+        else kn = a.z[(size_t)ray * S + j - 1];
+        knots[j] = kn;
+    }
+    __syncthreads();
+    const float* urow = a.u + (size_t)ray * a.u_row_stride;
+    const float zt = a.zero_tol, eps = a.eps;
+    for (int k = lane; k < N; k += 64) {
+        const size_t o = (size_t)ray * N + k;
+        const float u = urow[k];
+        const int ind = (int)a.inds[o];
+        const int below = ind - 1 > 0 ? ind - 1 : 0;
+        const int above = ind < K - 1 ? ind : K - 1;
+        const float s0 = knots[below], s1 = knots[above];
+        const int di = below < S ? below : S;
+        const float d = tau[di + 1] - tau[di];
+        float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
+        const float g = a.g_samples[o];
+        if (d >= zt || d <= -zt) {
+            const bool rising = d >= zt;
+            // (a NaN sample falls back to s_left in the forward: no gradient)
+            const float t = invert_segment(s0, s1, Tr[below], tau[below], tau[above], u, eps, rising);
+            if (t == t) invert_segment_grad(s0, s1, Tr[below], tau[below], tau[above], u, eps, rising, g, g0, g1, g2);
+        }
+        gT0[k] = g0; ga[k] = g1; gb[k] = g2;
+        lo[k] = below; hi[k] = above;
+    }
+    __syncthreads();
+    if (!live) return;
+    // per-knot sums in sample order (deterministic); all reads are LDS broadcasts
+    for (int j = lane; j < K; j += 64) {
+        float st = 0.0f, sT = 0.0f;
+        for (int k = 0; k < N; ++k) {
+            const int b = lo[k], t = hi[k];
+            if (b == j) { sT += gT0[k]; st += ga[k]; }
+            if (t == j) st += gb[k];
+        }
+        a.g_tau[(size_t)ray * K + j] = st;
+        a.g_T[(size_t)ray * K + j] = sT;
+    }
+}
+
 struct MergeArgs {
     const float* z;
     const float* z_new;
@@ -304,6 +416,27 @@ extern "C" int plnerf_sample_pl(const float* z, const float* weights, const floa
     int rc = set_lds((const void*)sample_pl_kernel, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(sample_pl_kernel, dim3((R + WAVES - 1) / WAVES), dim3(WAVES * 64), lds,
+                       (hipStream_t)stream, a);
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}
+
+
+extern "C" int plnerf_sample_pl_bwd(const float* z, const float* tau, const float* T, const float* near,
+                                    const float* far, const float* u, int u_row_stride, const int64_t* inds,
+                                    const float* g_samples, int R, int S, int N, float zero_tol, float epsilon,
+                                    float* g_tau, float* g_T, plnerf_stream_t stream) {
+    if (R < 0 || S < 1 || N < 1 || (u_row_stride != 0 && u_row_stride != N)) return PLNERF_EINVAL;
+    if (S > PLNERF_MAX_SAMPLES) return PLNERF_ERANGE;
+    if (R == 0) return PLNERF_OK;
+    if (!z || !tau || !T || !near || !far || !u || !inds || !g_samples || !g_tau || !g_T) return PLNERF_EINVAL;
+    SamplePlBwdArgs a{z, tau, T, near, far, u, u_row_stride, inds, g_samples, R, S, N, 0, zero_tol, epsilon,
+                      g_tau, g_T};
+    a.lds_stride = ((3 * (S + 2) + 5 * N) + 3) & ~3;
+    const size_t lds = (size_t)WAVES * a.lds_stride * sizeof(float);
+    int rc = set_lds((const void*)sample_pl_bwd_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sample_pl_bwd_kernel, dim3((R + WAVES - 1) / WAVES), dim3(WAVES * 64), lds,
                        (hipStream_t)stream, a);
     PLNERF_CHECK_LAUNCH();
     return PLNERF_OK;

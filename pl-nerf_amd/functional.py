@@ -43,9 +43,11 @@ KERNEL_TIMER = None
 class QuadratureFn(torch.autograd.Function):
     """raw2outputs (run_plnerf.py:553-624) -> plnerf_quad_fwd / plnerf_quad_bwd.
 
-    Differentiable with respect to `raw` through rgb_map, disp_map, acc_map, weights and
-    depth_map.  tau and T are returned for the sampler only and are not differentiable
-    (on the reference path their sole consumer is detached, run_plnerf.py:728)."""
+    Differentiable with respect to `raw` through every output.  On the reference's NVS path the
+    only consumer of tau and T (the sampler) is detached (run_plnerf.py:728) and they receive no
+    gradient; the depth-supervised variant differentiates through the sampler
+    (depth_supervised_exps/run_nerf_sample_based_depth.py:923-934), which is what their upstream
+    gradients are for."""
 
     @staticmethod
     def forward(ctx, raw, z, near, far, rays_d, noise, mode, color_mode, white_bkgd, farcolorfix):
@@ -74,7 +76,8 @@ class QuadratureFn(torch.autograd.Function):
         ctx.save_for_backward(raw_c, z_c, near_c, far_c, d_c, noise_c if noise_c is not None else torch.empty(0),
                               depth, acc)
         ctx.cfg = (mode, color_mode, bool(white_bkgd), bool(farcolorfix), noise_c is not None)
-        ctx.mark_non_differentiable(tau, T)
+        if not linear:
+            ctx.mark_non_differentiable(tau, T)
         ctx.set_materialize_grads(False)
         return rgb, disp, acc, w, depth, tau, T
 
@@ -98,13 +101,15 @@ class QuadratureFn(torch.autograd.Function):
             g_depth = gd if g_depth is None else g_depth + gd
             g_acc = ga if g_acc is None else g_acc + ga
         g_w = None if g_w is None else _f32c(g_w)
+        g_tau = None if (g_tau is None or mode != "linear") else _f32c(g_tau)
+        g_T = None if (g_T is None or mode != "linear") else _f32c(g_T)
         g_raw = torch.empty(R, S, 4, device=dev)
         if R > 0:
             L.check(L.lib().plnerf_quad_bwd(
               L.dptr(raw_c), L.dptr(z_c), L.dptr(near_c), L.dptr(far_c), L.dptr(d_c),
               L.dptr(noise_c) if has_noise else None, R, S, L.MODE[mode], L.COLOR[color_mode],
               int(white_bkgd), int(farcolorfix), L.dptr(g_rgb), L.dptr(g_depth), L.dptr(g_acc), L.dptr(g_w),
-              L.dptr(g_raw), L.stream()), "plnerf_quad_bwd")
+              L.dptr(g_tau), L.dptr(g_T), L.dptr(g_raw), L.stream()), "plnerf_quad_bwd")
         return g_raw, None, None, None, None, None, None, None, None, None
 
 
@@ -189,25 +194,60 @@ def sample_const(bins, weights, u, want_inds=False):
     return (out, inds) if want_inds else out
 
 
+class SamplePlFn(torch.autograd.Function):
+    """sample_pdf_reformulation (run_nerf_helpers.py:364-445) -> plnerf_sample_pl / plnerf_sample_pl_bwd.
+    Differentiable with respect to tau and T (what autograd derives for the reference: the interval
+    search is piecewise constant in the weights; z, near, far are detached upstream).  Outputs:
+    samples, T_below, tau_below, bin_below, inds -- only `samples` carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, z, weights, tau, T, near, far, u, zero_tol, eps):
+        R, S = z.shape
+        N = u.shape[-1]
+        dev = z.device
+        z_c, w_c, tau_c, T_c = _f32c(z), _f32c(weights), _f32c(tau), _f32c(T)
+        near_c, far_c, u_c = _f32c(near).reshape(-1), _f32c(far).reshape(-1), _f32c(u)
+        stride = N if u_c.dim() == 2 else 0
+        out = torch.empty(R, N, device=dev)
+        Tb = torch.empty(R, N, device=dev)
+        taub = torch.empty(R, N, device=dev)
+        binb = torch.empty(R, N, device=dev)
+        inds = torch.empty(R, N, device=dev, dtype=torch.int64)
+        if R > 0:
+            L.check(L.lib().plnerf_sample_pl(
+                L.dptr(z_c, "z_vals"), L.dptr(w_c, "weights"), L.dptr(tau_c, "tau"), L.dptr(T_c, "T"),
+                L.dptr(near_c, "near"), L.dptr(far_c, "far"), L.dptr(u_c, "u"), stride, R, S, N, float(zero_tol),
+                float(eps), L.dptr(out), L.dptr(Tb), L.dptr(taub), L.dptr(binb),
+                L.dptr(inds, "inds", torch.int64), L.stream()), "plnerf_sample_pl")
+        ctx.save_for_backward(z_c, tau_c, T_c, near_c, far_c, u_c, inds)
+        ctx.cfg = (stride, float(zero_tol), float(eps))
+        ctx.mark_non_differentiable(Tb, taub, binb, inds)
+        ctx.set_materialize_grads(False)
+        return out, Tb, taub, binb, inds
+
+    @staticmethod
+    def backward(ctx, g_samples, g_Tb, g_taub, g_binb, g_inds):
+        if g_samples is None:
+            return (None,) * 9
+        z_c, tau_c, T_c, near_c, far_c, u_c, inds = ctx.saved_tensors
+        stride, zero_tol, eps = ctx.cfg
+        R, S = z_c.shape
+        N = inds.shape[-1]
+        g_c = _f32c(g_samples)
+        g_tau = torch.empty(R, S + 2, device=z_c.device)
+        g_T = torch.empty(R, S + 2, device=z_c.device)
+        if R > 0:
+            L.check(L.lib().plnerf_sample_pl_bwd(
+                L.dptr(z_c), L.dptr(tau_c), L.dptr(T_c), L.dptr(near_c), L.dptr(far_c), L.dptr(u_c), stride,
+                L.dptr(inds, "inds", torch.int64), L.dptr(g_c), R, S, N, zero_tol, eps, L.dptr(g_tau), L.dptr(g_T),
+                L.stream()), "plnerf_sample_pl_bwd")
+        return None, None, g_tau, g_T, None, None, None, None, None
+
+
 def sample_pl(z, weights, tau, T, near, far, u, zero_tol, eps, want_extras=False, want_inds=False):
-    """plnerf_sample_pl; returns samples or (samples, T_below, tau_below, bin_below[, inds])."""
-    R, S = z.shape
-    N = u.shape[-1]
-    dev = z.device
-    z_c, w_c, tau_c, T_c = _f32c(z), _f32c(weights), _f32c(tau), _f32c(T)
-    near_c, far_c, u_c = _f32c(near).reshape(-1), _f32c(far).reshape(-1), _f32c(u)
-    stride = N if u_c.dim() == 2 else 0
-    out = torch.empty(R, N, device=dev)
-    Tb = torch.empty(R, N, device=dev) if want_extras else None
-    taub = torch.empty(R, N, device=dev) if want_extras else None
-    binb = torch.empty(R, N, device=dev) if want_extras else None
-    inds = torch.empty(R, N, device=dev, dtype=torch.int64) if want_inds else None
-    if R > 0:
-        L.check(L.lib().plnerf_sample_pl(
-            L.dptr(z_c, "z_vals"), L.dptr(w_c, "weights"), L.dptr(tau_c, "tau"), L.dptr(T_c, "T"),
-            L.dptr(near_c, "near"), L.dptr(far_c, "far"), L.dptr(u_c, "u"), stride, R, S, N, float(zero_tol),
-            float(eps), L.dptr(out), L.dptr(Tb), L.dptr(taub), L.dptr(binb),
-            L.dptr(inds, "inds", torch.int64), L.stream()), "plnerf_sample_pl")
+    """plnerf_sample_pl; returns samples or (samples, T_below, tau_below, bin_below[, inds]).
+    `samples` is differentiable with respect to tau and T (SamplePlFn)."""
+    out, Tb, taub, binb, inds = SamplePlFn.apply(z, weights, tau, T, near, far, u, zero_tol, eps)
     if want_extras:
         return (out, Tb, taub, binb, inds) if want_inds else (out, Tb, taub, binb)
     return (out, inds) if want_inds else out

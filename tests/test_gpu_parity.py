@@ -217,6 +217,66 @@ def test_sample_pl_vs_oracle_large_and_det(P):
     assert_close(out, ref, what="sample_pl det")
 
 
+def test_sampler_backward_vs_oracle_autograd(P):
+    """The depth-supervised variant back-propagates through sample_pdf_reformulation
+    (depth_supervised_exps/run_nerf_sample_based_depth.py:923-934): d samples / d (tau, T) from
+    plnerf_sample_pl_bwd, and d (tau, T) / d raw joined into plnerf_quad_bwd, against torch autograd
+    on the oracle's restatement of the same functions.
+
+    The closed form is ill-conditioned in fp32 (the discriminant cancels; see the forward test): the
+    oracle's own fp32 autograd differs from its fp64 autograd by ~1e-3 of max|g| on g_tau.  The
+    yardstick is therefore the fp64 oracle, and the bound is the fp32 oracle's own distance from it
+    (x2, + 1e-5)."""
+    from plnerf_amd import functional as Fn
+
+    def rel(a, b):
+        return float((a.detach().cpu().double() - b).abs().max()) / (float(b.abs().max()) + 1e-300)
+
+    for (R, S, N, seed) in [(64, 64, 64, 3), (33, 192, 128, 4), (16, 21, 77, 5)]:
+        raw, z, near, far, d, _ = quad_case(R, S, seed)
+        gen = torch.Generator().manual_seed(seed)
+        u = torch.rand(R, N, generator=gen) * 0.999
+        cot = torch.randn(R, N, generator=gen)
+        cot_rgb = torch.randn(R, 3, generator=gen)
+        with torch.no_grad():
+            _, _, _, w, _, tau, Tr = orc.raw2outputs(raw, z, near, far, d, "linear", "midpoint")
+
+        # stage 1: sampler alone, gradients with respect to tau and T
+        def sampler_grads(dt):
+            tau_r, T_r = tau.to(dt).clone().requires_grad_(True), Tr.to(dt).clone().requires_grad_(True)
+            s_ref = orc.sample_pdf_reformulation(z.to(dt), w.to(dt), tau_r, T_r, near.to(dt), far.to(dt), N,
+                                                 u=u.to(dt))[0]
+            (s_ref * cot.to(dt)).sum().backward()
+            return tau_r.grad, T_r.grad
+        ref64, ref32 = sampler_grads(torch.float64), sampler_grads(torch.float32)
+        tau_h, T_h = g(tau).requires_grad_(True), g(Tr).requires_grad_(True)
+        s_hip = Fn.sample_pl(g(z), g(w), tau_h, T_h, g(near), g(far), g(u), 1e-4, 1e-3)
+        (s_hip * g(cot)).sum().backward()
+        for name, a, b64, b32 in (("g_tau", tau_h.grad, ref64[0], ref32[0]), ("g_T", T_h.grad, ref64[1], ref32[1])):
+            e_hip, e_orc = rel(a, b64), rel(b32, b64)
+            print(f"sampler bwd R={R} S={S} N={N}: {name} err vs fp64 oracle: HIP {e_hip:.3e}, fp32 oracle {e_orc:.3e}")
+            assert e_hip <= 2 * e_orc + 1e-5, (name, e_hip, e_orc)
+
+        # stage 2: raw -> (rgb, tau, T) -> samples, one loss through both the image and the sampler
+        def raw_grad(dt):
+            raw_r = raw.to(dt).clone().requires_grad_(True)
+            out = orc.raw2outputs(raw_r, z.to(dt), near.to(dt), far.to(dt), d.to(dt), "linear", "midpoint",
+                                  white_bkgd=True)
+            # interval indices from the fp32 weights, so every precision inverts the same intervals
+            s_ref = orc.sample_pdf_reformulation(z.to(dt), w.to(dt), out[5], out[6], near.to(dt), far.to(dt), N,
+                                                 u=u.to(dt))[0]
+            ((s_ref * cot.to(dt)).sum() + (out[0] * cot_rgb.to(dt)).sum()).backward()
+            return raw_r.grad
+        r64, r32 = raw_grad(torch.float64), raw_grad(torch.float32)
+        raw_h = g(raw).requires_grad_(True)
+        outh = P.raw2outputs(raw_h, g(z), g(near), g(far), g(d), "linear", "midpoint", white_bkgd=True)
+        s_hip = Fn.sample_pl(g(z), g(w), outh[5], outh[6], g(near), g(far), g(u), 1e-4, 1e-3)
+        ((s_hip * g(cot)).sum() + (outh[0] * g(cot_rgb)).sum()).backward()
+        e_hip, e_orc = rel(raw_h.grad, r64), rel(r32, r64)
+        print(f"raw grad through sampler + image R={R} S={S}: err vs fp64 oracle: HIP {e_hip:.3e}, fp32 oracle {e_orc:.3e}")
+        assert e_hip <= 2 * e_orc + 1e-5, (e_hip, e_orc)
+
+
 def test_merge_sort(P):
     from plnerf_amd import functional as Fn
     for R, S, N in ((513, 64, 128), (64, 128, 64), (3, 1, 1), (7, 500, 524)):
