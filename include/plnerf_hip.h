@@ -52,8 +52,13 @@ extern "C" {
 #define PLNERF_MAX_SAMPLES 1022 /* S+2 knots must fit the per-wave LDS row */
 
 /* Network geometry this library is specialised for: the reference defaults
- * (run_plnerf.py:784-825: netdepth 8, netwidth 256, skips [4], multires 10,
- * multires_views 4, use_viewdirs).  595,844 parameters per network. */
+ * (run_plnerf.py:784-825: netdepth 8, netwidth 256, skips [4], use_viewdirs; multires 10,
+ * multires_views 4 -> input_ch 63, input_ch_views 27; 595,844 parameters per network).
+ * The two input widths are run-time arguments (input_ch <= 64, input_ch_views <= 32) so
+ * that the depth-supervised variant's network (multires 9, multires_views 0 -> 57 / 3,
+ * depth_supervised_exps/run_nerf_sample_based_depth.py:550-561, 1306-1309) runs on the
+ * same kernels; the in-kernel positional encoding exists for 63 / 27 only, other widths
+ * pass the encoding in (`embedded`). */
 #define PLNERF_N_PARAM_TENSORS 24
 #define PLNERF_N_PARAMS 595844
 
@@ -149,8 +154,8 @@ int plnerf_merge_sort(const float* z, const float* z_new, const float* near, con
 size_t plnerf_mlp_packed_bytes(int precision);
 /* Re-layout the 24 parameter tensors into MFMA fragment order (call after every
  * optimizer step; cheap: one pass over 2.4 MB). */
-int plnerf_mlp_pack_weights(const float* const* params, int precision, void* packed,
-                            plnerf_stream_t stream);
+int plnerf_mlp_pack_weights(const float* const* params, int precision, int input_ch,
+                            int input_ch_views, void* packed, plnerf_stream_t stream);
 
 /* Bytes of forward state saved for the backward pass (activations of every layer) and of
  * backward scratch (per-layer pre-activation gradients, split-K partial sums). */
@@ -159,12 +164,12 @@ size_t plnerf_mlp_bwd_workspace_bytes(int n_rows, int precision);
 
 /* Forward.  Either (pts [n_rows,3] AND viewdirs [n_rows/samples_per_ray, 3]) with
  * embedded == NULL -- the encoding is computed in the kernel prologue, once per sample
- * for xyz and from the per-ray direction -- or embedded [n_rows, 90] (a caller-supplied
- * encoding; NeRF.forward's own signature).  saved == NULL for inference.
- * raw_out [n_rows,4]. */
+ * for xyz and from the per-ray direction (input_ch 63 / input_ch_views 27 only) -- or
+ * embedded [n_rows, input_ch + input_ch_views] (a caller-supplied encoding; NeRF.forward's
+ * own signature).  saved == NULL for inference.  raw_out [n_rows,4]. */
 int plnerf_mlp_fwd(const void* packed, int precision, const float* pts, const float* viewdirs,
-                   const float* embedded, int n_rows, int samples_per_ray, float* raw_out,
-                   void* saved, plnerf_stream_t stream);
+                   const float* embedded, int input_ch, int input_ch_views, int n_rows,
+                   int samples_per_ray, float* raw_out, void* saved, plnerf_stream_t stream);
 
 /* Backward: g_raw [n_rows,4] -> gradients of all 24 parameter tensors, written (not
  * accumulated) to grads[24] (device pointers, same shapes as params).  Needs the `saved`
@@ -172,9 +177,9 @@ int plnerf_mlp_fwd(const void* packed, int precision, const float* pts, const fl
  * plnerf_mlp_bwd_workspace_bytes().  Inputs (pts / viewdirs) receive no gradient, as on
  * the reference path (they do not depend on parameters; z_samples is detached,
  * run_plnerf.py:728). */
-int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, int n_rows,
-                   const void* saved, void* workspace, float* const* grads,
-                   plnerf_stream_t stream);
+int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, int input_ch,
+                   int input_ch_views, int n_rows, const void* saved, void* workspace,
+                   float* const* grads, plnerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused Adam step over a flat parameter buffer (torch.optim.Adam semantics as used at

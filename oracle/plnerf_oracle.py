@@ -468,3 +468,185 @@ def synthetic_blender_rays(n_rays, seed=0, near=2.0, far=6.0, H=800, W=800, thet
     o, d = o.reshape(-1, 3)[pix], d.reshape(-1, 3)[pix]
     target = torch.from_numpy(rng.random((n_rays, 3), dtype=np.float32))
     return pack_ray_batch(o, d, near, far), target
+
+
+# ============================================================================
+# Depth-supervised variant of the path.  Restates
+# depth_supervised_exps/run_nerf_sample_based_depth.py and
+# depth_supervised_exps/model/run_nerf_helpers.py; pinned by fixture G8.
+# ============================================================================
+DEPTH_XYZ_FREQS = 9     # --multires default (run_nerf_sample_based_depth.py:1306)
+DEPTH_DIR_FREQS = 0     # --multires_views default (:1308): identity only -> 3 channels
+
+
+def param_shapes_depth(xyz_freqs=DEPTH_XYZ_FREQS, dir_freqs=DEPTH_DIR_FREQS):
+    """Same module tree as param_shapes() with input_ch = 3 + 6*9 = 57 and input_ch_views = 3
+    (model/run_nerf_helpers.py:164-179 with the depth script's default flags)."""
+    xyz, dirc = 3 + 6 * xyz_freqs, 3 + 6 * dir_freqs
+    out = []
+    for name, shape in param_shapes():
+        if name == "pts_linears.0.weight":
+            shape = (WIDTH, xyz)
+        elif name == f"pts_linears.{SKIP_AFTER + 1}.weight":
+            shape = (WIDTH, WIDTH + xyz)
+        elif name == "views_linears.0.weight":
+            shape = (WIDTH // 2, WIDTH + dirc)
+        out.append((name, shape))
+    return out
+
+
+def closed_form_state_dict_depth(seed=0, sharpen=False):
+    """closed_form_state_dict's sine hash on the depth variant's shapes."""
+    shapes = param_shapes_depth()
+    table = dict(shapes)
+    sd = {}
+    for li, (name, shape) in enumerate(shapes):
+        fan_in = shape[1] if len(shape) == 2 else table[name.replace("bias", "weight")][1]
+        bound = 1.0 / math.sqrt(fan_in)
+        idx = np.arange(int(np.prod(shape)), dtype=np.float64)
+        h = np.sin(12.9898 * (idx + 1.0) + 78.233 * (li + 1.0) + 37.719 * (seed + 1.0)) * 43758.5453
+        frac = h - np.floor(h)
+        sd[name] = torch.from_numpy(((2.0 * frac - 1.0) * bound).astype(np.float32).reshape(shape))
+    if sharpen:
+        sd["alpha_linear.weight"] = sd["alpha_linear.weight"] * 30.0
+        sd["alpha_linear.bias"] = sd["alpha_linear.bias"] + 0.5
+    return sd
+
+
+def positional_encoding_pi(x, n_freqs):
+    """model/run_nerf_helpers.py:100-130: p_fn(x * np.pi * freq), i.e. (x * pi) * 2^k in x's dtype."""
+    blocks = [x]
+    for k in range(n_freqs):
+        xs = x * np.pi * float(2 ** k)
+        blocks.append(torch.sin(xs))
+        blocks.append(torch.cos(xs))
+    return torch.cat(blocks, dim=-1)
+
+
+def nerf_mlp_depth(sd, embedded):
+    """model/run_nerf_helpers.py:181-205: the same trunk, input widths read off the weights, and
+    softplus(beta=10) on the density channel (:200)."""
+    xyz_ch = sd["pts_linears.0.weight"].shape[1]
+    enc_xyz, enc_dir = embedded[..., :xyz_ch], embedded[..., xyz_ch:]
+    h = enc_xyz
+    for i in range(DEPTH):
+        h = F.relu(F.linear(h, sd[f"pts_linears.{i}.weight"], sd[f"pts_linears.{i}.bias"]))
+        if i == SKIP_AFTER:
+            h = torch.cat([enc_xyz, h], dim=-1)
+    alpha = F.linear(h, sd["alpha_linear.weight"], sd["alpha_linear.bias"])
+    feat = F.linear(h, sd["feature_linear.weight"], sd["feature_linear.bias"])
+    hv = F.relu(F.linear(torch.cat([feat, enc_dir], dim=-1), sd["views_linears.0.weight"],
+                         sd["views_linears.0.bias"]))
+    rgb = F.linear(hv, sd["rgb_linear.weight"], sd["rgb_linear.bias"])
+    return torch.cat([rgb, F.softplus(alpha, beta=10)], dim=-1)
+
+
+def query_network_depth(sd, pts, viewdirs, bb_center=0.0, bb_scale=1.0, xyz_freqs=DEPTH_XYZ_FREQS,
+                        dir_freqs=DEPTH_DIR_FREQS, netchunk=65536):
+    """run_nerf_sample_based_depth.py:52-68 (embedded_cam empty, its default)."""
+    R, S = pts.shape[0], pts.shape[1]
+    flat = (pts.reshape(-1, 3) - bb_center) * bb_scale
+    emb = positional_encoding_pi(flat, xyz_freqs)
+    dirs = viewdirs[:, None, :].expand(R, S, 3).reshape(-1, 3)
+    emb = torch.cat([emb, positional_encoding_pi(dirs, dir_freqs)], dim=-1)
+    outs = [nerf_mlp_depth(sd, emb[i:i + netchunk]) for i in range(0, emb.shape[0], netchunk)]
+    return torch.cat(outs, 0).reshape(R, S, 4)
+
+
+def _draw_u_depth(R, n, det, pytest, load_u):
+    """model/run_nerf_helpers.py:619-638."""
+    if load_u is not None:
+        return load_u
+    if det:
+        u = torch.linspace(0.0, 1.0, steps=n).expand(R, n)
+    else:
+        u = torch.rand(R, n)
+    if pytest:
+        np.random.seed(0)
+        if det:
+            u = torch.Tensor(np.broadcast_to(np.linspace(0.0, 1.0, n), [R, n]).copy())
+        else:
+            u = torch.Tensor(np.random.rand(R, n))
+    return u
+
+
+def render_rays_depth(ray_batch, sd_coarse, sd_fine, N_samples, mode, color_mode, perturb=0.0,
+                      N_importance=0, white_bkgd=False, raw_noise_std=0.0, pytest=False, cached_u=None,
+                      bb_center=0.0, bb_scale=1.0, t_rand=None, u_fine=None):
+    """run_nerf_sample_based_depth.py:792-958, mode 'linear' (the PL-NeRF configuration), is_joint False.
+    `pred_hyp` stays attached to the final weights' tau and T (:923-934).  t_rand / u_fine inject the
+    stratified draw and the importance draw for HIP-vs-oracle comparisons."""
+    if mode != "linear":
+        raise ValueError("the restatement covers mode='linear'")
+    rays_o, rays_d = ray_batch[:, 0:3], ray_batch[:, 3:6]
+    viewdirs = ray_batch[:, 8:11]
+    near, far = ray_batch[:, 6:7], ray_batch[:, 7:8]
+    z = stratified_z(near, far, N_samples, False, perturb, pytest, t_rand)
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
+    raw = query_network_depth(sd_coarse, pts, viewdirs, bb_center, bb_scale)
+    rgb, disp, acc, w, depth, tau, T = raw2outputs(raw, z, near, far, rays_d, mode, color_mode, raw_noise_std,
+                                                   pytest, white_bkgd)
+    R = ray_batch.shape[0]
+    ret = {}
+    if N_importance == 0:
+        u = _draw_u_depth(R, N_samples, perturb == 0.0, pytest, None)
+        hyp = sample_pdf_reformulation(z, w, tau, T, near, far, N_samples, u=u)[0]
+    else:
+        coarse = (rgb, disp, acc, depth, z, w)
+        z_new = sample_pdf_reformulation(z, w, tau, T, near, far, N_importance, det=(perturb == 0.0),
+                                         pytest=pytest, u=u_fine)[0].detach()
+        z_new = torch.clamp(z_new, near, far)
+        z, _ = torch.sort(torch.cat([z, z_new], -1), -1)
+        pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
+        raw = query_network_depth(sd_fine if sd_fine is not None else sd_coarse, pts, viewdirs, bb_center, bb_scale)
+        rgb, disp, acc, w, depth, tau, T = raw2outputs(raw, z, near, far, rays_d, mode, color_mode, raw_noise_std,
+                                                       pytest, white_bkgd)
+        u = _draw_u_depth(R, N_importance, perturb == 0.0, pytest, cached_u)
+        hyp = sample_pdf_reformulation(z, w, tau, T, near, far, N_importance, u=u)[0]
+        ret.update({"rgb0": coarse[0], "disp0": coarse[1], "acc0": coarse[2], "depth0": coarse[3],
+                    "z_vals0": coarse[4], "weights0": coarse[5],
+                    "z_std": torch.std(hyp, dim=-1, unbiased=False)})
+    ret.update({"rgb_map": rgb, "disp_map": disp, "acc_map": acc, "depth_map": depth, "z_vals": z,
+                "weights": w[..., 1:], "pred_hyp": hyp, "u": u, "raw": raw})
+    return ret
+
+
+def compute_space_carving_loss(pred_depth, target_hypothesis, is_joint=False, mask=None, norm_p=2, threshold=0.0):
+    """model/run_nerf_helpers.py:52-86."""
+    n_points = pred_depth.shape[1]
+    target = target_hypothesis.repeat(1, 1, n_points) if target_hypothesis.shape[-1] == 1 else target_hypothesis
+    dist = torch.norm(pred_depth.unsqueeze(-1) - target.unsqueeze(-1), p=norm_p, dim=-1)
+    if mask is not None:
+        dist = dist * mask.unsqueeze(0).repeat(dist.shape[0], 1).unsqueeze(-1)
+    if threshold > 0:
+        dist = torch.where(dist < threshold, torch.zeros(()), dist)
+    if is_joint:
+        return torch.mean(torch.min(torch.mean(dist, axis=1), axis=0)[0], axis=-1)
+    return torch.mean(torch.mean(torch.min(dist, dim=0)[0], dim=-1))
+
+
+def depth_train_step(sd_coarse, sd_fine, ray_batch, target_s, target_h, render_kwargs, space_carving_weight=0.007,
+                     lr=5e-4, mask=None, adam_state=None):
+    """run_nerf_sample_based_depth.py:1126-1157: loss = mse(rgb) + w * space_carving(pred_hyp, target_h) +
+    mse(rgb0); clip_grad_value_(0.1); ONE Adam over both networks.  Parameters are updated in place; returns
+    (loss, space_carving_loss, grads_coarse, grads_fine) with the gradients BEFORE clipping."""
+    params = [p.requires_grad_(True) for p in list(sd_coarse.values()) + list(sd_fine.values())]
+    if adam_state is None or "opt" not in adam_state:
+        opt = torch.optim.Adam(params, lr=lr, betas=(0.9, 0.999))
+        if adam_state is not None:
+            adam_state["opt"] = opt
+    else:
+        opt = adam_state["opt"]
+    ret = render_rays_depth(ray_batch, sd_coarse, sd_fine, **render_kwargs)
+    opt.zero_grad()
+    loss = torch.mean((ret["rgb_map"] - target_s) ** 2)
+    sc = compute_space_carving_loss(ret["pred_hyp"], target_h, mask=mask)
+    loss = loss + space_carving_weight * sc
+    if "rgb0" in ret:
+        loss = loss + torch.mean((ret["rgb0"] - target_s) ** 2)
+    loss.backward()
+    g_c = {k: (v.grad.clone() if v.grad is not None else torch.zeros_like(v)) for k, v in sd_coarse.items()}
+    g_f = {k: (v.grad.clone() if v.grad is not None else torch.zeros_like(v)) for k, v in sd_fine.items()}
+    torch.nn.utils.clip_grad_value_(params, 0.1)
+    opt.step()
+    return loss.detach(), sc.detach(), g_c, g_f

@@ -9,6 +9,7 @@ from . import _lib
 from .nerf import NeRF, Embedder, get_embedder
 from .rays import get_rays, get_rays_np, ndc_rays
 from .train import TrainStep, checkpoint_path, save_checkpoint, select_rays
+from . import depth   # depth-supervised variant of the path (depth_supervised_exps/)
 from .render import (batchify, batchify_rays, compute_weights, compute_weights_piecewise_linear, create_nerf,
                      raw2outputs, render, render_rays, run_network, sample_pdf, sample_pdf_reformulation)
 
@@ -27,5 +28,5 @@ __all__ = [
     "NeRF", "Embedder", "get_embedder", "get_rays", "get_rays_np", "ndc_rays", "batchify", "batchify_rays",
     "compute_weights", "compute_weights_piecewise_linear", "create_nerf", "raw2outputs", "render",
     "render_rays", "run_network", "sample_pdf", "sample_pdf_reformulation", "img2mse", "library_path",
-    "library_version", "TrainStep", "save_checkpoint", "checkpoint_path", "select_rays",
+    "library_version", "depth", "TrainStep", "save_checkpoint", "checkpoint_path", "select_rays",
 ]

@@ -14,6 +14,10 @@ inline int ns_of(int precision) {
 }
 inline int f16_of(int precision) { return precision == PLNERF_PREC_F16X3 || precision == PLNERF_PREC_F16; }
 inline bool known(int precision) { return precision >= PLNERF_PREC_FP32 && precision <= PLNERF_PREC_F16; }
+// network input widths the padded GEMMs can hold (the reference's defaults are 63 / 27)
+inline bool geometry_ok(int input_ch, int input_ch_views) {
+    return input_ch >= 1 && input_ch <= lay::PE_K && input_ch_views >= 1 && input_ch_views <= lay::DPE_K;
+}
 }  // namespace
 
 extern "C" size_t plnerf_mlp_packed_bytes(int precision) {
@@ -22,14 +26,15 @@ extern "C" size_t plnerf_mlp_packed_bytes(int precision) {
     return 0;
 }
 
-extern "C" int plnerf_mlp_pack_weights(const float* const* params, int precision, void* packed,
-                                       plnerf_stream_t stream) {
-    if (!params || !packed) return PLNERF_EINVAL;
+extern "C" int plnerf_mlp_pack_weights(const float* const* params, int precision, int input_ch,
+                                       int input_ch_views, void* packed, plnerf_stream_t stream) {
+    if (!params || !packed || !geometry_ok(input_ch, input_ch_views)) return PLNERF_EINVAL;
     if (!known(precision)) return PLNERF_ENOSYS;
     for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i)
         if (!params[i]) return PLNERF_EINVAL;
-    if (precision == PLNERF_PREC_FP32) return impl::f32_pack(params, packed, (hipStream_t)stream);
-    return impl::bf16_pack(params, ns_of(precision), f16_of(precision), packed, (hipStream_t)stream);
+    if (precision == PLNERF_PREC_FP32) return impl::f32_pack(params, input_ch, input_ch_views, packed, (hipStream_t)stream);
+    return impl::bf16_pack(params, input_ch, input_ch_views, ns_of(precision), f16_of(precision), packed,
+                           (hipStream_t)stream);
 }
 
 extern "C" size_t plnerf_mlp_saved_bytes(int n_rows, int precision) {
@@ -44,25 +49,28 @@ extern "C" size_t plnerf_mlp_bwd_workspace_bytes(int n_rows, int precision) {
 }
 
 extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pts, const float* viewdirs,
-                              const float* embedded, int n_rows, int samples_per_ray, float* raw_out,
-                              void* saved, plnerf_stream_t stream) {
+                              const float* embedded, int input_ch, int input_ch_views, int n_rows,
+                              int samples_per_ray, float* raw_out, void* saved, plnerf_stream_t stream) {
     if (!known(precision)) return PLNERF_ENOSYS;
-    if (n_rows < 0) return PLNERF_EINVAL;
+    if (n_rows < 0 || !geometry_ok(input_ch, input_ch_views)) return PLNERF_EINVAL;
+    // the in-kernel encoding is the reference's default one: 3 + 6*10 and 3 + 6*4 channels
+    if (!embedded && (input_ch != lay::XYZ_CH || input_ch_views != lay::DIR_CH)) return PLNERF_EINVAL;
     if (n_rows == 0) return PLNERF_OK;
     if (!packed || !raw_out) return PLNERF_EINVAL;
     if (!embedded && (!pts || !viewdirs || samples_per_ray < 1)) return PLNERF_EINVAL;
     if (precision == PLNERF_PREC_FP32)
-        return impl::f32_fwd(packed, pts, viewdirs, embedded, n_rows, samples_per_ray, raw_out, saved,
-                             (hipStream_t)stream);
-    return impl::bf16_fwd(packed, ns_of(precision), f16_of(precision), pts, viewdirs, embedded, n_rows, samples_per_ray, raw_out,
-                          saved, (hipStream_t)stream);
+        return impl::f32_fwd(packed, pts, viewdirs, embedded, input_ch, input_ch_views, n_rows, samples_per_ray,
+                             raw_out, saved, (hipStream_t)stream);
+    return impl::bf16_fwd(packed, ns_of(precision), f16_of(precision), pts, viewdirs, embedded, input_ch,
+                          input_ch_views, n_rows, samples_per_ray, raw_out, saved, (hipStream_t)stream);
 }
 
-extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, int n_rows,
-                              const void* saved, void* workspace, float* const* grads,
-                              plnerf_stream_t stream) {
+extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, int input_ch,
+                              int input_ch_views, int n_rows, const void* saved, void* workspace,
+                              float* const* grads, plnerf_stream_t stream) {
     if (!known(precision)) return PLNERF_ENOSYS;
     if (!packed || !g_raw || !saved || !workspace || !grads || n_rows < 1) return PLNERF_EINVAL;
+    if (!geometry_ok(input_ch, input_ch_views)) return PLNERF_EINVAL;
     for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i)
         if (!grads[i]) return PLNERF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -72,5 +80,6 @@ extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_
     else rc = impl::bf16_dgrad(packed, ns_of(precision), f16_of(precision), g_raw, n_rows, (const float*)saved, dz, st);
     if (rc) return rc;
     // weight gradients over the fp32 planes; the big 256x256 jobs use the mode's MFMA type
-    return impl::f32_wgrad(g_raw, n_rows, (const float*)saved, dz, grads, ns_of(precision), 0, st);
+    return impl::f32_wgrad(g_raw, n_rows, (const float*)saved, dz, grads, input_ch, input_ch_views, ns_of(precision), 0,
+                           st);
 }

@@ -56,19 +56,21 @@ namespace impl {
 
 size_t bf16_packed_bytes(int ns) { return plnerf_h16_bf16::h16_packed_bytes(ns); }
 
-int bf16_pack(const float* const* params, int ns, int f16, void* packed, hipStream_t st) {
+int bf16_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, int f16, void* packed, hipStream_t st) {
     // The f16 modes are hybrids: IEEE-half operands in the forward GEMMs (values are O(1), the 11-bit
     // mantissa buys 8x tighter products), bf16 operands in the backward GEMMs (pre-activation
     // gradients span the whole fp32 exponent range and would flush to zero in half precision).
-    if (!f16) return plnerf_h16_bf16::h16_pack(params, ns, 3, packed, st);
-    const int rc = plnerf_h16_f16::h16_pack(params, ns, 1, packed, st);
-    return rc ? rc : plnerf_h16_bf16::h16_pack(params, ns, 2, packed, st);
+    if (!f16) return plnerf_h16_bf16::h16_pack(params, xyz_ch, dir_ch, ns, 3, packed, st);
+    const int rc = plnerf_h16_f16::h16_pack(params, xyz_ch, dir_ch, ns, 1, packed, st);
+    return rc ? rc : plnerf_h16_bf16::h16_pack(params, xyz_ch, dir_ch, ns, 2, packed, st);
 }
 
 int bf16_fwd(const void* packed, int ns, int f16, const float* pts, const float* viewdirs, const float* embedded,
-             int n_rows, int samples_per_ray, float* raw_out, void* saved, hipStream_t st) {
-    return f16 ? plnerf_h16_f16::h16_fwd(packed, ns, pts, viewdirs, embedded, n_rows, samples_per_ray, raw_out, saved, st)
-               : plnerf_h16_bf16::h16_fwd(packed, ns, pts, viewdirs, embedded, n_rows, samples_per_ray, raw_out, saved, st);
+             int xyz_ch, int dir_ch, int n_rows, int samples_per_ray, float* raw_out, void* saved, hipStream_t st) {
+    return f16 ? plnerf_h16_f16::h16_fwd(packed, ns, pts, viewdirs, embedded, xyz_ch, dir_ch, n_rows, samples_per_ray,
+                                         raw_out, saved, st)
+               : plnerf_h16_bf16::h16_fwd(packed, ns, pts, viewdirs, embedded, xyz_ch, dir_ch, n_rows, samples_per_ray,
+                                          raw_out, saved, st);
 }
 
 int bf16_dgrad(const void* packed, int ns, int f16, const float* g_raw, int n_rows, const float* saved, float* dz,

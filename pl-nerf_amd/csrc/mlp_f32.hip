@@ -136,6 +136,7 @@ struct FwdArgs {
     const float* pts;
     const float* viewdirs;
     const float* embedded;
+    int xyz_ch, dir_ch;   // columns of `embedded`: input_ch | input_ch_views
     int n_rows, spr;
     float* raw_out;
     float* saved;
@@ -178,17 +179,17 @@ __global__ __launch_bounds__(256) void mlp_fwd_f32_kernel(FwdArgs a) {
 
     // ---- prologue: encodings into LDS --------------------------------------------------
     if (a.embedded) {
-        for (int e = tid; e < TM * EMB_CH; e += 256) {
-            const int row = e / EMB_CH, c = e - row * EMB_CH;
+        const int emb_ch = a.xyz_ch + a.dir_ch;
+        for (int e = tid; e < TM * emb_ch; e += 256) {
+            const int row = e / emb_ch, c = e - row * emb_ch;
             const int grow = min(row0 + row, a.n_rows - 1);
-            const float v = a.embedded[(size_t)grow * EMB_CH + c];
-            if (c < XYZ_CH) pe[row * LDP + c] = v;
-            else dpe[row * LDD + (c - XYZ_CH)] = v;
+            const float v = a.embedded[(size_t)grow * emb_ch + c];
+            if (c < a.xyz_ch) pe[row * LDP + c] = v;
+            else dpe[row * LDD + (c - a.xyz_ch)] = v;
         }
         for (int row = tid; row < TM; row += 256) {
-            pe[row * LDP + XYZ_CH] = 0.0f;
-#pragma unroll
-            for (int c = DIR_CH; c < DPE_K; ++c) dpe[row * LDD + c] = 0.0f;
+            for (int c = a.xyz_ch; c < PE_K; ++c) pe[row * LDP + c] = 0.0f;
+            for (int c = a.dir_ch; c < DPE_K; ++c) dpe[row * LDD + c] = 0.0f;
         }
     } else {
         // thread -> (row, q): q indexes which frequencies this thread encodes
@@ -918,21 +919,21 @@ __global__ void wgrad_reduce_kernel(ReduceArgs a) {
         const int job = idx >> 16, r = idx & 65535, o = r >> 8, i = r & 255;
         // jobs: L1, L2, L3, L4, L5 (hidden part), L6, L7, feature
         if (job < 4) a.G.p[2 * (job + 1)][o * W + i] = s;
-        else if (job == 4) a.G.p[10][o * (W + XYZ_CH) + XYZ_CH + i] = s;
+        else if (job == 4) a.G.p[10][o * (W + a.G.xyz_ch) + a.G.xyz_ch + i] = s;
         else if (job < 7) a.G.p[2 * (job + 1)][o * W + i] = s;
         else a.G.p[P_WF][o * W + i] = s;
     } else if (idx < PART_PE0) {
         const int r = idx - PART_VMAIN, o = r >> 8, i = r & 255;
-        a.G.p[P_WV][o * (W + DIR_CH) + i] = s;
+        a.G.p[P_WV][o * (W + a.G.dir_ch) + i] = s;
     } else if (idx < PART_PE5) {
         const int r = idx - PART_PE0, o = r >> 6, i = r & 63;
-        if (i < XYZ_CH) a.G.p[0][o * XYZ_CH + i] = s;
+        if (i < a.G.xyz_ch) a.G.p[0][o * a.G.xyz_ch + i] = s;
     } else if (idx < PART_VDIR) {
         const int r = idx - PART_PE5, o = r >> 6, i = r & 63;
-        if (i < XYZ_CH) a.G.p[10][o * (W + XYZ_CH) + i] = s;
+        if (i < a.G.xyz_ch) a.G.p[10][o * (W + a.G.xyz_ch) + i] = s;
     } else if (idx < PART_BIAS) {
         const int r = idx - PART_VDIR, o = r >> 5, i = r & 31;
-        if (i < DIR_CH) a.G.p[P_WV][o * (W + DIR_CH) + W + i] = s;
+        if (i < a.G.dir_ch) a.G.p[P_WV][o * (W + a.G.dir_ch) + W + i] = s;
     } else {
         const int r = idx - PART_BIAS;
         if (r < 8 * W) a.G.p[2 * (r >> 8) + 1][r & 255] = s;
@@ -998,8 +999,9 @@ namespace impl {
 
 size_t f32_packed_bytes() { return (size_t)PACKED_FLOATS * sizeof(float); }
 
-int f32_pack(const float* const* params, void* packed, hipStream_t st) {
+int f32_pack(const float* const* params, int xyz_ch, int dir_ch, void* packed, hipStream_t st) {
     ParamPtrs P;
+    P.xyz_ch = xyz_ch; P.dir_ch = dir_ch;
     for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i) {
         if (!params[i]) return PLNERF_EINVAL;
         P.p[i] = params[i];
@@ -1010,11 +1012,11 @@ int f32_pack(const float* const* params, void* packed, hipStream_t st) {
     return PLNERF_OK;
 }
 
-int f32_fwd(const void* packed, const float* pts, const float* viewdirs, const float* embedded, int n_rows,
-            int samples_per_ray, float* raw_out, void* saved, hipStream_t st) {
+int f32_fwd(const void* packed, const float* pts, const float* viewdirs, const float* embedded, int xyz_ch,
+            int dir_ch, int n_rows, int samples_per_ray, float* raw_out, void* saved, hipStream_t st) {
     constexpr int NI = 2, TM = 32 * NI;
-    FwdArgs a{(const float*)packed, pts, viewdirs, embedded, n_rows, samples_per_ray < 1 ? 1 : samples_per_ray,
-              raw_out, (float*)saved};
+    FwdArgs a{(const float*)packed, pts, viewdirs, embedded, xyz_ch, dir_ch, n_rows,
+              samples_per_ray < 1 ? 1 : samples_per_ray, raw_out, (float*)saved};
     const size_t lds = (size_t)TM * (LDA + LDP + LDD) * sizeof(float);
     dim3 grid((n_rows + TM - 1) / TM), block(256);
     if (saved) {
@@ -1043,7 +1045,7 @@ int f32_dgrad(const void* packed, const float* g_raw, int n_rows, const float* s
 
 // Weight gradients from the fp32 planes (saved activations + dz planes written by any of the
 // dgrad kernels): split-K partials, head reductions, deterministic final sum into grads[24].
-int f32_wgrad(const float* g_raw, int n_rows, const float* sv, float* dz, float* const* grads, int ns,
+int f32_wgrad(const float* g_raw, int n_rows, const float* sv, float* dz, float* const* grads, int xyz_ch, int dir_ch, int ns,
               int f16, hipStream_t st) {
     const size_t N = (size_t)n_rows;
     float* part = dz + (size_t)DZ_PER_ROW * N;
@@ -1134,6 +1136,7 @@ int f32_wgrad(const float* g_raw, int n_rows, const float* sv, float* dz, float*
     {
         ReduceArgs a{};
         a.part = part; a.head_part = head_part; a.splits = splits; a.n_head = n_head;
+        a.G.xyz_ch = xyz_ch; a.G.dir_ch = dir_ch;
         for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i) {
             if (!grads[i]) return PLNERF_EINVAL;
             a.G.p[i] = grads[i];

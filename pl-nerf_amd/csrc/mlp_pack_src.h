@@ -6,8 +6,10 @@
 
 namespace plnerf {
 
-struct ParamPtrs { const float* p[PLNERF_N_PARAM_TENSORS]; };
-struct GradPtrs { float* p[PLNERF_N_PARAM_TENSORS]; };
+// xyz_ch / dir_ch: the network's input_ch / input_ch_views (63 / 27 at the reference's default flags,
+// 57 / 3 for the depth-supervised variant); the GEMMs' K ranges are padded to PE_K / DPE_K with zeros.
+struct ParamPtrs { const float* p[PLNERF_N_PARAM_TENSORS]; int xyz_ch, dir_ch; };
+struct GradPtrs { float* p[PLNERF_N_PARAM_TENSORS]; int xyz_ch, dir_ch; };
 
 using namespace lay;
 
@@ -15,14 +17,14 @@ using namespace lay;
 // (k indexes the padded input: encodings 63->64 / 27->32, skip layer = [encoding 64 | hidden 256])
 __device__ __forceinline__ float fwd_src(const ParamPtrs& P, int g, int k, int j) {
     switch (g) {
-        case G_L0: return k < XYZ_CH ? P.p[0][j * XYZ_CH + k] : 0.0f;
+        case G_L0: return k < P.xyz_ch ? P.p[0][j * P.xyz_ch + k] : 0.0f;
         case G_L5:
-            if (k < PE_K) return k < XYZ_CH ? P.p[10][j * (W + XYZ_CH) + k] : 0.0f;
-            return P.p[10][j * (W + XYZ_CH) + XYZ_CH + (k - PE_K)];
+            if (k < PE_K) return k < P.xyz_ch ? P.p[10][j * (W + P.xyz_ch) + k] : 0.0f;
+            return P.p[10][j * (W + P.xyz_ch) + P.xyz_ch + (k - PE_K)];
         case G_FEAT: return P.p[P_WF][j * W + k];
         case G_VIEWS:
-            if (k < W) return P.p[P_WV][j * (W + DIR_CH) + k];
-            return (k - W) < DIR_CH ? P.p[P_WV][j * (W + DIR_CH) + k] : 0.0f;
+            if (k < W) return P.p[P_WV][j * (W + P.dir_ch) + k];
+            return (k - W) < P.dir_ch ? P.p[P_WV][j * (W + P.dir_ch) + k] : 0.0f;
         default: return P.p[2 * g][j * W + k];  // G_L1..G_L4, G_L6, G_L7: layer index == g
     }
 }
@@ -30,9 +32,9 @@ __device__ __forceinline__ float fwd_src(const ParamPtrs& P, int g, int k, int j
 // dgrad operand of GEMM g: W[o][col0 + i] (the hidden-state columns only)
 __device__ __forceinline__ float bwd_src(const ParamPtrs& P, int g, int o, int i) {
     switch (g) {
-        case D_VIEWS: return P.p[P_WV][o * (W + DIR_CH) + i];
+        case D_VIEWS: return P.p[P_WV][o * (W + P.dir_ch) + i];
         case D_FEAT: return P.p[P_WF][o * W + i];
-        case D_L5: return P.p[10][o * (W + XYZ_CH) + XYZ_CH + i];
+        case D_L5: return P.p[10][o * (W + P.xyz_ch) + P.xyz_ch + i];
         case D_L7: return P.p[14][o * W + i];
         case D_L6: return P.p[12][o * W + i];
         case D_L4: return P.p[8][o * W + i];

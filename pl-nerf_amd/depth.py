@@ -1,0 +1,300 @@
+"""Depth-supervised variant of the path (BASELINE config 5): the caller-side
+mirror of depth_supervised_exps/run_nerf_sample_based_depth.py and
+depth_supervised_exps/model/run_nerf_helpers.py, on the same HIP kernels.
+
+What differs from the NVS path (render.py):
+  * the encoder multiplies by pi (model/run_nerf_helpers.py:123) and the default widths are
+    multires 9 / multires_views 0 -> input_ch 57, input_ch_views 3 (run_nerf_sample_based_depth.py:
+    1306-1309): the encoding is evaluated here and handed to the fused MLP as `embedded`;
+  * positions pass through (x - bb_center) * bb_scale first (:56);
+  * the density channel goes through softplus(beta=10) (model/run_nerf_helpers.py:200);
+  * render_rays draws a third set of samples, `pred_hyp`, from the final weights WITHOUT detaching them
+    (:923-934): the space-carving loss back-propagates through the sampler (plnerf_sample_pl_bwd) and
+    the transmittance / density knots (g_tau, g_T of plnerf_quad_bwd);
+  * one Adam over both networks, gradient values clipped to 0.1 (:1155-1157).
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import functional as Fn
+from .nerf import Embedder, NeRF
+from .render import batchify, raw2outputs as _raw2outputs, sample_pdf, sample_pdf_reformulation
+
+
+def get_embedder(multires, i=0):
+    """model/run_nerf_helpers.py:132-148: gamma(x) with sin/cos(x * pi * 2^k)."""
+    if i == -1:
+        return torch.nn.Identity(), 3
+    emb = Embedder(include_input=True, input_dims=3, max_freq_log2=multires - 1, num_freqs=multires,
+                   log_sampling=True, periodic_fns=[torch.sin, torch.cos], input_scale=np.pi)
+    return emb, emb.out_dim
+
+
+def run_network(inputs, viewdirs, embedded_cam, fn, embed_fn, embeddirs_fn, bb_center, bb_scale, netchunk=1024 * 64):
+    """run_nerf_sample_based_depth.py:52-68."""
+    inputs_flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
+    inputs_flat = (inputs_flat - bb_center) * bb_scale
+    embedded = embed_fn(inputs_flat)
+    if viewdirs is not None:
+        input_dirs = viewdirs[:, None].expand(inputs.shape)
+        input_dirs_flat = torch.reshape(input_dirs, [-1, input_dirs.shape[-1]])
+        embedded_dirs = embeddirs_fn(input_dirs_flat)
+        embedded = torch.cat([embedded, embedded_dirs,
+                              embedded_cam.unsqueeze(0).expand(embedded_dirs.shape[0], embedded_cam.shape[0])], -1)
+    outputs_flat = batchify(fn, netchunk)(embedded)
+    return torch.reshape(outputs_flat, list(inputs.shape[:-1]) + [outputs_flat.shape[-1]])
+
+
+def raw2outputs(raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std=0, pytest=False, white_bkgd=False,
+                farcolorfix=False):
+    """run_nerf_sample_based_depth.py:709-773.  `farcolorfix` is accepted and ignored there."""
+    return _raw2outputs(raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std, pytest=pytest,
+                        white_bkgd=white_bkgd, farcolorfix=False)
+
+
+def _draw_u(n_rays, N_samples, det, pytest, load_u, joint, device):
+    """The draw of the *_return_u samplers (model/run_nerf_helpers.py:619-638; joint: 792-812)."""
+    if load_u is not None:
+        return load_u
+    if det:
+        u = Fn.cpu_linspace(N_samples, device).expand(n_rays, N_samples)
+    elif joint:
+        u = torch.rand(N_samples, device=device).unsqueeze(0).repeat(n_rays, 1)
+    else:
+        u = torch.rand(n_rays, N_samples, device=device)
+    if pytest:
+        np.random.seed(0)
+        if det:
+            u = torch.Tensor(np.broadcast_to(np.linspace(0., 1., N_samples), [n_rays, N_samples]).copy()).to(device)
+        else:
+            u = torch.Tensor(np.random.rand(n_rays, N_samples)).to(device)
+    return u
+
+
+def sample_pdf_reformulation_return_u(bins, weights, tau, T, near, far, N_samples, det=False, pytest=False,
+                                      load_u=None, quad_solution_v2=True, zero_threshold=1e-4, epsilon_=1e-3,
+                                      joint=False):
+    """model/run_nerf_helpers.py:607-692 (and :780- for joint=True).  Returns (samples, T_below, tau_below,
+    bin_below, u); `samples` is differentiable with respect to tau and T."""
+    u = _draw_u(bins.shape[0], N_samples, det, pytest, load_u, joint, bins.device).contiguous()
+    s, Tb, taub, binb = Fn.sample_pl(bins, weights, tau, T, near, far, u, zero_threshold, epsilon_, want_extras=True)
+    return s, Tb, taub, binb, u
+
+
+def sample_pdf_return_u(bins, weights, N_samples, det=False, pytest=False, load_u=None, joint=False):
+    """model/run_nerf_helpers.py:343-394 (piecewise-constant mode).  The kernel has no backward: the returned
+    samples carry no gradient (the reference's would, through the normalised cdf); constant-mode depth
+    supervision therefore fails loudly instead of training on a silently detached hypothesis."""
+    if torch.is_grad_enabled() and weights.requires_grad:
+        raise NotImplementedError("constant-mode pred_hyp is not differentiable on the HIP path; use mode='linear' "
+                                  "(the PL-NeRF configuration) or evaluate under torch.no_grad()")
+    u = _draw_u(bins.shape[0], N_samples, det, pytest, load_u, joint, bins.device).contiguous()
+    return Fn.sample_const(bins, weights, u), u
+
+
+def perturb_z_vals(z_vals, pytest):
+    """run_nerf_sample_based_depth.py:775-790."""
+    mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+    upper = torch.cat([mids, z_vals[..., -1:]], -1)
+    lower = torch.cat([z_vals[..., :1], mids], -1)
+    if pytest:
+        t_rand = Fn.numpy_uniform(list(z_vals.shape), z_vals.device)
+    else:
+        t_rand = torch.rand_like(z_vals)
+    return lower + (upper - lower) * t_rand
+
+
+def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples, mode, color_mode,
+                precomputed_z_samples=None, embedded_cam=None, retraw=False, lindisp=False, perturb=0.,
+                N_importance=0, network_fine=None, raw_noise_std=0., verbose=False, pytest=False, white_bkgd=False,
+                is_joint=False, cached_u=None, scale_sample_gradient=False, quad_solution_v2=False, zero_tol=1e-4,
+                epsilon=1e-3, farcolorfix=False):
+    """run_nerf_sample_based_depth.py:792-958.  Returns the reference's dict: rgb_map, disp_map, acc_map,
+    depth_map, z_vals, weights, pred_hyp, u (+ raw; + rgb0, disp0, acc0, depth0, z_vals0, weights0, z_std)."""
+    dev = ray_batch.device
+    N_rays = ray_batch.shape[0]
+    rays_o, rays_d = ray_batch[:, 0:3], ray_batch[:, 3:6]
+    viewdirs = ray_batch[:, 8:11] if use_viewdirs else None
+    bounds = torch.reshape(ray_batch[..., 6:8], [-1, 1, 2])
+    near, far = bounds[..., 0], bounds[..., 1]
+    t_vals = Fn.cpu_linspace(N_samples, dev)
+    if not lindisp:
+        z_vals = near * (1. - t_vals) + far * t_vals
+    else:
+        z_vals = 1. / (1. / near * (1. - t_vals) + 1. / far * t_vals)
+    if perturb > 0.:
+        z_vals = perturb_z_vals(z_vals, pytest)
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+    raw = network_query_fn(pts, viewdirs, embedded_cam, network_fn)
+    rgb_map, disp_map, acc_map, weights, depth_map, tau, T = raw2outputs(
+        raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std, pytest=pytest, white_bkgd=white_bkgd,
+        farcolorfix=farcolorfix)
+
+    def hypotheses(z_vals, weights, tau, T, n, load_u):
+        if mode == "linear":
+            s, _, _, _, u = sample_pdf_reformulation_return_u(
+                z_vals, weights, tau, T, near, far, n, det=(perturb == 0.), pytest=pytest, load_u=load_u,
+                quad_solution_v2=quad_solution_v2, joint=is_joint)
+        elif mode == "constant":
+            z_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+            s, u = sample_pdf_return_u(z_mid, weights[..., 1:-1], n, det=(perturb == 0.), pytest=pytest,
+                                       load_u=load_u, joint=is_joint)
+        else:
+            raise ValueError("mode must be 'linear' or 'constant'")
+        return s, u
+
+    if N_importance == 0:
+        pred_depth_hyp, u = hypotheses(z_vals, weights, tau, T, N_samples, None)
+    else:
+        rgb_map_0, disp_map_0, acc_map_0, depth_map_0, z_vals_0, weights_0 = \
+            rgb_map, disp_map, acc_map, depth_map, z_vals, weights
+        if mode == "linear":
+            z_samples = sample_pdf_reformulation(z_vals, weights, tau, T, near, far, N_importance, det=(perturb == 0.),
+                                                 pytest=pytest, quad_solution_v2=quad_solution_v2)[0]
+        else:
+            z_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+            z_samples = sample_pdf(z_mid, weights[..., 1:-1], N_importance, det=(perturb == 0.), pytest=pytest)
+        z_samples = z_samples.detach()
+        z_vals = Fn.merge_sort(z_vals, z_samples, near, far)          # clamp + cat + sort (:902-906)
+        pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+        run_fn = network_fn if network_fine is None else network_fine
+        raw = network_query_fn(pts, viewdirs, embedded_cam, run_fn)
+        rgb_map, disp_map, acc_map, weights, depth_map, tau, T = raw2outputs(
+            raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std, pytest=pytest, white_bkgd=white_bkgd)
+        pred_depth_hyp, u = hypotheses(z_vals, weights, tau, T, N_importance, cached_u)
+        z_std = torch.std(pred_depth_hyp, dim=-1, unbiased=False)
+
+    if mode == "linear":
+        weights = weights[..., 1:]
+    ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map, 'depth_map': depth_map,
+           'z_vals': z_vals, 'weights': weights, 'pred_hyp': pred_depth_hyp, 'u': u}
+    if retraw:
+        ret['raw'] = raw
+    if N_importance > 0:
+        ret['rgb0'] = rgb_map_0
+        ret['disp0'] = disp_map_0
+        ret['acc0'] = acc_map_0
+        ret['depth0'] = depth_map_0
+        ret['z_vals0'] = z_vals_0
+        ret['weights0'] = weights_0
+        ret['z_std'] = z_std
+    return ret
+
+
+def compute_space_carving_loss(pred_depth, target_hypothesis, is_joint=False, mask=None, norm_p=2, threshold=0.0):
+    """model/run_nerf_helpers.py:52-86.  pred_depth [n_rays, n_points]; target_hypothesis
+    [n_hyp, n_rays, 1 or n_points].  A handful of small reductions: torch ops on the device."""
+    n_rays, n_points = pred_depth.shape
+    if target_hypothesis.shape[-1] == 1:
+        target = target_hypothesis.repeat(1, 1, n_points)
+    else:
+        target = target_hypothesis
+    distances = torch.norm(pred_depth.unsqueeze(-1) - target.unsqueeze(-1), p=norm_p, dim=-1)
+    if mask is not None:
+        distances = distances * mask.unsqueeze(0).repeat(distances.shape[0], 1).unsqueeze(-1)
+    if threshold > 0:
+        distances = torch.where(distances < threshold, torch.zeros((), device=distances.device), distances)
+    if is_joint:
+        quantile_mean = torch.mean(distances, axis=1)
+        return torch.mean(torch.min(quantile_mean, axis=0)[0], axis=-1)
+    best_hyp = torch.min(distances, dim=0)[0]
+    return torch.mean(torch.mean(best_hyp, dim=-1))
+
+
+def create_nerf(args, scene_render_params=None, device=None):
+    """run_nerf_sample_based_depth.py:547-644: (render_kwargs_train, render_kwargs_test, start, grad_vars,
+    optimizer).  One Adam over the parameters of both networks; no nn.DataParallel (ray shards go through
+    dp.py instead, one process per GPU)."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() \
+            else torch.device("cpu")
+    precision = getattr(args, "precision", "fp32")
+    embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
+    input_ch_views, embeddirs_fn = 0, None
+    if args.use_viewdirs:
+        embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
+    output_ch = 5 if args.N_importance > 0 else 4
+    input_ch_cam = getattr(args, "input_ch_cam", 0)
+
+    def make(D, W):
+        return NeRF(D=D, W=W, input_ch=input_ch, output_ch=output_ch, skips=[4], input_ch_views=input_ch_views,
+                    input_ch_cam=input_ch_cam, use_viewdirs=args.use_viewdirs, precision=precision,
+                    density_activation="softplus", dense_layer_init=True).to(device)
+    model = make(args.netdepth, args.netwidth)
+    grad_vars = list(model.parameters())
+    model_fine = None
+    if args.N_importance > 0:
+        model_fine = make(args.netdepth_fine, args.netwidth_fine)
+        grad_vars += list(model_fine.parameters())
+    bb_center, bb_scale = getattr(args, "bb_center", 0.0), getattr(args, "bb_scale", 1.0)
+
+    def network_query_fn(inputs, viewdirs, embedded_cam, network_fn):
+        return run_network(inputs, viewdirs, embedded_cam, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
+                           bb_center=bb_center, bb_scale=bb_scale, netchunk=getattr(args, "netchunk", 1024 * 64))
+    fused = {"fused": True} if torch.device(device).type == "cuda" else {}
+    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999), **fused)
+    start = 0
+    ckdir = os.path.join(getattr(args, "ckpt_dir", ""), getattr(args, "expname", ""))
+    if not getattr(args, "no_reload", True) and os.path.isdir(ckdir):
+        ckpts = [os.path.join(ckdir, f) for f in sorted(os.listdir(ckdir)) if f.endswith('.tar')]
+        if ckpts:
+            ckpt = torch.load(ckpts[-1], map_location=device)
+            start = ckpt['global_step']
+            optimizer.load_state_dict(ckpt['optimizer_state_dict'])
+            model.load_state_dict(ckpt['network_fn_state_dict'])
+            if model_fine is not None:
+                model_fine.load_state_dict(ckpt['network_fine_state_dict'])
+    render_kwargs_train = {
+        'network_query_fn': network_query_fn, 'embedded_cam': torch.tensor((), device=device),
+        'perturb': args.perturb, 'N_importance': args.N_importance, 'network_fine': model_fine,
+        'N_samples': args.N_samples, 'network_fn': model, 'use_viewdirs': args.use_viewdirs,
+        'raw_noise_std': args.raw_noise_std, 'white_bkgd': args.white_bkgd, 'mode': args.mode,
+        'color_mode': args.color_mode,
+    }
+    render_kwargs_train.update(scene_render_params or {})
+    render_kwargs_train['lindisp'] = getattr(args, "lindisp", False)
+    render_kwargs_test = dict(render_kwargs_train)
+    render_kwargs_test['perturb'] = False
+    render_kwargs_test['raw_noise_std'] = 0.
+    return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer
+
+
+class DepthTrainStep:
+    """One iteration of the reference's depth-supervised loop (run_nerf_sample_based_depth.py:1126-1157):
+    loss = mse(rgb) + space_carving_weight * space_carving(pred_hyp, target_h) + mse(rgb0); backward;
+    clip_grad_value_(0.1); Adam.  `ray_batch` is the packed [R, 11] batch render_rays takes."""
+
+    def __init__(self, args, render_kwargs_train, optimizer, grad_vars, distributed=None):
+        from . import dp
+        self.args, self.kw, self.optimizer, self.grad_vars = args, render_kwargs_train, optimizer, grad_vars
+        self.global_step = 0
+        nets = [n for n in (self.kw["network_fn"], self.kw.get("network_fine")) if n is not None]
+        distributed = torch.distributed.is_initialized() if distributed is None else distributed
+        self.bucket = dp.GradientBucket(nets) if distributed and torch.distributed.get_world_size() > 1 else None
+
+    def __call__(self, ray_batch, target_s, target_h, space_carving_mask=None, cached_u=None, pytest=False):
+        a = self.args
+        kw = {k: v for k, v in self.kw.items() if k not in ("ndc", "near", "far")}
+        out = render_rays(ray_batch, retraw=True, is_joint=getattr(a, "is_joint", False), cached_u=cached_u,
+                          quad_solution_v2=getattr(a, "quad_solution_v2", False), pytest=pytest, **kw)
+        self.optimizer.zero_grad()
+        img_loss = torch.mean((out['rgb_map'] - target_s) ** 2)
+        loss = img_loss
+        sc = torch.zeros((), device=ray_batch.device)
+        if getattr(a, "space_carving_weight", 0.) > 0. and self.global_step + 1 > getattr(a, "warm_start_nerf", 0):
+            sc = compute_space_carving_loss(out["pred_hyp"], target_h, is_joint=getattr(a, "is_joint", False),
+                                            norm_p=getattr(a, "norm_p", 2),
+                                            threshold=getattr(a, "space_carving_threshold", 0.0),
+                                            mask=space_carving_mask)
+            loss = loss + a.space_carving_weight * sc
+        if 'rgb0' in out:
+            loss = loss + torch.mean((out['rgb0'] - target_s) ** 2)
+        loss.backward()
+        if self.bucket is not None:
+            self.bucket.allreduce_mean()
+        torch.nn.utils.clip_grad_value_(self.grad_vars, 0.1)
+        self.optimizer.step()
+        self.global_step += 1
+        return loss.detach(), img_loss.detach(), sc.detach(), out

@@ -5,15 +5,20 @@
 `.parameters()` order are identical and reference checkpoints load unchanged
 (run_plnerf.py:454-471, 1324-1332).
 """
+import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import _lib as L
 from .functional import MlpFn
 
-# The one architecture the HIP kernels are specialised for: the reference's defaults
-# (run_plnerf.py:784-825), used by every config under configs/.
+# The architecture the HIP kernels are specialised for: the reference's trunk (run_plnerf.py:784-825),
+# used by every config under configs/.  The two input widths are run-time: 63 / 27 at the default
+# flags (the in-kernel positional encoding exists for exactly these), anything up to 64 / 32 with a
+# caller-side encoding -- e.g. 57 / 3 for the depth-supervised variant.
 SUPPORTED = dict(D=8, W=256, input_ch=63, input_ch_views=27, skips=[4], use_viewdirs=True)
+MAX_INPUT_CH, MAX_VIEW_CH = 64, 32
 
 
 class Embedder:
@@ -31,6 +36,8 @@ class Embedder:
         self.max_freq_log2 = kwargs["max_freq_log2"]
         self.log_sampling = kwargs["log_sampling"]
         self.periodic_fns = kwargs["periodic_fns"]
+        # depth-supervised variant: fn(x * pi * freq) (depth_supervised_exps/model/run_nerf_helpers.py:123)
+        self.input_scale = kwargs.get("input_scale", None)
         if self.log_sampling:
             self.freq_bands = [float(2.0 ** f) for f in
                                torch.linspace(0.0, self.max_freq_log2, steps=self.num_freqs).tolist()]
@@ -41,7 +48,8 @@ class Embedder:
                                           self.num_freqs * len(self.periodic_fns))
 
     def is_standard(self, n_freqs):
-        return (self.input_dims == 3 and self.include_input and self.log_sampling and
+        return (self.input_scale is None and
+                self.input_dims == 3 and self.include_input and self.log_sampling and
                 self.num_freqs == n_freqs and self.max_freq_log2 == n_freqs - 1 and
                 list(self.periodic_fns) == [torch.sin, torch.cos])
 
@@ -49,7 +57,8 @@ class Embedder:
         blocks = [inputs] if self.include_input else []
         for f in self.freq_bands:
             for fn in self.periodic_fns:
-                blocks.append(fn(inputs * f))
+                # same association as the reference: (x * pi) * freq
+                blocks.append(fn(inputs * f) if self.input_scale is None else fn(inputs * self.input_scale * f))
         return torch.cat(blocks, -1)
 
     __call__ = embed
@@ -70,39 +79,64 @@ class NeRF(nn.Module):
     HIP kernel; `precision` selects the contraction arithmetic ("fp32" = exact fp32 MFMA)."""
 
     def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False,
-                 precision="fp32"):
+                 precision="fp32", input_ch_cam=0, density_activation=None, dense_layer_init=False):
+        """input_ch_cam, density_activation="softplus" (beta 10 on the density channel) and
+        dense_layer_init (xavier-uniform weights with the layer's gain, zero biases) are the
+        depth-supervised variant's NeRF (depth_supervised_exps/model/run_nerf_helpers.py:90-98,
+        143-205); the defaults are run_nerf_helpers.py:76-128."""
         super().__init__()
         self.D, self.W = D, W
-        self.input_ch, self.input_ch_views = input_ch, input_ch_views
+        self.input_ch, self.input_ch_views, self.input_ch_cam = input_ch, input_ch_views, input_ch_cam
+        self.view_ch = input_ch_views + input_ch_cam
         self.skips = skips
         self.use_viewdirs = use_viewdirs
         self.precision = precision
+        if density_activation not in (None, "softplus"):
+            raise ValueError("density_activation must be None or 'softplus'")
+        self.density_activation = density_activation
         self.pts_linears = nn.ModuleList(
             [nn.Linear(input_ch, W)] +
             [nn.Linear(W + input_ch, W) if i in skips else nn.Linear(W, W) for i in range(D - 1)])
-        self.views_linears = nn.ModuleList([nn.Linear(input_ch_views + W, W // 2)])
+        self.views_linears = nn.ModuleList([nn.Linear(self.view_ch + W, W // 2)])
         if use_viewdirs:
             self.feature_linear = nn.Linear(W, W)
             self.alpha_linear = nn.Linear(W, 1)
             self.rgb_linear = nn.Linear(W // 2, 3)
         else:
             self.output_linear = nn.Linear(W, output_ch)
+        if dense_layer_init:
+            relu_layers = list(self.pts_linears) + list(self.views_linears)
+            for m in self.modules():
+                if isinstance(m, nn.Linear):
+                    gain = nn.init.calculate_gain("relu" if any(m is r for r in relu_layers) else "linear")
+                    nn.init.xavier_uniform_(m.weight, gain=gain)
+                    nn.init.zeros_(m.bias)
         self._packed = None
 
     # -- HIP plumbing ---------------------------------------------------------------
     def is_supported(self):
         return (self.D == SUPPORTED["D"] and self.W == SUPPORTED["W"] and
-                self.input_ch == SUPPORTED["input_ch"] and
-                self.input_ch_views == SUPPORTED["input_ch_views"] and
+                1 <= self.input_ch <= MAX_INPUT_CH and 1 <= self.view_ch <= MAX_VIEW_CH and
                 list(self.skips) == SUPPORTED["skips"] and self.use_viewdirs)
+
+    def has_fused_encoding(self):
+        """True when the kernel's own positional encoding (3 + 6*10 | 3 + 6*4 channels) is this network's."""
+        return (self.input_ch == SUPPORTED["input_ch"] and self.input_ch_views == SUPPORTED["input_ch_views"] and
+                self.input_ch_cam == 0)
 
     def _require_supported(self):
         if not self.is_supported():
             raise NotImplementedError(
-                "plnerf_amd's HIP MLP is specialised for the reference's default architecture "
-                f"{SUPPORTED}; got D={self.D}, W={self.W}, input_ch={self.input_ch}, "
-                f"input_ch_views={self.input_ch_views}, skips={self.skips}, "
-                f"use_viewdirs={self.use_viewdirs}.  There is no generic/CPU fallback.")
+                "plnerf_amd's HIP MLP is specialised for the reference's trunk "
+                f"(D={SUPPORTED['D']}, W={SUPPORTED['W']}, skips={SUPPORTED['skips']}, use_viewdirs, input_ch <= "
+                f"{MAX_INPUT_CH}, input_ch_views + input_ch_cam <= {MAX_VIEW_CH}); got D={self.D}, W={self.W}, "
+                f"input_ch={self.input_ch}, input_ch_views={self.input_ch_views}, input_ch_cam={self.input_ch_cam}, "
+                f"skips={self.skips}, use_viewdirs={self.use_viewdirs}.  There is no generic/CPU fallback.")
+
+    def _activate(self, raw):
+        if self.density_activation == "softplus":   # depth_supervised_exps/model/run_nerf_helpers.py:200
+            return torch.cat([raw[..., :3], F.softplus(raw[..., 3:], beta=10)], -1)
+        return raw
 
     def param_list(self):
         """The 24 parameter tensors in state_dict order (the C ABI's `params[24]`)."""
@@ -123,8 +157,8 @@ class NeRF(nn.Module):
         flat = [p.detach() for p in params]
         if self._packed is None or self._packed.device != dev or self._packed.numel() * 4 != nbytes:
             self._packed = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
-        L.check(L.lib().plnerf_mlp_pack_weights(L.ptr_table(flat), prec, L.dptr(self._packed), L.stream()),
-                "plnerf_mlp_pack_weights")
+        L.check(L.lib().plnerf_mlp_pack_weights(L.ptr_table(flat), prec, int(self.input_ch), int(self.view_ch),
+                                                L.dptr(self._packed), L.stream()), "plnerf_mlp_pack_weights")
         return self._packed
 
     # -- reference interface --------------------------------------------------------
@@ -132,13 +166,18 @@ class NeRF(nn.Module):
         self._require_supported()
         lead = x.shape[:-1]
         flat = x.reshape(-1, x.shape[-1])
+        if flat.shape[-1] != self.input_ch + self.view_ch:
+            raise ValueError(f"NeRF.forward expects {self.input_ch + self.view_ch} embedded channels, got {flat.shape[-1]}")
         out = MlpFn.apply(None, None, flat, 1, self, torch.is_grad_enabled(), *self.param_list())
-        return out.reshape(*lead, 4)
+        return self._activate(out.reshape(*lead, 4))
 
     def query(self, pts, viewdirs):
         """Fused entry: pts [R,S,3], viewdirs [R,3] -> raw [R,S,4]; the encoding happens in
         the kernel prologue (what run_network does on the hot path)."""
         self._require_supported()
+        if not self.has_fused_encoding():
+            raise NotImplementedError("the in-kernel encoding is the reference default (63 | 27 channels); "
+                                      "embed on the caller side and use forward()")
         R, S = pts.shape[0], pts.shape[1]
         out = MlpFn.apply(pts.reshape(-1, 3), viewdirs, None, S, self, torch.is_grad_enabled(), *self.param_list())
-        return out.reshape(R, S, 4)
+        return self._activate(out.reshape(R, S, 4))

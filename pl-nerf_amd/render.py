@@ -29,7 +29,7 @@ def batchify(fn, chunk):
 
 
 def _fusable(fn, embed_fn, embeddirs_fn, viewdirs):
-    return (isinstance(fn, NeRF) and fn.is_supported() and viewdirs is not None and
+    return (isinstance(fn, NeRF) and fn.is_supported() and fn.has_fused_encoding() and viewdirs is not None and
             isinstance(embed_fn, Embedder) and embed_fn.is_standard(10) and
             isinstance(embeddirs_fn, Embedder) and embeddirs_fn.is_standard(4))
 

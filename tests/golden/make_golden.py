@@ -7,7 +7,7 @@ _ref_import.py):
 
 Fixtures are data only: inputs and the reference's outputs.  Network weights
 come from oracle.plnerf_oracle.closed_form_state_dict (an RNG-free recipe), so
-they are not stored.  Fixture ids follow SURVEY.md section 8c (G1..G7).
+they are not stored.  Fixture ids follow SURVEY.md section 8c (G1..G8).
 """
 import os
 import sys
@@ -289,7 +289,79 @@ def g7():
     npz("g7_rays", H=H, W=W, focal=f, c2w=c2w, rays_o=o, rays_d=d, ndc_o=o2, ndc_d=d2)
 
 
+# ---------------------------------------------------------------- G8: depth-supervised variant
+def import_depth_reference():
+    """depth_supervised_exps/run_nerf_sample_based_depth.py and its model package, imported read-only."""
+    ddir = os.path.join("/root/reference", "depth_supervised_exps")
+    if ddir not in sys.path:
+        sys.path.insert(0, ddir)
+    import run_nerf_sample_based_depth as D      # noqa: E402
+    import model.run_nerf_helpers as DH          # noqa: E402
+    return D, DH
+
+
+def g8():
+    """The depth-supervised variant: pi-scaled encoder + softplus density network
+    (57 | 3 input channels), render_rays with the attached `pred_hyp`, space-carving loss, and one clipped
+    Adam step over both networks -- all from the reference's own functions."""
+    D, DH = import_depth_reference()
+    out = {}
+    embed_fn, input_ch = DH.get_embedder(9, 0)
+    embeddirs_fn, input_ch_views = DH.get_embedder(0, 0)
+    assert (input_ch, input_ch_views) == (57, 3)
+
+    def net(seed):
+        m = DH.NeRF(D=8, W=256, input_ch=input_ch, output_ch=5, skips=[4], input_ch_views=input_ch_views,
+                    input_ch_cam=0, use_viewdirs=True)
+        m.load_state_dict(orc.closed_form_state_dict_depth(seed, sharpen=True))
+        return m
+    coarse, fine = net(0), net(1)
+
+    def query(inputs, viewdirs, embedded_cam, fn):
+        return D.run_network(inputs, viewdirs, embedded_cam, fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
+                             bb_center=0.0, bb_scale=1.0, netchunk=65536)
+    # (a) the network on its own
+    gen = torch.Generator().manual_seed(8)
+    pts = (torch.rand(6, 16, 3, generator=gen) * 2 - 1) * 2.5
+    vd = torch.nn.functional.normalize(torch.randn(6, 3, generator=gen), dim=-1)
+    with torch.no_grad():
+        raw = query(pts, vd, torch.tensor(()), coarse)
+        emb = torch.cat([embed_fn(pts.reshape(-1, 3)), embeddirs_fn(vd[:, None].expand(pts.shape).reshape(-1, 3))], -1)
+    out.update({"mlp_pts": pts, "mlp_viewdirs": vd, "mlp_embedded": emb, "mlp_raw": raw})
+    # (b) render_rays + (c) one training step
+    R, Ns, Ni, n_hyp, sc_w = 24, 32, 48, 3, 0.007
+    batch, target = scene_rays(R, seed=8)
+    rng = np.random.default_rng(8)
+    target_h = torch.from_numpy(rng.uniform(2.0, 6.0, size=(n_hyp, R, 1)).astype(np.float32))
+    params = list(coarse.parameters()) + list(fine.parameters())
+    opt = torch.optim.Adam(params=params, lr=5e-4, betas=(0.9, 0.999))
+    ret = D.render_rays(batch, True, coarse, query, Ns, "linear", "midpoint", embedded_cam=torch.tensor(()),
+                        retraw=True, perturb=1.0, N_importance=Ni, network_fine=fine, raw_noise_std=0.0,
+                        pytest=True, white_bkgd=True, is_joint=False, cached_u=None)
+    for k in ("rgb_map", "disp_map", "acc_map", "depth_map", "z_vals", "weights", "pred_hyp", "u", "raw", "rgb0",
+              "disp0", "acc0", "depth0", "z_vals0", "weights0", "z_std"):
+        out["render_" + k] = ret[k]
+    opt.zero_grad()
+    img_loss = DH.img2mse(ret["rgb_map"], target)
+    sc = DH.compute_space_carving_loss(ret["pred_hyp"], target_h, is_joint=False, norm_p=2, threshold=0.0, mask=None)
+    loss = img_loss + sc_w * sc + DH.img2mse(ret["rgb0"], target)
+    loss.backward()
+    for m, tag in ((coarse, "coarse"), (fine, "fine")):
+        for name, prm in m.named_parameters():
+            out[f"grad_{tag}_{name}_norm"] = prm.grad.norm()
+            out[f"grad_{tag}_{name}_sample"] = sample_elems(prm.grad)
+    torch.nn.utils.clip_grad_value_(params, 0.1)
+    opt.step()
+    for m, tag in ((coarse, "coarse"), (fine, "fine")):
+        for name, prm in m.named_parameters():
+            out[f"param_{tag}_{name}_sample"] = sample_elems(prm)
+    out.update({"ray_batch": batch, "target": target, "target_h": target_h, "N_samples": Ns, "N_importance": Ni,
+                "space_carving_weight": sc_w, "loss": loss.detach(), "space_carving_loss": sc.detach(),
+                "sample_stride": 97})
+    npz("g8_depth_variant", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for name in which:
         globals()[name]()

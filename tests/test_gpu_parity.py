@@ -577,6 +577,152 @@ def test_train_step_golden_and_oracle(P, golden):
                 assert float((prm.detach().reshape(-1)[::stride].cpu() - ref).abs().max()) <= 1.25e-3
 
 
+# ----------------------------------------------------------------------------- depth-supervised variant (8f-1)
+def _depth_args(gd, precision="fp32"):
+    from argparse import Namespace
+    return Namespace(multires=9, i_embed=0, use_viewdirs=True, multires_views=0, input_ch_cam=0,
+                     N_importance=int(gd["N_importance"]), N_samples=int(gd["N_samples"]), netdepth=8, netwidth=256,
+                     netdepth_fine=8, netwidth_fine=256, netchunk=65536, lrate=5e-4, perturb=1.0, white_bkgd=True,
+                     raw_noise_std=0.0, mode="linear", color_mode="midpoint", lindisp=False, no_reload=True,
+                     space_carving_weight=float(gd["space_carving_weight"]), warm_start_nerf=0, is_joint=False,
+                     norm_p=2, space_carving_threshold=0.0, precision=precision, bb_center=0.0, bb_scale=1.0)
+
+
+def _depth_setup(P, gd, precision="fp32"):
+    from plnerf_amd import depth as Dp
+    kw, kw_test, start, grad_vars, opt = Dp.create_nerf(_depth_args(gd, precision), device=dev())
+    assert (kw["network_fn"].input_ch, kw["network_fn"].input_ch_views) == (57, 3)
+    kw["network_fn"].load_state_dict(orc.closed_form_state_dict_depth(0, True))
+    kw["network_fine"].load_state_dict(orc.closed_form_state_dict_depth(1, True))
+    return Dp, kw, grad_vars, opt
+
+
+def test_depth_variant_network_golden(P, golden):
+    """57 | 3 input channels, pi-scaled encoder, softplus density (depth_supervised_exps/model/
+    run_nerf_helpers.py:100-205) through the same fused MLP, against the reference's own outputs (G8);
+    also the non-default widths' weight gradients against the oracle."""
+    gd = golden("g8_depth_variant")
+    Dp, kw, _, _ = _depth_setup(P, gd)
+    pts, vd = g(T(gd["mlp_pts"])), g(T(gd["mlp_viewdirs"]))
+    with torch.no_grad():
+        raw = kw["network_query_fn"](pts, vd, kw["embedded_cam"], kw["network_fn"])
+    assert_close(raw, gd["mlp_raw"], what="g8 network output")
+    for prec, tol in (("f16x3", 1e-5), ("bf16x3", 2e-5)):
+        Dp2, kw2, _, _ = _depth_setup(P, gd, prec)
+        with torch.no_grad():
+            raw2 = kw2["network_query_fn"](pts, vd, kw2["embedded_cam"], kw2["network_fn"])
+        err = maxdiff(raw2, T(gd["mlp_raw"]))
+        print(f"g8 network {prec}: max err {err:.3e}")
+        assert err <= tol * (1 + float(T(gd["mlp_raw"]).abs().max()))
+    # gradients of the 57- and 3-wide weight blocks (fp32 path) vs oracle autograd
+    net = kw["network_fn"]
+    emb = g(T(gd["mlp_embedded"]))
+    cot = torch.randn(emb.shape[0], 4, generator=torch.Generator().manual_seed(1))
+    out = net(emb)
+    (out * g(cot)).sum().backward()
+    sd = {k: v.clone().requires_grad_(True) for k, v in orc.closed_form_state_dict_depth(0, True).items()}
+    (orc.nerf_mlp_depth(sd, T(gd["mlp_embedded"])) * cot).sum().backward()
+    for name, prm in net.named_parameters():
+        ref = sd[name].grad
+        err = float((prm.grad.cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+        assert err <= 1e-4, (name, err)
+
+
+def test_depth_variant_render_and_train_step_golden(P, golden):
+    """render_rays of the depth-supervised variant (pred_hyp attached) and one training step
+    (run_nerf_sample_based_depth.py:792-958, 1126-1157) against the reference (G8)."""
+    gd = golden("g8_depth_variant")
+    stride = int(gd["sample_stride"])
+    Dp, kw, grad_vars, opt = _depth_setup(P, gd)
+    batch, target, target_h = g(T(gd["ray_batch"])), g(T(gd["target"])), g(T(gd["target_h"]))
+    args = _depth_args(gd)
+    step = Dp.DepthTrainStep(args, kw, opt, grad_vars, distributed=False)
+    # forward only first: every output of the dict
+    with torch.no_grad():
+        ret = Dp.render_rays(batch, retraw=True, pytest=True, **{k: v for k, v in kw.items()})
+    assert set(ret) == {"rgb_map", "disp_map", "acc_map", "depth_map", "z_vals", "weights", "pred_hyp", "u", "raw",
+                        "rgb0", "disp0", "acc0", "depth0", "z_vals0", "weights0", "z_std"}
+    assert torch.equal(ret["u"].cpu(), T(gd["render_u"]))
+    for k in ("rgb0", "acc0", "depth0", "disp0", "z_vals0", "weights0"):      # coarse pass: continuous, strict
+        assert_close(ret[k], gd["render_" + k], what=f"g8 {k}")
+    for k in ("rgb_map", "acc_map", "depth_map", "z_vals", "pred_hyp", "z_std"):
+        err = maxdiff(ret[k], T(gd["render_" + k]))
+        print(f"g8 {k}: max err {err:.3e}")
+        assert_close(ret[k], gd["render_" + k], atol=1e-4, rtol=1e-4, what=f"g8 {k}")
+    loss, img_loss, sc, _ = step(batch, target, target_h, pytest=True)
+    assert abs(float(loss) - float(gd["loss"])) <= 1e-5, (float(loss), float(gd["loss"]))
+    assert abs(float(sc) - float(gd["space_carving_loss"])) <= 1e-4, (float(sc), float(gd["space_carving_loss"]))
+    # parameters after the clipped Adam step (first step: every weight moves by ~lr, sign flips of tiny
+    # gradients show as 2*lr)
+    for net, tag in ((kw["network_fn"], "coarse"), (kw["network_fine"], "fine")):
+        for name, prm in net.named_parameters():
+            ref = T(gd[f"param_{tag}_{name}_sample"])
+            assert float((prm.detach().reshape(-1)[::stride].cpu() - ref).abs().max()) <= 1.25e-3, (tag, name)
+
+
+def test_depth_variant_gradients_vs_oracle(P):
+    """Gradients of the full depth-supervised loss (image + space carving through pred_hyp + coarse image) with
+    respect to both networks, HIP vs oracle on shared draws, before clipping.
+
+    The loss runs through the ill-conditioned closed form of the sampler (see
+    test_sampler_backward_vs_oracle_autograd): the fp32 oracle's own gradients sit ~1e-2 of max|g| away from
+    its fp64 gradients on the fine network.  Yardstick = fp64 oracle; bound = twice the fp32 oracle's own
+    distance from it (+5e-4), per network, plus a cosine check on the whole gradient."""
+    import sys
+    from plnerf_amd import depth as Dp
+    R, Ns, Ni = 48, 32, 48
+    gdummy = {"N_importance": Ni, "N_samples": Ns, "space_carving_weight": 0.05}
+    Dp, kw, grad_vars, opt = _depth_setup(P, gdummy)
+    batch, target = orc.synthetic_blender_rays(R, seed=11)
+    gen = torch.Generator().manual_seed(11)
+    t_rand, u_fine, u_hyp = torch.rand(R, Ns, generator=gen), torch.rand(R, Ni, generator=gen) * 0.999, \
+        torch.rand(R, Ni, generator=gen) * 0.999
+    target_h = 2.0 + 4.0 * torch.rand(3, R, 1, generator=gen)
+
+    def oracle(dt):
+        sd_c = {k: v.to(dt) for k, v in orc.closed_form_state_dict_depth(0, True).items()}
+        sd_f = {k: v.to(dt) for k, v in orc.closed_form_state_dict_depth(1, True).items()}
+        okw = dict(N_samples=Ns, N_importance=Ni, mode="linear", color_mode="midpoint", perturb=1.0, white_bkgd=True,
+                   t_rand=t_rand.to(dt), u_fine=u_fine.to(dt), cached_u=u_hyp.to(dt))
+        return orc.depth_train_step(sd_c, sd_f, batch.to(dt), target.to(dt), target_h.to(dt), okw,
+                                    space_carving_weight=0.05)
+    loss_o, sc_o, g_c32, g_f32 = oracle(torch.float32)
+    _, _, g_c64, g_f64 = oracle(torch.float64)
+    # HIP: same draws injected by patching the two draw helpers for this call
+    dmod = sys.modules[Dp.__name__]
+    rmod = sys.modules[Dp.__name__.rsplit(".", 1)[0] + ".render"]   # (the package attribute `render` is the function)
+    orig_perturb, orig_draw = dmod.perturb_z_vals, rmod._draw_u
+    try:
+        def fixed_perturb(z_vals, pytest):
+            mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+            upper = torch.cat([mids, z_vals[..., -1:]], -1)
+            lower = torch.cat([z_vals[..., :1], mids], -1)
+            return lower + (upper - lower) * g(t_rand)
+        dmod.perturb_z_vals = fixed_perturb
+        rmod._draw_u = lambda *a, **k: g(u_fine)
+        ret = Dp.render_rays(g(batch), retraw=True, cached_u=g(u_hyp), **kw)
+    finally:
+        dmod.perturb_z_vals, rmod._draw_u = orig_perturb, orig_draw
+    sc = Dp.compute_space_carving_loss(ret["pred_hyp"], g(target_h))
+    loss = P.img2mse(ret["rgb_map"], g(target)) + 0.05 * sc + P.img2mse(ret["rgb0"], g(target))
+    loss.backward()
+    print(f"depth loss HIP {float(loss.detach()):.6f} oracle {float(loss_o):.6f}; space carving "
+          f"{float(sc.detach()):.5f} / {float(sc_o):.5f}")
+    assert abs(float(loss.detach()) - float(loss_o)) <= 2e-5 and abs(float(sc.detach()) - float(sc_o)) <= 2e-4
+
+    def rel(a, b):
+        return float((a.double() - b).abs().max()) / (float(b.abs().max()) + 1e-300)
+    for net, g32, g64, tag in ((kw["network_fn"], g_c32, g_c64, "coarse"), (kw["network_fine"], g_f32, g_f64, "fine")):
+        e_hip = max(rel(prm.grad.cpu(), g64[name]) for name, prm in net.named_parameters())
+        e_orc = max(rel(g32[name], g64[name]) for name in g64)
+        flat_h = torch.cat([prm.grad.cpu().double().reshape(-1) for _, prm in net.named_parameters()])
+        flat_o = torch.cat([g64[name].reshape(-1) for name, _ in net.named_parameters()])
+        cos = float(torch.dot(flat_h, flat_o) / (flat_h.norm() * flat_o.norm()))
+        print(f"depth variant {tag} gradients vs fp64 oracle: HIP {e_hip:.3e}, fp32 oracle {e_orc:.3e}, cosine {cos:.7f}")
+        assert e_hip <= 2 * e_orc + 5e-4, (tag, e_hip, e_orc)
+        assert cos >= 0.9999, (tag, cos)
+
+
 def test_fused_adam_matches_torch(P):
     from plnerf_amd import _lib as L
     gen = torch.Generator().manual_seed(0)

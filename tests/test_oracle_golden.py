@@ -115,6 +115,38 @@ def test_g6_train_step(golden):
                       atol=2e-6, rtol=1e-5)
 
 
+def test_g8_depth_variant(golden):
+    """The depth-supervised restatement (oracle section 8f-1) against the reference's own outputs: network,
+    render_rays with the attached pred_hyp, space-carving loss, gradients and the clipped Adam step."""
+    g = golden("g8_depth_variant")
+    stride = int(g["sample_stride"])
+    sd_c, sd_f = orc.closed_form_state_dict_depth(0, True), orc.closed_form_state_dict_depth(1, True)
+    raw = orc.query_network_depth(sd_c, T(g["mlp_pts"]), T(g["mlp_viewdirs"]))
+    close(raw, g["mlp_raw"], atol=1e-6, rtol=1e-6)
+    flat = T(g["mlp_pts"]).reshape(-1, 3)
+    emb = torch.cat([orc.positional_encoding_pi(flat, 9),
+                     T(g["mlp_viewdirs"])[:, None].expand(6, 16, 3).reshape(-1, 3)], -1)
+    assert torch.equal(emb, T(g["mlp_embedded"]))
+    kw = dict(N_samples=int(g["N_samples"]), N_importance=int(g["N_importance"]), mode="linear",
+              color_mode="midpoint", perturb=1.0, white_bkgd=True, raw_noise_std=0.0, pytest=True)
+    with torch.no_grad():
+        ret = orc.render_rays_depth(T(g["ray_batch"]), sd_c, sd_f, **kw)
+    assert torch.equal(ret["u"], T(g["render_u"]))
+    for k in ("rgb_map", "disp_map", "acc_map", "depth_map", "z_vals", "weights", "pred_hyp", "raw", "rgb0", "disp0",
+              "acc0", "depth0", "z_vals0", "weights0", "z_std"):
+        close(ret[k], g["render_" + k], atol=2e-6, rtol=2e-5)
+    loss, sc, g_c, g_f = orc.depth_train_step(sd_c, sd_f, T(g["ray_batch"]), T(g["target"]), T(g["target_h"]), kw,
+                                              space_carving_weight=float(g["space_carving_weight"]))
+    close(loss, g["loss"], atol=1e-6, rtol=1e-6)
+    close(sc, g["space_carving_loss"], atol=1e-6, rtol=1e-6)
+    for tag, grads, sd in (("coarse", g_c, sd_c), ("fine", g_f, sd_f)):
+        for name, gr in grads.items():
+            ref_norm = float(g[f"grad_{tag}_{name}_norm"])
+            assert abs(float(gr.norm()) - ref_norm) <= 1e-5 * max(ref_norm, 1e-6) + 1e-9, (tag, name)
+            close(gr.reshape(-1)[::stride], g[f"grad_{tag}_{name}_sample"], atol=1e-7, rtol=2e-4)
+            close(sd[name].detach().reshape(-1)[::stride], g[f"param_{tag}_{name}_sample"], atol=2e-6, rtol=1e-5)
+
+
 def test_g7_rays(golden):
     g = golden("g7_rays")
     H, W, f = int(g["H"]), int(g["W"]), float(g["focal"])
