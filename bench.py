@@ -32,7 +32,8 @@ if ROOT not in sys.path:
 FWD_FLOP_PER_ROW = 1186816      # 2 x 593,408 MAC per network evaluation
 TRAIN_FLOP_PER_ROW = 3489024    # forward + wgrad + dgrad
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8 TB/s HBM3E
-FWD_TRAIN_BYTES_PER_ROW = 2596 * 4 + 12 + 16  # saved state (planes + masks) written, xyz read, raw written
+# training forward, algorithmic bytes per row: saved state written + xyz read (12) + raw written (16)
+FWD_TRAIN_BYTES_PER_ROW = {"fp32": 2596 * 4 + 28, "h16": 2528 * 2 + 272 + 28}   # fp32 planes | half planes + relu masks
 PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "f16x3": 2500.0, "f16": 2500.0}   # MI355X_MICROARCH.md, dense
 
 
@@ -168,12 +169,13 @@ def main():
         except Exception:
             traffic = None
         ach = rows_fine * FWD_FLOP_PER_ROW / (fwd_ms * 1e-3) / 1e12 if fwd_ms else None
-        # Which roofline binds the training forward: 1,186,816 FLOP against 10,412 algorithmic bytes per row
-        # (fp32 state planes 10,112 + relu masks 272 written, 12 read, 16 out) = 114 FLOP/B.  The ridge is
-        # 157.3 TF / 8 TB/s = 20 FLOP/B for fp32 MFMA (MFMA-bound) and 2.5 PF / 8 TB/s = 312 FLOP/B for the
-        # 16-bit MFMA modes (HBM-bound).
+        # Which roofline binds the training forward: 1,186,816 FLOP against the algorithmic bytes per row.
+        # fp32 mode: 10,412 B (fp32 planes) = 114 FLOP/B against a ridge of 157.3 TF / 8 TB/s = 20 FLOP/B:
+        # MFMA-bound.  16-bit modes: 5,356 B (half planes + relu masks) = 222 FLOP/B against a ridge of
+        # 2.5 PF / 8 TB/s = 312 FLOP/B: HBM-bound.
         hbm_bound = a.precision != "fp32"
-        ach_gbs = rows_fine * FWD_TRAIN_BYTES_PER_ROW / (fwd_ms * 1e-3) / 1e9 if fwd_ms else None
+        bytes_per_row = FWD_TRAIN_BYTES_PER_ROW["h16" if hbm_bound else "fp32"]
+        ach_gbs = rows_fine * bytes_per_row / (fwd_ms * 1e-3) / 1e9 if fwd_ms else None
         out = {
             "metric": "training rays/sec (coarse+fine, 64+128 samples)",
             "value": R * world * a.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": a.steps,
@@ -191,7 +193,7 @@ def main():
                 "unit": "GB/s" if hbm_bound else "TFLOP/s",
                 "frac": ((ach_gbs / HBM_PEAK_GBS) if hbm_bound else (ach / peak)) if ach else None,
                 "traffic": traffic, "launch_ms": fwd_ms, "rows_per_launch": rows_fine,
-                "bytes_per_row": FWD_TRAIN_BYTES_PER_ROW, "flop_per_row": FWD_FLOP_PER_ROW,
+                "bytes_per_row": bytes_per_row, "flop_per_row": FWD_FLOP_PER_ROW,
                 "mfma_tflops": ach, "mfma_peak_tflops": peak,
                 # MFMA work actually issued: bf16x3 spends 3 MFMAs per algorithmic product
                 "mfma_issue_frac": ((ach * {"fp32": 1, "bf16x3": 3, "bf16": 1, "f16x3": 3, "f16": 1}[a.precision] / peak) if ach else None),

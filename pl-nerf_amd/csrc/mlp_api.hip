@@ -37,15 +37,19 @@ extern "C" int plnerf_mlp_pack_weights(const float* const* params, int precision
                            (hipStream_t)stream);
 }
 
+// fp32 mode: fp32 planes; 16-bit MFMA modes: half planes (mlp_layout.h)
 extern "C" size_t plnerf_mlp_saved_bytes(int n_rows, int precision) {
     if (!known(precision) || n_rows < 0) return 0;
-    return (size_t)lay::SAVED_PER_ROW * (size_t)n_rows * sizeof(float);
+    if (precision == PLNERF_PREC_FP32) return (size_t)lay::SAVED_PER_ROW * (size_t)n_rows * sizeof(float);
+    return ((size_t)lay::SVH_BYTES_PER_ROW * (size_t)n_rows + 15) & ~(size_t)15;
 }
 
 extern "C" size_t plnerf_mlp_bwd_workspace_bytes(int n_rows, int precision) {
     if (!known(precision) || n_rows < 0) return 0;
-    return ((size_t)lay::DZ_PER_ROW * (size_t)n_rows + (size_t)lay::MAX_SPLITS * lay::PART_PER_SPLIT +
-            (size_t)lay::MAX_HEAD_WGS * lay::HEAD_PART) * sizeof(float);
+    const size_t partials = ((size_t)lay::MAX_SPLITS * lay::PART_PER_SPLIT + (size_t)lay::MAX_HEAD_WGS * lay::HEAD_PART) *
+                            sizeof(float);
+    if (precision == PLNERF_PREC_FP32) return (size_t)lay::DZ_PER_ROW * (size_t)n_rows * sizeof(float) + partials;
+    return impl::h16_dz_bytes(n_rows) + lay::WSH_SCALARS_BYTES + partials;
 }
 
 extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pts, const float* viewdirs,
@@ -74,12 +78,20 @@ extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_
     for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i)
         if (!grads[i]) return PLNERF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    float* dz = (float*)workspace;
-    int rc;
-    if (precision == PLNERF_PREC_FP32) rc = impl::f32_dgrad(packed, g_raw, n_rows, (const float*)saved, dz, st);
-    else rc = impl::bf16_dgrad(packed, ns_of(precision), f16_of(precision), g_raw, n_rows, (const float*)saved, dz, st);
+    if (precision == PLNERF_PREC_FP32) {
+        float* dz = (float*)workspace;
+        const int rc = impl::f32_dgrad(packed, g_raw, n_rows, (const float*)saved, dz, st);
+        if (rc) return rc;
+        return impl::wgrad(g_raw, n_rows, saved, dz, nullptr, dz + (size_t)lay::DZ_PER_ROW * (size_t)n_rows, grads,
+                           input_ch, input_ch_views, false, st);
+    }
+    // 16-bit modes: [dz half planes][max |g_raw|][partials]
+    unsigned char* ws = (unsigned char*)workspace;
+    unsigned* gmax = (unsigned*)(ws + impl::h16_dz_bytes(n_rows));
+    float* partials = (float*)(ws + impl::h16_dz_bytes(n_rows) + lay::WSH_SCALARS_BYTES);
+    int rc = impl::absmax(g_raw, (size_t)n_rows * 4, gmax, st);
     if (rc) return rc;
-    // weight gradients over the fp32 planes; the big 256x256 jobs use the mode's MFMA type
-    return impl::f32_wgrad(g_raw, n_rows, (const float*)saved, dz, grads, input_ch, input_ch_views, ns_of(precision), 0,
-                           st);
+    rc = impl::bf16_dgrad(packed, ns_of(precision), g_raw, n_rows, saved, ws, gmax, st);
+    if (rc) return rc;
+    return impl::wgrad(g_raw, n_rows, saved, ws, gmax, partials, grads, input_ch, input_ch_views, true, st);
 }

@@ -73,10 +73,10 @@ int bf16_fwd(const void* packed, int ns, int f16, const float* pts, const float*
                                           raw_out, saved, st);
 }
 
-int bf16_dgrad(const void* packed, int ns, int f16, const float* g_raw, int n_rows, const float* saved, float* dz,
-               hipStream_t st) {
-    (void)f16;   // backward GEMMs always run on bf16 operands (see bf16_pack)
-    return plnerf_h16_bf16::h16_dgrad(packed, ns, g_raw, n_rows, saved, dz, st);
+int bf16_dgrad(const void* packed, int ns, const float* g_raw, int n_rows, const void* saved, void* dz,
+               const unsigned* gmax, hipStream_t st) {
+    // backward GEMMs always run on bf16 operands (see bf16_pack)
+    return plnerf_h16_bf16::h16_dgrad(packed, ns, g_raw, n_rows, saved, dz, gmax, st);
 }
 
 }  // namespace impl

@@ -36,6 +36,10 @@
 using namespace plnerf;
 using namespace plnerf::lay;
 
+#ifndef PLNERF_WG_SPLITS
+#define PLNERF_WG_SPLITS 112
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -464,8 +468,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_f32_kernel(BwdArgs a) {
 // backward: weight gradients, split-K TN GEMM  C[o][i] = sum_m A[m][o] B[m][i]
 // ------------------------------------------------------------------------------------
 struct WJob {
-    const float* A;   // dz plane, row stride lda
-    const float* B;   // activation plane, row stride ldb
+    const void* A;    // dz plane (fp32 or half elements), row stride lda elements
+    const void* B;    // activation plane, row stride ldb elements
     int lda, ldb, O, I;
     int part_off;     // offset (floats) of this job's [O][I] partial inside a split block
     int bias_off;     // offset of the [O] bias partial, or -1
@@ -492,8 +496,8 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradArgs a) {
     const int m_begin = split * a.rows_per_split;
     const int m_end = min(a.n_rows, m_begin + a.rows_per_split);
     const int kh = lane >> 5, ll = lane & 31;
-    const float* Ap = job.A + o_base + ll;
-    const float* Bp = job.B + i_base + ll;
+    const float* Ap = (const float*)job.A + o_base + ll;
+    const float* Bp = (const float*)job.B + i_base + ll;
     f32x16 acc[NO][NI];
     zero_acc(acc);
     float bsum[NO];
@@ -554,152 +558,47 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradArgs a) {
     }
 }
 
-// The same TN GEMM on v_mfma_f32_32x32x16_bf16 for the bf16 / bf16x3 modes.  The operands are
-// still the fp32 [row][feature] planes: a lane builds its k-contiguous fragment (8 consecutive
-// rows of one feature column) from 8 coalesced dword loads and splits it into bf16 hi (+ lo) in
-// registers, so no transposed copy of the activations is ever stored.  One load buffer per
-// operand: fragments are built from it, then the next 16 rows are requested into the same
-// registers and arrive while this step's NO*NI*(1|3) MFMAs run.
-// 8 waves as 4(o) x 2(i), each 64(o) x 128(i): a 256 x 256 workgroup tile reads every plane once.
-typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
-
-template <int NS>
-__device__ __forceinline__ void split_frag(const float (&v)[8], wbf16x8& hi, wbf16x8& lo) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        hi[e] = (__bf16)v[e];
-        if (NS == 2) lo[e] = (__bf16)(v[e] - (float)hi[e]);
-    }
-}
-
-template <int NS, int NI>
-__global__ __launch_bounds__(512) void wgrad_bf16_kernel(WgradArgs a) {
-    constexpr int NO = 2, WI = 2;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const WJob job = a.jobs[a.tile_job[blockIdx.x]];
-    const int wo = wave / WI, wi = wave % WI;
-    const int o_base = a.tile_o0[blockIdx.x] + wo * NO * 32;
-    const int i_base = wi * NI * 32;
-    const bool o_live = o_base < job.O && i_base < job.I;   // O = 128 / I = 32 jobs: surplus waves idle
-    const int split = blockIdx.y;
-    const int m_begin = split * a.rows_per_split;
-    const int m_end = min(a.n_rows, m_begin + a.rows_per_split);
-    const int g8 = 8 * (lane >> 5), ll = lane & 31;
-    const float* Ap = job.A + (o_live ? o_base : 0) + ll;
-    const float* Bp = job.B + (o_live ? i_base : 0) + ll;
-    if (!o_live) return;
-    f32x16 acc[NO][NI];
-    zero_acc(acc);
-    float bsum[NO];
-#pragma unroll
-    for (int o = 0; o < NO; ++o) bsum[o] = 0.0f;
-    float av[NO][8], bv[NI][8];
-    auto load = [&](int m) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int mm = m + g8 + e;
-            const bool ok = mm < m_end;
-#pragma unroll
-            for (int o = 0; o < NO; ++o) av[o][e] = ok ? Ap[(size_t)mm * job.lda + o * 32] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < NI; ++i) bv[i][e] = ok ? Bp[(size_t)mm * job.ldb + i * 32] : 0.0f;
-        }
-    };
-    if (m_begin < m_end) load(m_begin);
-    for (int m = m_begin; m < m_end; m += 16) {
-        wbf16x8 ah[NO], al[NO], bh[NI], bl[NI];
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            split_frag<NS>(av[o], ah[o], al[o]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bsum[o] += av[o][e];
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) split_frag<NS>(bv[i], bh[i], bl[i]);
-        if (m + 16 < m_end) load(m + 16);
-#pragma unroll
-        for (int o = 0; o < NO; ++o)
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                acc[o][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[o], bh[i], acc[o][i], 0, 0, 0);
-                if (NS == 2) {
-                    acc[o][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[o], bh[i], acc[o][i], 0, 0, 0);
-                    acc[o][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[o], bl[i], acc[o][i], 0, 0, 0);
-                }
-            }
-    }
-    float* part = a.part + (size_t)split * PART_PER_SPLIT;
-    float* cpart = part + job.part_off;
-#pragma unroll
-    for (int o = 0; o < NO; ++o)
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int orow = o_base + o * 32 + frag_row(r, lane);
-                const int icol = i_base + i * 32 + ll;
-                cpart[(size_t)orow * job.I + icol] = acc[o][i][r];
-            }
-    if (job.bias_off >= 0 && wi == 0) {
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            const float b = bsum[o] + __shfl_xor(bsum[o], 32);
-            if (lane < 32) part[job.bias_off + o_base + o * 32 + ll] = b;
-        }
-    }
-}
-
-// LDS-staged version of the bf16-MFMA weight gradient (the one the launcher uses).  The register
-// version above spends ~14 VALU instructions per MFMA re-splitting every operand value in each of
-// the 2-4 waves that need it (measured: VALU-bound, 24 % MFMA busy).  Here a workgroup loads each
-// 16-row slab of dz / activations ONCE with coalesced 16-byte loads, splits each value ONCE into
-// bf16 hi (+ lo), and stores the slab row-major in LDS; waves then build their k-contiguous MFMA
-// fragments with ds_read_b64_tr_b16, the gfx950 transposing LDS read (lane = feature column,
-// 4 consecutive rows per read; row stride 576 B puts the 4 rows of a read on disjoint banks).
-// Stage k+1 is fetched into registers before stage k's MFMAs and converted/written after them;
-// one barrier per stage.
+// The same TN GEMM for the 16-bit MFMA modes, on v_mfma_f32_32x32x16_f16 over the HALF planes of
+// mlp_layout.h (both operands are stored in half by the training forward / the dgrad kernel, so one
+// MFMA per product; the dz planes carry a power-of-two scale that the reduction divides out).
+// A workgroup loads each 16-row slab of dz / activations ONCE with coalesced 16-byte loads and stores
+// it row-major in LDS; waves then build their k-contiguous MFMA fragments with ds_read_b64_tr_b16,
+// the gfx950 transposing LDS read (lane = feature column, 4 consecutive rows per read; row stride
+// 576 B puts the 4 rows of a read on disjoint banks; semantics pinned by tools/probes/tr16_probe.hip).
+// Stage k+1 is fetched into registers before stage k's MFMAs and written to LDS after them; one
+// barrier per stage.  8 waves as 4(o) x 2(i), each 64(o) x 32 NI(i): a 256 x 256 workgroup tile
+// reads every plane once.  (History: a register-only version re-split fp32 operands in every wave
+// and was VALU-bound, 24 % MFMA busy -- profiles/r01_bf16x3_pmc_sq_tcp_before_lds_wgrad.txt.)
 typedef short v4s16 __attribute__((ext_vector_type(4)));
+typedef _Float16 wh8 __attribute__((ext_vector_type(8)));
 constexpr int TR_ROWS = 16;            // rows per stage = one MFMA k-step
-constexpr int TR_RS = 288;             // LDS row stride in 16-bit elements (256 + 32): 576 B
+constexpr int TR_RS = 288;             // LDS row stride in half elements (256 + 32): 576 B
 constexpr int TR_PLANE = TR_ROWS * TR_RS;
 
-// the 32x32x16 MFMA of the element type
-__device__ __forceinline__ f32x16 mfma16(__bf16 __attribute__((ext_vector_type(8))) a,
-                                         __bf16 __attribute__((ext_vector_type(8))) b, f32x16 c, int, int, int) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 mfma16(_Float16 __attribute__((ext_vector_type(8))) a,
-                                         _Float16 __attribute__((ext_vector_type(8))) b, f32x16 c, int, int, int) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-
-template <typename T>
-__device__ __forceinline__ T __attribute__((ext_vector_type(8))) tr_frag(const T* plane, int lane, int col0) {
-    typedef T vec8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ wh8 tr_frag(const _Float16* plane, int lane, int col0) {
     // 8 consecutive rows (k) of column col0 + (lane & 31), rows 8 * (lane >> 5) .. +7
     const int lam = lane & 15, gam = lane >> 4;
     const int row = 8 * (gam >> 1) + (lam >> 2), col = col0 + 16 * (gam & 1) + 4 * (lam & 3);
-    const T* p = plane + row * TR_RS + col;
+    const _Float16* p = plane + row * TR_RS + col;
     typedef __attribute__((address_space(3))) v4s16* lds_v4;
     const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)p);
     const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p + 4 * TR_RS));
-    union { v4s16 h[2]; vec8 v; } u;
+    union { v4s16 h[2]; wh8 v; } u;
     u.h[0] = lo;
     u.h[1] = hi;
     return u.v;
 }
 
-template <typename T, int NS, int NI>
-__global__ __launch_bounds__(512) void wgrad_tr_kernel(WgradArgs a) {
-    typedef T vec8 __attribute__((ext_vector_type(8)));
+template <int NI>
+__global__ __launch_bounds__(512) void wgrad_tr16_kernel(WgradArgs a) {
     constexpr int NO = 2, WI = 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    // [buffer 2][operand A,B][plane NS][TR_ROWS][TR_RS]
-    T* lds = reinterpret_cast<T*>(smem_raw);
+    _Float16* lds = reinterpret_cast<_Float16*>(smem_raw);   // [buffer 2][operand A,B][TR_ROWS][TR_RS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const WJob job = a.jobs[a.tile_job[blockIdx.x]];
+    const _Float16* Ag = (const _Float16*)job.A;
+    const _Float16* Bg = (const _Float16*)job.B;
     const int wo = wave / WI, wi = wave % WI;
     const int o_base = a.tile_o0[blockIdx.x] + wo * NO * 32;
     const int i_base = wi * NI * 32;
@@ -707,51 +606,31 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(WgradArgs a) {
     const int split = blockIdx.y;
     const int m_begin = split * a.rows_per_split;
     const int m_end = min(a.n_rows, m_begin + a.rows_per_split);
-    const int a_f4 = job.O >> 2, b_f4 = job.I >> 2;      // float4 per row of each operand
-    // this thread's (row, float4) slots in the 16-row slab: up to 2 for A and 2 for B
-    int a_row[2], a_col[2], b_row[2], b_col[2];
+    // this thread's (row, 8-half chunk) slot in the 16-row slab of each operand (O, I <= 256: one each)
+    const int a_c8 = job.O >> 3, b_c8 = job.I >> 3;
+    const int a_row = tid / a_c8, a_col = (tid - a_row * a_c8) * 8;
+    const int b_row = tid / b_c8, b_col = (tid - b_row * b_c8) * 8;
+    wh8 ra, rb;
+    float bs[8];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int q = tid + 512 * j;
-        a_row[j] = q / a_f4; a_col[j] = (q - a_row[j] * a_f4) * 4;
-        b_row[j] = q / b_f4; b_col[j] = (q - b_row[j] * b_f4) * 4;
-    }
-    float4 ra[2], rb[2];
-    float4 bs[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    for (int e = 0; e < 8; ++e) bs[e] = 0.0f;
     auto fetch = [&](int m) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a_row[j] < TR_ROWS && m + a_row[j] < m_end)
-                ra[j] = *reinterpret_cast<const float4*>(job.A + (size_t)(m + a_row[j]) * job.lda + a_col[j]);
-            if (b_row[j] < TR_ROWS && m + b_row[j] < m_end)
-                rb[j] = *reinterpret_cast<const float4*>(job.B + (size_t)(m + b_row[j]) * job.ldb + b_col[j]);
-        }
-    };
-    auto put = [&](T* dst, const float4& v) {   // dst = hi plane slot; lo plane is NS-1 planes later
-        const float x[4] = {v.x, v.y, v.z, v.w};
-        typedef T b4 __attribute__((ext_vector_type(4)));
-        b4 h, l;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            h[e] = (T)x[e];
-            l[e] = (T)(x[e] - (float)h[e]);
-        }
-        *reinterpret_cast<b4*>(dst) = h;
-        if (NS == 2) *reinterpret_cast<b4*>(dst + TR_PLANE) = l;
+        for (int e = 0; e < 8; ++e) { ra[e] = (_Float16)0.0f; rb[e] = (_Float16)0.0f; }
+        if (a_row < TR_ROWS && m + a_row < m_end)
+            ra = *reinterpret_cast<const wh8*>(Ag + (size_t)(m + a_row) * job.lda + a_col);
+        if (b_row < TR_ROWS && m + b_row < m_end)
+            rb = *reinterpret_cast<const wh8*>(Bg + (size_t)(m + b_row) * job.ldb + b_col);
     };
     auto stash = [&](int buf) {
-        T* A0 = lds + (size_t)buf * 2 * NS * TR_PLANE;
-        T* B0 = A0 + NS * TR_PLANE;
+        _Float16* A0 = lds + (size_t)buf * 2 * TR_PLANE;
+        _Float16* B0 = A0 + TR_PLANE;
+        if (a_row < TR_ROWS) {
+            *reinterpret_cast<wh8*>(A0 + a_row * TR_RS + a_col) = ra;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (a_row[j] < TR_ROWS) {
-                put(A0 + a_row[j] * TR_RS + a_col[j], ra[j]);
-                bs[j].x += ra[j].x; bs[j].y += ra[j].y; bs[j].z += ra[j].z; bs[j].w += ra[j].w;
-            }
-            if (b_row[j] < TR_ROWS) put(B0 + b_row[j] * TR_RS + b_col[j], rb[j]);
+            for (int e = 0; e < 8; ++e) bs[e] += (float)ra[e];
         }
+        if (b_row < TR_ROWS) *reinterpret_cast<wh8*>(B0 + b_row * TR_RS + b_col) = rb;
     };
     f32x16 acc[NO][NI];
     zero_acc(acc);
@@ -765,29 +644,18 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(WgradArgs a) {
         const bool more = m + TR_ROWS < m_end;
         if (more) fetch(m + TR_ROWS);
         if (live) {
-            const T* A0 = lds + (size_t)buf * 2 * NS * TR_PLANE;
-            const T* B0 = A0 + NS * TR_PLANE;
-            vec8 ah[NO], al[NO], bh[NI], bl[NI];
+            const _Float16* A0 = lds + (size_t)buf * 2 * TR_PLANE;
+            const _Float16* B0 = A0 + TR_PLANE;
+            wh8 af[NO], bf[NI];
 #pragma unroll
-            for (int o = 0; o < NO; ++o) {
-                ah[o] = tr_frag(A0, lane, o_base + 32 * o);
-                if (NS == 2) al[o] = tr_frag(A0 + TR_PLANE, lane, o_base + 32 * o);
-            }
+            for (int o = 0; o < NO; ++o) af[o] = tr_frag(A0, lane, o_base + 32 * o);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                bh[i] = tr_frag(B0, lane, i_base + 32 * i);
-                if (NS == 2) bl[i] = tr_frag(B0 + TR_PLANE, lane, i_base + 32 * i);
-            }
+            for (int i = 0; i < NI; ++i) bf[i] = tr_frag(B0, lane, i_base + 32 * i);
 #pragma unroll
             for (int o = 0; o < NO; ++o)
 #pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    acc[o][i] = mfma16(ah[o], bh[i], acc[o][i], 0, 0, 0);
-                    if (NS == 2) {
-                        acc[o][i] = mfma16(al[o], bh[i], acc[o][i], 0, 0, 0);
-                        acc[o][i] = mfma16(ah[o], bl[i], acc[o][i], 0, 0, 0);
-                    }
-                }
+                for (int i = 0; i < NI; ++i)
+                    acc[o][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[o], bf[i], acc[o][i], 0, 0, 0);
         }
         if (more) stash(buf ^ 1);
         __syncthreads();
@@ -808,12 +676,13 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(WgradArgs a) {
                 }
     }
     if (job.bias_off >= 0) {
-        // bias partial = column sums of the dz slab: every thread summed its (row-slot, 4 features)
-        float* red = reinterpret_cast<float*>(smem_raw);      // [slot 0..(512*2/a_f4)-1][O] -> reuse LDS
+        // bias partial = column sums of the dz slab: every thread summed its (row slot, 8 features)
+        float* red = reinterpret_cast<float*>(smem_raw);      // [TR_ROWS][O] floats (<= 16 KB), reusing the LDS
         __syncthreads();
+        if (a_row < TR_ROWS) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            if (a_row[j] < TR_ROWS) *reinterpret_cast<float4*>(red + a_row[j] * job.O + a_col[j]) = bs[j];
+            for (int e = 0; e < 8; ++e) red[a_row * job.O + a_col + e] = bs[e];
+        }
         __syncthreads();
         for (int f = tid; f < job.O; f += 512) {
             float sum = 0.0f;
@@ -824,15 +693,17 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(WgradArgs a) {
 }
 
 // sigma / rgb heads: dW_alpha = sum_m g_sigma h7, dW_rgb[c] = sum_m g_c hv, and their biases
+template <typename PT>
 struct HeadArgs {
     const float* g_raw;
-    const float* h7;
-    const float* hv;
+    const PT* h7;     // saved planes: float (fp32 mode) or _Float16 (16-bit modes)
+    const PT* hv;
     int n_rows, rows_per_wg;
     float* part;  // [n_wg][HEAD_PART]
 };
 
-__global__ __launch_bounds__(256) void wgrad_head_kernel(HeadArgs a) {
+template <typename PT>
+__global__ __launch_bounds__(256) void wgrad_head_kernel(HeadArgs<PT> a) {
     __shared__ float red[8][4];
     __shared__ float rgbred[128][3];
     const int tid = threadIdx.x;
@@ -849,10 +720,10 @@ __global__ __launch_bounds__(256) void wgrad_head_kernel(HeadArgs a) {
     for (int p = 0; p < m_pairs; ++p) {
         const int m = m_begin + 2 * p;
         const float4 g0 = g4[m], g1 = g4[m + 1];
-        wa = fmaf(g0.w, a.h7[(size_t)m * W + tid], wa);
-        wa = fmaf(g1.w, a.h7[(size_t)(m + 1) * W + tid], wa);
+        wa = fmaf(g0.w, (float)a.h7[(size_t)m * W + tid], wa);
+        wa = fmaf(g1.w, (float)a.h7[(size_t)(m + 1) * W + tid], wa);
         const float4 g = half ? g1 : g0;
-        const float h = a.hv[(size_t)(m + half) * HV + ci];
+        const float h = (float)a.hv[(size_t)(m + half) * HV + ci];
         r0 = fmaf(g.x, h, r0);
         r1 = fmaf(g.y, h, r1);
         r2 = fmaf(g.z, h, r2);
@@ -860,9 +731,9 @@ __global__ __launch_bounds__(256) void wgrad_head_kernel(HeadArgs a) {
     if ((m_end - m_begin) & 1) {
         const int m = m_end - 1;
         const float4 g = g4[m];
-        wa = fmaf(g.w, a.h7[(size_t)m * W + tid], wa);
+        wa = fmaf(g.w, (float)a.h7[(size_t)m * W + tid], wa);
         if (half == 0) {
-            const float h = a.hv[(size_t)m * HV + ci];
+            const float h = (float)a.hv[(size_t)m * HV + ci];
             r0 = fmaf(g.x, h, r0);
             r1 = fmaf(g.y, h, r1);
             r2 = fmaf(g.z, h, r2);
@@ -891,21 +762,27 @@ __global__ __launch_bounds__(256) void wgrad_head_kernel(HeadArgs a) {
     }
 }
 
+constexpr int WG_SPLITS = PLNERF_WG_SPLITS;
+constexpr int HEAD_OUT = 644;   // dW_alpha 256, dW_rgb 384, b_alpha 1, b_rgb 3
 struct ReduceArgs {
     const float* part;
     const float* head_part;
     int splits, n_head;
+    const unsigned* gmax;   // 16-bit modes: the dz planes were scaled by 2^(DZH_TARGET_EXP - exponent(max |g_raw|))
     GradPtrs G;
 };
 
 __global__ void wgrad_reduce_kernel(ReduceArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= PART_PER_SPLIT + HEAD_PART) return;
+    if (idx >= PART_PER_SPLIT + HEAD_OUT * 64) return;
     if (idx >= PART_PER_SPLIT) {
-        const int h = idx - PART_PER_SPLIT;
-        if (h >= 644) return;
+        // head partials: one wavefront per output element (up to 512 partials each; a single thread walking
+        // them was the longest thing in this kernel)
+        const int r = idx - PART_PER_SPLIT, h = r >> 6, lane = r & 63;
         float s = 0.0f;
-        for (int w = 0; w < a.n_head; ++w) s += a.head_part[(size_t)w * HEAD_PART + h];
+        for (int w = lane; w < a.n_head; w += 64) s += a.head_part[(size_t)w * HEAD_PART + h];
+        s = wave_sum(s);
+        if (lane != 0) return;
         if (h < 256) a.G.p[P_WA][h] = s;
         else if (h < 640) a.G.p[P_WR][h - 256] = s;
         else if (h == 640) a.G.p[P_BA][0] = s;
@@ -915,6 +792,14 @@ __global__ void wgrad_reduce_kernel(ReduceArgs a) {
     float s = 0.0f;
 #pragma unroll 8
     for (int sp = 0; sp < a.splits; ++sp) s += a.part[(size_t)sp * PART_PER_SPLIT + idx];
+    if (a.gmax) {   // undo the power-of-two scale of the half dz planes (exact)
+        const float gm = __uint_as_float(*a.gmax);
+        if (gm > 0.0f && gm < __builtin_inff()) {
+            int e;
+            (void)frexpf(gm, &e);
+            s = ldexpf(s, e - (int)DZH_TARGET_EXP);
+        }
+    }
     if (idx < PART_VMAIN) {
         const int job = idx >> 16, r = idx & 65535, o = r >> 8, i = r & 255;
         // jobs: L1, L2, L3, L4, L5 (hidden part), L6, L7, feature
@@ -958,28 +843,28 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     p[i] = p[i] - step_size * (mi / denom);
 }
 
-// launch wgrad_tr_kernel for (element type, planes)
-template <typename T, int NS, int NI>
-inline void launch_tr_one(dim3 grid, size_t lds, hipStream_t st, const WgradArgs& a) {
-    (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel<T, NS, NI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    hipLaunchKernelGGL((wgrad_tr_kernel<T, NS, NI>), grid, dim3(512), lds, st, a);
-}
-template <int NI>
-inline void launch_tr(int ns, int f16, dim3 grid, size_t lds, hipStream_t st, const WgradArgs& a) {
-    if (f16) {
-        if (ns == 1) launch_tr_one<_Float16, 1, NI>(grid, lds, st, a);
-        else launch_tr_one<_Float16, 2, NI>(grid, lds, st, a);
-    } else {
-        if (ns == 1) launch_tr_one<__bf16, 1, NI>(grid, lds, st, a);
-        else launch_tr_one<__bf16, 2, NI>(grid, lds, st, a);
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, unsigned* out) {
+    float m = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = fabsf(x[i]);
+        m = (v > m || v != v) ? v : m;          // a NaN sticks (and compares above every float as bits)
     }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_xor(m, d);
+        m = (o > m || o != o) ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
+// Row ranges of the split-K weight gradient.  The grid is (9 tiles) x splits workgroups of 512 threads and
+// 36 KB of LDS, 4 resident per CU = 1024 slots: 112 splits = 1008 workgroups run as exactly one wave
+// (128 = one wave + a 12 % tail: +1 % step time; 56 and 28, at 2 and 1 per CU, hide less latency:
+// +4 % and +14 %).
 inline int splits_for(int n_rows) {
     int s = (n_rows + 1023) / 1024;
     if (s < 1) s = 1;
-    if (s > MAX_SPLITS) s = MAX_SPLITS;
+    if (s > WG_SPLITS) s = WG_SPLITS;
     return s;
 }
 inline int head_wgs_for(int n_rows) {
@@ -1045,22 +930,38 @@ int f32_dgrad(const void* packed, const float* g_raw, int n_rows, const float* s
 
 // Weight gradients from the fp32 planes (saved activations + dz planes written by any of the
 // dgrad kernels): split-K partials, head reductions, deterministic final sum into grads[24].
-int f32_wgrad(const float* g_raw, int n_rows, const float* sv, float* dz, float* const* grads, int xyz_ch, int dir_ch, int ns,
-              int f16, hipStream_t st) {
+int absmax(const float* x, size_t n, unsigned* out, hipStream_t st) {
+    if (hipMemsetAsync(out, 0, sizeof(unsigned), st) != hipSuccess) return PLNERF_ELAUNCH;
+    const int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, x, n, out);
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}
+
+template <int NI>
+inline void launch_tr16(dim3 grid, hipStream_t st, const WgradArgs& a) {
+    const size_t lds = (size_t)2 * 2 * TR_PLANE * sizeof(_Float16);   // 2 buffers x {A, B}
+    hipLaunchKernelGGL((wgrad_tr16_kernel<NI>), grid, dim3(512), lds, st, a);
+}
+
+int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, const unsigned* gmax, float* part,
+          float* const* grads, int xyz_ch, int dir_ch, bool h16, hipStream_t st) {
     const size_t N = (size_t)n_rows;
-    float* part = dz + (size_t)DZ_PER_ROW * N;
+    const size_t es = h16 ? sizeof(_Float16) : sizeof(float);        // plane element size
     float* head_part = part + (size_t)MAX_SPLITS * PART_PER_SPLIT;
     const int splits = splits_for(n_rows);
     int rps = (n_rows + splits - 1) / splits;
     rps = (rps + 15) & ~15;
-    auto splane = [&](int p) { return sv + (size_t)p * W * N; };
-    auto dplane = [&](int p) { return dz + (size_t)p * W * N; };
-    const float* hv_plane = sv + (size_t)SV_HV_OFF * N;
-    const float* pe_plane = sv + (size_t)SV_PE_OFF * N;
-    const float* dpe_plane = sv + (size_t)SV_DPE_OFF * N;
-    const float* dzv_plane = dz + (size_t)DZ_V_OFF * N;
+    const unsigned char* sv = (const unsigned char*)saved;
+    const unsigned char* dz = (const unsigned char*)dzv;
+    auto splane = [&](int p) { return (const void*)(sv + (size_t)p * W * N * es); };
+    auto dplane = [&](int p) { return (const void*)(dz + (size_t)p * W * N * es); };
+    const void* hv_plane = sv + (size_t)SV_HV_OFF * N * es;
+    const void* pe_plane = sv + (size_t)SV_PE_OFF * N * es;
+    const void* dpe_plane = sv + (size_t)SV_DPE_OFF * N * es;
+    const void* dzv_plane = dz + (size_t)DZ_V_OFF * N * es;
     {
-        // main: 128(o) x 256(i) workgroup tiles
+        // main: 256 x 256 layer jobs + the view layer's feature columns
         WgradArgs a{};
         const int layer_of_job[8] = {1, 2, 3, 4, 5, 6, 7, -1};
         int nt = 0;
@@ -1079,69 +980,59 @@ int f32_wgrad(const float* g_raw, int n_rows, const float* sv, float* dz, float*
             jb.lda = W; jb.ldb = W; jb.O = W; jb.I = W;
             jb.part_off = PART_MAIN + j * W * W;
             a.tile_job[nt] = j; a.tile_o0[nt++] = 0;
-            if (ns == 0) { a.tile_job[nt] = j; a.tile_o0[nt++] = 128; }   // f32 kernel: 128-row o tiles
+            if (!h16) { a.tile_job[nt] = j; a.tile_o0[nt++] = 128; }   // f32 kernel: 128-row o tiles
         }
         WJob& jv = a.jobs[8];
         jv.A = dzv_plane; jv.lda = HV; jv.B = splane(SV_FEAT); jv.ldb = W; jv.O = HV; jv.I = W;
         jv.part_off = PART_VMAIN; jv.bias_off = PART_BIAS + 9 * W;
         a.tile_job[nt] = 8; a.tile_o0[nt++] = 0;
         a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
-        if (ns == 0) hipLaunchKernelGGL((wgrad_f32_kernel<2, 2, 2, 4, 4>), dim3(nt, splits), dim3(256), 0, st, a);
-        else {
-            const size_t lds = (size_t)2 * 2 * ns * TR_PLANE * 2;   // 2 buffers x {A,B} x planes, 16-bit elements
-            launch_tr<4>(ns, f16, dim3(nt, splits), lds, st, a);
-        }
+        if (!h16) hipLaunchKernelGGL((wgrad_f32_kernel<2, 2, 2, 4, 4>), dim3(nt, splits), dim3(256), 0, st, a);
+        else launch_tr16<4>(dim3(nt, splits), st, a);
         PLNERF_CHECK_LAUNCH();
     }
-    if (ns == 0) {
-        {
-            // encoding parts: 256(o) x 64(i)
-            WgradArgs a{};
-            a.jobs[0] = WJob{dplane(0), pe_plane, W, PE_K, W, PE_K, PART_PE0, PART_BIAS + 0 * W};
-            a.jobs[1] = WJob{dplane(5), pe_plane, W, PE_K, W, PE_K, PART_PE5, -1};
-            a.tile_job[0] = 0; a.tile_o0[0] = 0;
-            a.tile_job[1] = 1; a.tile_o0[1] = 0;
-            a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
-            hipLaunchKernelGGL((wgrad_f32_kernel<4, 1, 2, 2, 4>), dim3(2, splits), dim3(256), 0, st, a);
-            PLNERF_CHECK_LAUNCH();
-        }
-        {
-            // view layer, direction-encoding part: 128(o) x 32(i)
-            WgradArgs a{};
-            a.jobs[0] = WJob{dzv_plane, dpe_plane, HV, DPE_K, HV, DPE_K, PART_VDIR, -1};
-            a.tile_job[0] = 0; a.tile_o0[0] = 0;
-            a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
-            hipLaunchKernelGGL((wgrad_f32_kernel<4, 1, 1, 1, 8>), dim3(1, splits), dim3(256), 0, st, a);
-            PLNERF_CHECK_LAUNCH();
-        }
-    } else {
-        // the three thin jobs (encoding columns of L0 / L5, direction columns of the view layer) on the
-        // bf16-MFMA kernel with 32-wide i slabs
+    {
+        // the three thin jobs: encoding columns of L0 / L5 (256 x 64), direction columns of the view layer (128 x 32)
         WgradArgs a{};
         a.jobs[0] = WJob{dplane(0), pe_plane, W, PE_K, W, PE_K, PART_PE0, PART_BIAS + 0 * W};
         a.jobs[1] = WJob{dplane(5), pe_plane, W, PE_K, W, PE_K, PART_PE5, -1};
         a.jobs[2] = WJob{dzv_plane, dpe_plane, HV, DPE_K, HV, DPE_K, PART_VDIR, -1};
         for (int t = 0; t < 3; ++t) { a.tile_job[t] = t; a.tile_o0[t] = 0; }
         a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
-        const size_t lds = (size_t)2 * 2 * ns * TR_PLANE * 2;
-        launch_tr<1>(ns, f16, dim3(3, splits), lds, st, a);
+        if (h16) {
+            launch_tr16<1>(dim3(3, splits), st, a);
+        } else {
+            hipLaunchKernelGGL((wgrad_f32_kernel<4, 1, 2, 2, 4>), dim3(2, splits), dim3(256), 0, st, a);
+            PLNERF_CHECK_LAUNCH();
+            WgradArgs v{};
+            v.jobs[0] = a.jobs[2];
+            v.tile_job[0] = 0; v.tile_o0[0] = 0;
+            v.n_rows = n_rows; v.rows_per_split = rps; v.part = part;
+            hipLaunchKernelGGL((wgrad_f32_kernel<4, 1, 1, 1, 8>), dim3(1, splits), dim3(256), 0, st, v);
+        }
         PLNERF_CHECK_LAUNCH();
     }
     const int n_head = head_wgs_for(n_rows);
-    {
-        HeadArgs a{g_raw, splane(7), hv_plane, n_rows, (n_rows + n_head - 1) / n_head, head_part};
-        hipLaunchKernelGGL(wgrad_head_kernel, dim3(n_head), dim3(256), 0, st, a);
-        PLNERF_CHECK_LAUNCH();
+    if (h16) {
+        HeadArgs<_Float16> a{g_raw, (const _Float16*)splane(7), (const _Float16*)hv_plane, n_rows,
+                             (n_rows + n_head - 1) / n_head, head_part};
+        hipLaunchKernelGGL(wgrad_head_kernel<_Float16>, dim3(n_head), dim3(256), 0, st, a);
+    } else {
+        HeadArgs<float> a{g_raw, (const float*)splane(7), (const float*)hv_plane, n_rows,
+                          (n_rows + n_head - 1) / n_head, head_part};
+        hipLaunchKernelGGL(wgrad_head_kernel<float>, dim3(n_head), dim3(256), 0, st, a);
     }
+    PLNERF_CHECK_LAUNCH();
     {
         ReduceArgs a{};
         a.part = part; a.head_part = head_part; a.splits = splits; a.n_head = n_head;
+        a.gmax = h16 ? gmax : nullptr;
         a.G.xyz_ch = xyz_ch; a.G.dir_ch = dir_ch;
         for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i) {
             if (!grads[i]) return PLNERF_EINVAL;
             a.G.p[i] = grads[i];
         }
-        const int total = PART_PER_SPLIT + HEAD_PART;
+        const int total = PART_PER_SPLIT + HEAD_OUT * 64;   // PART_PER_SPLIT is a multiple of 64: head waves stay whole
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a);
         PLNERF_CHECK_LAUNCH();
     }

