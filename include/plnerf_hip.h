@@ -39,15 +39,16 @@ extern "C" {
 /* colour rule of the linear mode: run_plnerf.py:581 / :593 */
 #define PLNERF_COLOR_MIDPOINT 0
 #define PLNERF_COLOR_LEFT 1
-/* arithmetic of the MLP contractions */
-#define PLNERF_PREC_FP32 0   /* v_mfma_f32_32x32x2_f32: exact fp32 fma chains        */
-#define PLNERF_PREC_BF16X3 1 /* 3-term bf16 split on v_mfma_f32_32x32x16_bf16        */
-#define PLNERF_PREC_BF16 2   /* plain bf16 operands, fp32 accumulate                 */
-/* Hybrids: IEEE-half operands (11-bit mantissa) in the forward GEMMs, where every value is
- * O(1); the backward GEMMs keep bf16 operands because pre-activation gradients span the
- * fp32 exponent range and would flush to zero in half precision. */
-#define PLNERF_PREC_F16X3 3  /* fwd: 3-term f16 split (v_mfma_f32_32x32x16_f16); bwd: BF16X3 */
-#define PLNERF_PREC_F16 4    /* fwd: plain f16 operands; bwd: BF16                          */
+/* arithmetic of the MLP FORWARD contractions (the 1e-5 parity contract is on forward outputs) */
+#define PLNERF_PREC_FP32 0   /* v_mfma_f32_32x32x2_f32: exact fp32 fma chains; fp32 backward too   */
+#define PLNERF_PREC_BF16X3 1 /* 3-term bf16 split on v_mfma_f32_32x32x16_bf16 (16 mantissa bits)  */
+#define PLNERF_PREC_BF16 2   /* plain bf16 operands, fp32 accumulate                              */
+#define PLNERF_PREC_F16X3 3  /* 3-term IEEE-half split on v_mfma_f32_32x32x16_f16 (22 bits)        */
+#define PLNERF_PREC_F16 4    /* plain half operands, fp32 accumulate                              */
+/* Backward of modes 1-4: the saved activations and the pre-activation gradients are IEEE-half
+ * planes, the latter under one power-of-two scale per launch (max |g_raw| -> [8,16), saturating
+ * conversion); dgrad chain and weight gradients are single half MFMAs with fp32 accumulation.
+ * Weight-gradient entries agree with fp32 autograd to ~1e-3 of max |g| (cosine > 0.999999). */
 
 #define PLNERF_MAX_SAMPLES 1022 /* S+2 knots must fit the per-wave LDS row */
 

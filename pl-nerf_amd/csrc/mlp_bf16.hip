@@ -46,9 +46,11 @@ using namespace plnerf;
 using namespace plnerf::lay;
 #define H16T _Float16
 #define H16_MFMA __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define H16_HAS_BWD   // the dgrad chain of every 16-bit mode runs on half operands
 #include "mlp_h16_body.inc"
 #undef H16T
 #undef H16_MFMA
+#undef H16_HAS_BWD
 }  // namespace plnerf_h16_f16
 
 namespace plnerf {
@@ -57,12 +59,10 @@ namespace impl {
 size_t bf16_packed_bytes(int ns) { return plnerf_h16_bf16::h16_packed_bytes(ns); }
 
 int bf16_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, int f16, void* packed, hipStream_t st) {
-    // The f16 modes are hybrids: IEEE-half operands in the forward GEMMs (values are O(1), the 11-bit
-    // mantissa buys 8x tighter products), bf16 operands in the backward GEMMs (pre-activation
-    // gradients span the whole fp32 exponent range and would flush to zero in half precision).
-    if (!f16) return plnerf_h16_bf16::h16_pack(params, xyz_ch, dir_ch, ns, 3, packed, st);
-    const int rc = plnerf_h16_f16::h16_pack(params, xyz_ch, dir_ch, ns, 1, packed, st);
-    return rc ? rc : plnerf_h16_bf16::h16_pack(params, xyz_ch, dir_ch, ns, 2, packed, st);
+    // forward section in the mode's element type (ns planes), dgrad section always one half plane
+    const int rc = f16 ? plnerf_h16_f16::h16_pack(params, xyz_ch, dir_ch, ns, 1, ns, packed, st)
+                       : plnerf_h16_bf16::h16_pack(params, xyz_ch, dir_ch, ns, 1, ns, packed, st);
+    return rc ? rc : plnerf_h16_f16::h16_pack(params, xyz_ch, dir_ch, 1, 2, ns, packed, st);
 }
 
 int bf16_fwd(const void* packed, int ns, int f16, const float* pts, const float* viewdirs, const float* embedded,
@@ -75,8 +75,7 @@ int bf16_fwd(const void* packed, int ns, int f16, const float* pts, const float*
 
 int bf16_dgrad(const void* packed, int ns, const float* g_raw, int n_rows, const void* saved, void* dz,
                const unsigned* gmax, hipStream_t st) {
-    // backward GEMMs always run on bf16 operands (see bf16_pack)
-    return plnerf_h16_bf16::h16_dgrad(packed, ns, g_raw, n_rows, saved, dz, gmax, st);
+    return plnerf_h16_f16::h16_dgrad(packed, ns, g_raw, n_rows, saved, dz, gmax, st);
 }
 
 }  // namespace impl
