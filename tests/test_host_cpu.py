@@ -208,3 +208,41 @@ def test_lr_schedule_matches_reference_quirk(built, tmp_path):
     ts.global_step = 2500
     assert abs(ts.learning_rate() - 5e-4 * 0.1 ** (2500 / 500000)) < 1e-12
     assert opt_c.param_groups[0]["lr"] == 1e-4        # until the first step; afterwards the fine rate (line 1315)
+
+
+def test_depth_variant_host_logic(built):
+    """CPU-checkable pieces of the depth-supervised mirror (plnerf_amd.depth): the pi-scaled encoder equals the
+    oracle's bit for bit, the networks come out 57 | 3 wide with the DenseLayer initialisation (xavier-uniform,
+    zero biases; depth_supervised_exps/model/run_nerf_helpers.py:89-98), and the space-carving loss equals the
+    oracle's restatement including its gradient."""
+    from argparse import Namespace
+    from oracle import plnerf_oracle as orc
+    from plnerf_amd import depth as Dp
+    emb, ch = Dp.get_embedder(9, 0)
+    embd, chv = Dp.get_embedder(0, 0)
+    assert (ch, chv) == (57, 3)
+    x = torch.randn(11, 3, generator=torch.Generator().manual_seed(0)) * 2
+    assert torch.equal(emb(x), orc.positional_encoding_pi(x, 9)) and torch.equal(embd(x), x)
+    args = Namespace(multires=9, i_embed=0, use_viewdirs=True, multires_views=0, input_ch_cam=0, N_importance=8,
+                     N_samples=8, netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256, lrate=5e-4, perturb=1.0,
+                     white_bkgd=True, raw_noise_std=0.0, mode="linear", color_mode="midpoint")
+    kw, kw_test, start, grad_vars, opt = Dp.create_nerf(args, device=torch.device("cpu"))
+    net = kw["network_fn"]
+    assert [tuple(p.shape) for p in net.parameters()] == [s for _, s in orc.param_shapes_depth()]
+    assert net.is_supported() and not net.has_fused_encoding() and net.density_activation == "softplus"
+    assert all(float(m.bias.detach().abs().max()) == 0.0 for m in net.modules() if isinstance(m, torch.nn.Linear))
+    w = net.pts_linears[1].weight
+    bound = (2.0 ** 0.5) * (6.0 / (256 + 256)) ** 0.5                    # xavier-uniform with the relu gain
+    assert float(w.detach().abs().max()) <= bound + 1e-6 and float(w.detach().abs().max()) > 0.9 * bound
+    assert len(grad_vars) == 48 and len(opt.param_groups[0]["params"]) == 48 and kw_test["perturb"] is False
+    gen = torch.Generator().manual_seed(2)
+    hyp = torch.rand(7, 16, generator=gen) * 4 + 2
+    target_h = torch.rand(3, 7, 1, generator=gen) * 4 + 2
+    mask = (torch.rand(7, generator=gen) > 0.3).float()
+    for kwargs in ({}, {"mask": mask}, {"is_joint": True}, {"threshold": 0.5}):
+        a = hyp.clone().requires_grad_(True)
+        b = hyp.clone().requires_grad_(True)
+        la = Dp.compute_space_carving_loss(a, target_h, **kwargs)
+        lb = orc.compute_space_carving_loss(b, target_h, **kwargs)
+        la.backward(); lb.backward()
+        assert torch.equal(la, lb) and torch.equal(a.grad, b.grad), kwargs
