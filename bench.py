@@ -204,6 +204,14 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a)
+        # RCCL writes its version banner through C stdio, which is block-buffered on a pipe and would otherwise
+        # come out at process exit, AFTER this line: flush it first so that the JSON is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
