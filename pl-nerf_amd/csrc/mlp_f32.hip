@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradArgs a) {
 // the gfx950 transposing LDS read (lane = feature column, 4 consecutive rows per read; row stride
 // 576 B puts the 4 rows of a read on disjoint banks; semantics pinned by tools/probes/tr16_probe.hip).
 // Stage k+1 is fetched into registers before stage k's MFMAs and written to LDS after them; one
-// barrier per stage.  8 waves as 4(o) x 2(i), each 64(o) x 32 NI(i): a 256 x 256 workgroup tile
+// barrier per stage.  (Fetching two stages ahead into a second register set measured 11 % slower.)  8 waves as 4(o) x 2(i), each 64(o) x 32 NI(i): a 256 x 256 workgroup tile
 // reads every plane once.  (History: a register-only version re-split fp32 operands in every wave
 // and was VALU-bound, 24 % MFMA busy -- profiles/r01_bf16x3_pmc_sq_tcp_before_lds_wgrad.txt.)
 typedef short v4s16 __attribute__((ext_vector_type(4)));
