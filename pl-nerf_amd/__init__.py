@@ -11,7 +11,8 @@ from .rays import get_rays, get_rays_np, ndc_rays
 from .train import TrainStep, checkpoint_path, save_checkpoint, select_rays
 from . import depth   # depth-supervised variant of the path (depth_supervised_exps/)
 from .render import (batchify, batchify_rays, compute_weights, compute_weights_piecewise_linear, create_nerf,
-                     raw2outputs, render, render_rays, run_network, sample_pdf, sample_pdf_reformulation)
+                     raw2outputs, render, render_path, render_rays, run_network, sample_pdf,
+                     sample_pdf_reformulation)
 
 img2mse = lambda x, y: ((x - y) ** 2).mean()   # run_nerf_helpers.py:17
 
@@ -26,7 +27,7 @@ def library_version():
 
 __all__ = [
     "NeRF", "Embedder", "get_embedder", "get_rays", "get_rays_np", "ndc_rays", "batchify", "batchify_rays",
-    "compute_weights", "compute_weights_piecewise_linear", "create_nerf", "raw2outputs", "render",
+    "compute_weights", "compute_weights_piecewise_linear", "create_nerf", "raw2outputs", "render", "render_path",
     "render_rays", "run_network", "sample_pdf", "sample_pdf_reformulation", "img2mse", "library_path",
     "library_version", "depth", "TrainStep", "save_checkpoint", "checkpoint_path", "select_rays",
 ]

@@ -258,6 +258,25 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
     return ret_list + [ret_dict]
 
 
+def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0):
+    """run_plnerf.py:178-216: render() once per pose; returns (rgbs [n,H,W,3], disps [n,H,W]) as numpy arrays.
+    Frames are rendered under torch.no_grad() (the reference calls this inside `with torch.no_grad()`); writing
+    PNGs (`savedir`) is the caller's business here -- image IO is outside the path -- so a
+    non-None savedir raises instead of being silently ignored."""
+    if savedir is not None:
+        raise NotImplementedError("render_path does not write images; save the returned arrays on the caller side")
+    H, W, focal = hwf
+    if render_factor != 0:
+        H, W, focal = H // render_factor, W // render_factor, focal / render_factor
+    rgbs, disps = [], []
+    with torch.no_grad():
+        for c2w in render_poses:
+            rgb, disp, acc, _ = render(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
+            rgbs.append(rgb.cpu().numpy())
+            disps.append(disp.cpu().numpy())
+    return np.stack(rgbs, 0), np.stack(disps, 0)
+
+
 def create_nerf(args, device=None):
     """run_plnerf.py:417-502: (render_kwargs_train, render_kwargs_test, start, grad_vars,
     optimizer, optimizer_coarse).  `device` (extension) defaults to cuda:<current>; optional

@@ -843,3 +843,27 @@ def test_full_image_render_c2w(P):
                           white_bkgd=True, pytest=True)
     assert_close(rgb.reshape(-1, 3), ref["rgb_map"], atol=1e-4, rtol=1e-4, what="full-image rgb")
     assert_close(extras["rgb0"].reshape(-1, 3), ref["rgb0"], what="full-image rgb0")
+
+
+def test_render_path(P):
+    """render_path (run_plnerf.py:178-216): one render() per pose, numpy stacks, render_factor downsampling;
+    image writing is outside the path and refuses loudly."""
+    H, W, f = 8, 12, 14.0
+    K = [[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]]
+    poses = torch.stack([P.rays.pose_spherical(a, -30.0, 4.0) for a in (0.0, 40.0, 80.0)]).to(dev())
+    emb_fn, _ = P.get_embedder(10, 0)
+    embd_fn, _ = P.get_embedder(4, 0)
+    qfn = lambda inputs, viewdirs, fn: P.run_network(inputs, viewdirs, fn, emb_fn, embd_fn)
+    sd = orc.closed_form_state_dict(0, True)
+    kw = dict(network_query_fn=qfn, perturb=0.0, N_importance=16, network_fine=make_net(P, sd), N_samples=16,
+              network_fn=make_net(P, sd), white_bkgd=True, raw_noise_std=0.0, mode="linear", color_mode="midpoint",
+              ndc=False, near=2.0, far=6.0, use_viewdirs=True)
+    rgbs, disps = P.render_path(poses, (H, W, f), K, 64, kw)
+    assert rgbs.shape == (3, H, W, 3) and disps.shape == (3, H, W) and np.isfinite(rgbs).all()
+    with torch.no_grad():
+        one = P.render(H, W, K, chunk=64, c2w=poses[1, :3, :4], **kw)[0]
+    assert np.array_equal(rgbs[1], one.cpu().numpy())
+    half = P.render_path(poses[:1], (H, W, f), K, 64, kw, render_factor=2)[0]
+    assert half.shape == (1, H // 2, W // 2, 3)
+    with pytest.raises(NotImplementedError):
+        P.render_path(poses[:1], (H, W, f), K, 64, kw, savedir="/tmp/x")
