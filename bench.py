@@ -188,7 +188,10 @@ def main():
                        "final_loss": float(loss.detach())},
             "roofline": {
                 "bound": "hbm" if hbm_bound else "mfma",
-                "kernel": ("mlp_fwd_f32_kernel" if a.precision == "fp32" else "mlp_fwd_train_kernel") + " (fine network, fused PE+12-layer MLP forward, saves backward state)",
+                "kernel": {"fp32": "mlp_fwd_f32_kernel<2,true>", "f16x3": "mlp_fwd_pp_kernel<2,true>",
+                           "f16": "mlp_fwd_pp_kernel<1,true>", "bf16x3": "mlp_fwd_train_kernel<2>",
+                           "bf16": "mlp_fwd_train_kernel<1>"}[a.precision]
+                          + " (fine network, fused PE+12-layer MLP forward, saves backward state)",
                 "achieved": ach_gbs if hbm_bound else ach, "peak": HBM_PEAK_GBS if hbm_bound else peak,
                 "unit": "GB/s" if hbm_bound else "TFLOP/s",
                 "frac": ((ach_gbs / HBM_PEAK_GBS) if hbm_bound else (ach / peak)) if ach else None,
