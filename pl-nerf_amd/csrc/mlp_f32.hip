@@ -37,7 +37,7 @@ using namespace plnerf;
 using namespace plnerf::lay;
 
 #ifndef PLNERF_WG_SPLITS
-#define PLNERF_WG_SPLITS 112
+#define PLNERF_WG_SPLITS 56
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -565,13 +565,18 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradArgs a) {
 // it row-major in LDS; waves then build their k-contiguous MFMA fragments with ds_read_b64_tr_b16,
 // the gfx950 transposing LDS read (lane = feature column, 4 consecutive rows per read; row stride
 // 576 B puts the 4 rows of a read on disjoint banks; semantics pinned by tools/probes/tr16_probe.hip).
-// Stage k+1 is fetched into registers before stage k's MFMAs and written to LDS after them; one
-// barrier per stage.  (Fetching two stages ahead into a second register set measured 11 % slower.)  8 waves as 4(o) x 2(i), each 64(o) x 32 NI(i): a 256 x 256 workgroup tile
+// A stage is TR_STEPS k-steps (64 rows): stage k+1 is fetched into registers before stage k's MFMAs and
+// written to LDS after them; one barrier per stage.  (Fetching two 16-row stages ahead into a second
+// register set measured 11 % slower.)  8 waves as 4(o) x 2(i), each 64(o) x 32 NI(i): a 256 x 256 workgroup tile
 // reads every plane once.  (History: a register-only version re-split fp32 operands in every wave
 // and was VALU-bound, 24 % MFMA busy -- profiles/r01_bf16x3_pmc_sq_tcp_before_lds_wgrad.txt.)
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 typedef _Float16 wh8 __attribute__((ext_vector_type(8)));
-constexpr int TR_ROWS = 16;            // rows per stage = one MFMA k-step
+#ifndef PLNERF_TR_STEPS
+#define PLNERF_TR_STEPS 4
+#endif
+constexpr int TR_STEPS = PLNERF_TR_STEPS;   // MFMA k-steps per LDS stage
+constexpr int TR_ROWS = 16;            // rows per MFMA k-step
 constexpr int TR_RS = 288;             // LDS row stride in half elements (256 + 32): 576 B
 constexpr int TR_PLANE = TR_ROWS * TR_RS;
 
@@ -592,8 +597,10 @@ __device__ __forceinline__ wh8 tr_frag(const _Float16* plane, int lane, int col0
 template <int NI>
 __global__ __launch_bounds__(512) void wgrad_tr16_kernel(WgradArgs a) {
     constexpr int NO = 2, WI = 2;
+    constexpr int KST = TR_STEPS, SROWS = TR_ROWS * KST;      // k-steps / rows per stage
+    constexpr int SPLANE = SROWS * TR_RS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    _Float16* lds = reinterpret_cast<_Float16*>(smem_raw);   // [buffer 2][operand A,B][TR_ROWS][TR_RS]
+    _Float16* lds = reinterpret_cast<_Float16*>(smem_raw);   // [buffer 2][operand A,B][SROWS][TR_RS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const WJob job = a.jobs[a.tile_job[blockIdx.x]];
@@ -606,31 +613,42 @@ __global__ __launch_bounds__(512) void wgrad_tr16_kernel(WgradArgs a) {
     const int split = blockIdx.y;
     const int m_begin = split * a.rows_per_split;
     const int m_end = min(a.n_rows, m_begin + a.rows_per_split);
-    // this thread's (row, 8-half chunk) slot in the 16-row slab of each operand (O, I <= 256: one each)
+    // this thread's (row, 8-half chunk) slots in the stage's slab of each operand (O, I <= 256: KST each)
     const int a_c8 = job.O >> 3, b_c8 = job.I >> 3;
-    const int a_row = tid / a_c8, a_col = (tid - a_row * a_c8) * 8;
-    const int b_row = tid / b_c8, b_col = (tid - b_row * b_c8) * 8;
-    wh8 ra, rb;
+    int a_row[KST], a_col[KST], b_row[KST], b_col[KST];
+#pragma unroll
+    for (int j = 0; j < KST; ++j) {
+        const int q = tid + 512 * j;
+        a_row[j] = q / a_c8; a_col[j] = (q - a_row[j] * a_c8) * 8;
+        b_row[j] = q / b_c8; b_col[j] = (q - b_row[j] * b_c8) * 8;
+    }
+    wh8 ra[KST], rb[KST];
     float bs[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bs[e] = 0.0f;
     auto fetch = [&](int m) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { ra[e] = (_Float16)0.0f; rb[e] = (_Float16)0.0f; }
-        if (a_row < TR_ROWS && m + a_row < m_end)
-            ra = *reinterpret_cast<const wh8*>(Ag + (size_t)(m + a_row) * job.lda + a_col);
-        if (b_row < TR_ROWS && m + b_row < m_end)
-            rb = *reinterpret_cast<const wh8*>(Bg + (size_t)(m + b_row) * job.ldb + b_col);
+        for (int j = 0; j < KST; ++j) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ra[j][e] = (_Float16)0.0f; rb[j][e] = (_Float16)0.0f; }
+            if (a_row[j] < SROWS && m + a_row[j] < m_end)
+                ra[j] = *reinterpret_cast<const wh8*>(Ag + (size_t)(m + a_row[j]) * job.lda + a_col[j]);
+            if (b_row[j] < SROWS && m + b_row[j] < m_end)
+                rb[j] = *reinterpret_cast<const wh8*>(Bg + (size_t)(m + b_row[j]) * job.ldb + b_col[j]);
+        }
     };
     auto stash = [&](int buf) {
-        _Float16* A0 = lds + (size_t)buf * 2 * TR_PLANE;
-        _Float16* B0 = A0 + TR_PLANE;
-        if (a_row < TR_ROWS) {
-            *reinterpret_cast<wh8*>(A0 + a_row * TR_RS + a_col) = ra;
+        _Float16* A0 = lds + (size_t)buf * 2 * SPLANE;
+        _Float16* B0 = A0 + SPLANE;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bs[e] += (float)ra[e];
+        for (int j = 0; j < KST; ++j) {
+            if (a_row[j] < SROWS) {
+                *reinterpret_cast<wh8*>(A0 + a_row[j] * TR_RS + a_col[j]) = ra[j];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bs[e] += (float)ra[j][e];
+            }
+            if (b_row[j] < SROWS) *reinterpret_cast<wh8*>(B0 + b_row[j] * TR_RS + b_col[j]) = rb[j];
         }
-        if (b_row < TR_ROWS) *reinterpret_cast<wh8*>(B0 + b_row * TR_RS + b_col) = rb;
     };
     f32x16 acc[NO][NI];
     zero_acc(acc);
@@ -640,22 +658,25 @@ __global__ __launch_bounds__(512) void wgrad_tr16_kernel(WgradArgs a) {
     }
     __syncthreads();
     int buf = 0;
-    for (int m = m_begin; m < m_end; m += TR_ROWS, buf ^= 1) {
-        const bool more = m + TR_ROWS < m_end;
-        if (more) fetch(m + TR_ROWS);
+    for (int m = m_begin; m < m_end; m += SROWS, buf ^= 1) {
+        const bool more = m + SROWS < m_end;
+        if (more) fetch(m + SROWS);
         if (live) {
-            const _Float16* A0 = lds + (size_t)buf * 2 * TR_PLANE;
-            const _Float16* B0 = A0 + TR_PLANE;
-            wh8 af[NO], bf[NI];
+            const _Float16* A0 = lds + (size_t)buf * 2 * SPLANE;
+            const _Float16* B0 = A0 + SPLANE;
 #pragma unroll
-            for (int o = 0; o < NO; ++o) af[o] = tr_frag(A0, lane, o_base + 32 * o);
+            for (int k = 0; k < KST; ++k) {
+                wh8 af[NO], bf[NI];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) bf[i] = tr_frag(B0, lane, i_base + 32 * i);
+                for (int o = 0; o < NO; ++o) af[o] = tr_frag(A0 + k * TR_PLANE, lane, o_base + 32 * o);
 #pragma unroll
-            for (int o = 0; o < NO; ++o)
+                for (int i = 0; i < NI; ++i) bf[i] = tr_frag(B0 + k * TR_PLANE, lane, i_base + 32 * i);
 #pragma unroll
-                for (int i = 0; i < NI; ++i)
-                    acc[o][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[o], bf[i], acc[o][i], 0, 0, 0);
+                for (int o = 0; o < NO; ++o)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+                        acc[o][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[o], bf[i], acc[o][i], 0, 0, 0);
+            }
         }
         if (more) stash(buf ^ 1);
         __syncthreads();
@@ -676,17 +697,19 @@ __global__ __launch_bounds__(512) void wgrad_tr16_kernel(WgradArgs a) {
                 }
     }
     if (job.bias_off >= 0) {
-        // bias partial = column sums of the dz slab: every thread summed its (row slot, 8 features)
-        float* red = reinterpret_cast<float*>(smem_raw);      // [TR_ROWS][O] floats (<= 16 KB), reusing the LDS
+        // bias partial = column sums of the dz slabs: every thread summed its chunk column over its row slots
+        // (the slots of one thread share a_col only when O/8 divides 512, i.e. O = 256 or 128: true for all jobs)
+        float* red = reinterpret_cast<float*>(smem_raw);      // [512 * 8 / O rows][O] floats, reusing the LDS
+        const int red_rows = 512 / a_c8;
         __syncthreads();
-        if (a_row < TR_ROWS) {
+        if (a_row[0] < red_rows) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[a_row * job.O + a_col + e] = bs[e];
+            for (int e = 0; e < 8; ++e) red[a_row[0] * job.O + a_col[0] + e] = bs[e];
         }
         __syncthreads();
         for (int f = tid; f < job.O; f += 512) {
             float sum = 0.0f;
-            for (int r = 0; r < TR_ROWS; ++r) sum += red[r * job.O + f];
+            for (int r = 0; r < red_rows; ++r) sum += red[r * job.O + f];
             part[job.bias_off + f] = sum;
         }
     }
@@ -857,10 +880,10 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
-// Row ranges of the split-K weight gradient.  The grid is (9 tiles) x splits workgroups of 512 threads and
-// 36 KB of LDS, 4 resident per CU = 1024 slots: 112 splits = 1008 workgroups run as exactly one wave
-// (128 = one wave + a 12 % tail: +1 % step time; 56 and 28, at 2 and 1 per CU, hide less latency:
-// +4 % and +14 %).
+// Row ranges of the split-K weight gradient and rows per LDS stage, tuned together on the 4096-ray step
+// (bench.py, ms per step): stage 16 rows: 112 splits 9.21 | 32 rows: 112 -> 8.58, 56 -> 8.79 | 48 rows:
+// 56 -> 8.48, 28 -> 9.00 | 64 rows: 56 -> 8.45, 84 -> 8.48, 112 -> 8.77, 28 -> 8.84.  Longer contiguous
+// bursts per plane (64 rows x 512 B = 32 KB) are worth more to the HBM than a third resident workgroup.
 inline int splits_for(int n_rows) {
     int s = (n_rows + 1023) / 1024;
     if (s < 1) s = 1;
@@ -940,7 +963,9 @@ int absmax(const float* x, size_t n, unsigned* out, hipStream_t st) {
 
 template <int NI>
 inline void launch_tr16(dim3 grid, hipStream_t st, const WgradArgs& a) {
-    const size_t lds = (size_t)2 * 2 * TR_PLANE * sizeof(_Float16);   // 2 buffers x {A, B}
+    const size_t lds = (size_t)2 * 2 * TR_STEPS * TR_PLANE * sizeof(_Float16);   // 2 buffers x {A, B}
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)wgrad_tr16_kernel<NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((wgrad_tr16_kernel<NI>), grid, dim3(512), lds, st, a);
 }
 
