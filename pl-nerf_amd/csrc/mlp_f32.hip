@@ -1018,6 +1018,7 @@ int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, co
     }
     {
         // the three thin jobs: encoding columns of L0 / L5 (256 x 64), direction columns of the view layer (128 x 32)
+        // (folding them into the main launch as extra tiles measured 1-2 % slower than this second launch)
         WgradArgs a{};
         a.jobs[0] = WJob{dplane(0), pe_plane, W, PE_K, W, PE_K, PART_PE0, PART_BIAS + 0 * W};
         a.jobs[1] = WJob{dplane(5), pe_plane, W, PE_K, W, PE_K, PART_PE5, -1};
