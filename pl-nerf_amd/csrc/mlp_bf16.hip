@@ -1,28 +1,26 @@
-// The PL-NeRF MLP on the 16-bit-operand MFMAs (v_mfma_f32_32x32x16_bf16 / _f16).
-// The kernel source lives in mlp_h16_body.inc and is compiled for two element types; the f16 split
-// (11+11 mantissa bits) reaches ~3e-7 where the bf16 split (8+8) reaches ~8e-6 at the same cost.
-// PLNERF_PREC_BF16 (NS = 1, plain bf16
-// operands) and PLNERF_PREC_BF16X3 (NS = 2: every operand is split x = hi + lo with
-// hi = bf16(x), lo = bf16(x - hi), and each product is evaluated as hi*hi + lo*hi + hi*lo with
-// fp32 accumulation -- ~2^-16 relative operand error, i.e. fp32-class results, at 3 MFMAs per
-// product instead of 16 fp32-MFMA passes).
+// The PL-NeRF MLP on the 16-bit-operand MFMAs (v_mfma_f32_32x32x16_bf16 / _f16): precision modes
+// PLNERF_PREC_BF16X3 / _F16X3 (NS = 2: every forward operand is split x = hi + lo with hi = T(x),
+// lo = T(x - hi), each product evaluated as hi*hi + lo*hi + hi*lo with fp32 accumulation -- fp32-class
+// results at 3 MFMAs per product instead of 16 fp32-MFMA passes; the half split's 11+11 mantissa bits reach
+// ~1e-6 where the bf16 split's 8+8 reach ~8e-6) and PLNERF_PREC_BF16 / _F16 (NS = 1, plain operands).
 //
 // Reference: run_network (run_plnerf.py:78-92) = Embedder (run_nerf_helpers.py:24-54) +
 // NeRF.forward (:105-128) and its autograd backward.
 //
-// Formulation: OUT^T[feature][sample] = W[feature][k] . X^T[k][sample].  The MFMA "A" operand is
-// the weight tile (pre-packed in fragment order, streamed from L2 by the one wave that owns that
-// 32-feature slab -- no LDS staging, no duplicate fetch), the "B" operand is the activation tile
-// in LDS, [sample][feature] row-major bf16, read with one 16-byte ds_read per fragment (row stride
-// 528 B == 16 mod 256 -> conflict-free).  With features on the accumulator rows, a lane's four
-// consecutive registers are four consecutive features of ONE sample, i.e. four consecutive k of
-// the next layer: the bias+ReLU epilogue converts them to bf16 and writes one 8-byte LDS store
-// per plane, in place.
-//
-// A 512-thread workgroup (8 waves, 2 per SIMD) owns a tile of TM samples (128 for bf16, 64 for
-// bf16x3; 94 KB of LDS either way) and walks all 12 layers without leaving the CU.  For
-// training, each layer's activation tile is additionally copied LDS -> HBM as coalesced fp32
-// rows (the same plane layout as the fp32 mode), so the fp32-MFMA weight-gradient stage is shared.
+// The kernel source lives in mlp_h16_body.inc (+ mlp_h16_fwd_pp.inc) and is compiled once per element type:
+//   forward, inference            mlp_fwd_pp_kernel<NS, false>      both element types
+//   forward, training             mlp_fwd_pp_kernel<NS, true>       half elements (the tile's hi plane IS the saved plane)
+//                                 mlp_fwd_train_kernel<NS>          bf16 elements (8 compute + 4 converting copy waves)
+//   backward, dgrad chain         mlp_bwd_h16_kernel                half elements only, shared by every mode
+// Formulation: OUT^T[feature][sample] = W[feature][k] . X^T[k][sample].  The MFMA "A" operand is the weight tile
+// (pre-packed in fragment order, owned by the one wave that computes that 32-feature slab -- no LDS staging, no
+// duplicate fetch), the "B" operand is the activation tile in LDS, [sample][feature] row-major 16-bit planes, read
+// with one 16-byte ds_read per fragment (row stride 528 B == 16 mod 256 -> conflict-free).  With features on the
+// accumulator rows, a lane's four consecutive registers are four consecutive features of ONE sample, i.e. four
+// consecutive k of the next layer: the bias+ReLU epilogue converts them and writes one 8-byte LDS store per plane,
+// in place.  A 512-thread workgroup owns a tile of TM samples (128 plain, 64 split) and walks all 12 layers without
+// leaving the CU.  State saved for the backward: IEEE-half planes + ReLU bit masks (mlp_layout.h); the weight-
+// gradient stage (mlp_f32.hip: wgrad_tr16_kernel) is shared by all four modes.
 #include <cstdlib>
 #include <type_traits>
 

@@ -25,6 +25,9 @@
 // wgrad_reduce_kernel sums the split-K partials deterministically into the 24 gradient
 // tensors in their original [out][in] layout.
 //
+// This file also holds the weight-gradient stage of the 16-bit modes (wgrad_tr16_kernel on the half planes,
+// absmax_kernel for their scale): launcher, head and reduction kernels are shared with the fp32 mode.
+//
 // Numerics: f32 MFMA is bit-for-bit an fmaf chain; only the summation order differs from
 // the reference's CPU GEMM, i.e. fp32 round-off (~1e-7 relative), well inside the 1e-5
 // parity bound.
@@ -951,8 +954,8 @@ int f32_dgrad(const void* packed, const float* g_raw, int n_rows, const float* s
     return PLNERF_OK;
 }
 
-// Weight gradients from the fp32 planes (saved activations + dz planes written by any of the
-// dgrad kernels): split-K partials, head reductions, deterministic final sum into grads[24].
+// Weight gradients from the saved activation planes and the dz planes of the mode's dgrad kernel (fp32 planes in
+// fp32 mode, half planes otherwise): split-K partials, head reductions, deterministic final sum into grads[24].
 int absmax(const float* x, size_t n, unsigned* out, hipStream_t st) {
     if (hipMemsetAsync(out, 0, sizeof(unsigned), st) != hipSuccess) return PLNERF_ELAUNCH;
     const int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));

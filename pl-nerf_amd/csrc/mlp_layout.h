@@ -76,11 +76,11 @@ constexpr int SV_FEAT = 8;
 constexpr int SV_HV_OFF = 9 * W;             // floats-per-row offset of the hv plane
 constexpr int SV_PE_OFF = SV_HV_OFF + HV;
 constexpr int SV_DPE_OFF = SV_PE_OFF + PE_K;
-constexpr int SV_FLOATS = SV_DPE_OFF + DPE_K;       // 2528 floats of fp32 planes per row
-// relu bit masks written by the bf16-family forward for its dgrad (1 bit per activation instead
-// of re-reading the fp32 planes): h0..h7 at 32 B/row each, then hv at 16 B/row
+constexpr int SV_FLOATS = SV_DPE_OFF + DPE_K;       // 2528 plane elements per row (fp32 in fp32 mode, half otherwise)
+// relu bit masks written by the 16-bit forward kernels for the dgrad kernel (1 bit per activation instead
+// of re-reading the planes): h0..h7 at 32 B/row each, then hv at 16 B/row
 constexpr int SV_MASK_BYTES = 8 * (W / 8) + HV / 8; // 272 B per row
-constexpr int SAVED_PER_ROW = SV_FLOATS + SV_MASK_BYTES / 4;   // 2596 floats
+constexpr int SAVED_PER_ROW = SV_FLOATS + SV_MASK_BYTES / 4;   // fp32 mode: 2596 floats per row
 
 // ---- backward workspace: pre-activation gradients, planes 0..7 = dz0..dz7, 8 = dz_feature,
 // then dz_view [128] ----------------------------------------------------------------------
