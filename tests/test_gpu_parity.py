@@ -633,6 +633,17 @@ def test_depth_variant_network_golden(P, golden):
         ref = sd[name].grad
         err = float((prm.grad.cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
         assert err <= 1e-4, (name, err)
+    # the same through the half backward of the 16-bit modes (57 | 3 wide weight-gradient blocks included)
+    Dp3, kw3, _, _ = _depth_setup(P, gd, "f16x3")
+    net3 = kw3["network_fn"]
+    (net3(emb) * g(cot)).sum().backward()
+    worst = 0.0
+    for name, prm in net3.named_parameters():
+        ref = sd[name].grad
+        assert prm.grad.shape == ref.shape
+        worst = max(worst, float((prm.grad.cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-30))
+    print(f"g8 network f16x3 gradients: worst err / max|g| = {worst:.3e}")
+    assert worst <= 3e-3, worst
 
 
 def test_depth_variant_render_and_train_step_golden(P, golden):
