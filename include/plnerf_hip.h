@@ -111,6 +111,15 @@ int plnerf_sample_const(const float* bins, const float* weights, const float* u,
                         int u_row_stride, int R, int B, int N, float* samples, int64_t* inds,
                         plnerf_stream_t stream);
 
+/* Backward of plnerf_sample_const with respect to `weights` (bins are detached on the reference
+ * path): what autograd derives for sample_pdf_return_u
+ * (depth_supervised_exps/model/run_nerf_helpers.py:343-394) when the depth-supervised variant runs
+ * in piecewise-constant mode.  inds [R,N] is the forward's index output; g_weights [R,B-1] is
+ * written (not accumulated), deterministically. */
+int plnerf_sample_const_bwd(const float* bins, const float* weights, const float* u,
+                            int u_row_stride, const int64_t* inds, const float* g_samples, int R,
+                            int B, int N, float* g_weights, plnerf_stream_t stream);
+
 /* sample_pdf_reformulation (run_nerf_helpers.py:364-445) with pw_linear_sample_increasing /
  * _decreasing (:340-361): z [R,S], weights [R,S+1], tau,T [R,S+2], near,far [R].
  * Outputs samples [R,N] and (each may be NULL) T_below, tau_below, bin_below [R,N],

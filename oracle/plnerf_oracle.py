@@ -573,11 +573,9 @@ def _draw_u_depth(R, n, det, pytest, load_u):
 def render_rays_depth(ray_batch, sd_coarse, sd_fine, N_samples, mode, color_mode, perturb=0.0,
                       N_importance=0, white_bkgd=False, raw_noise_std=0.0, pytest=False, cached_u=None,
                       bb_center=0.0, bb_scale=1.0, t_rand=None, u_fine=None):
-    """run_nerf_sample_based_depth.py:792-958, mode 'linear' (the PL-NeRF configuration), is_joint False.
-    `pred_hyp` stays attached to the final weights' tau and T (:923-934).  t_rand / u_fine inject the
-    stratified draw and the importance draw for HIP-vs-oracle comparisons."""
-    if mode != "linear":
-        raise ValueError("the restatement covers mode='linear'")
+    """run_nerf_sample_based_depth.py:792-958, is_joint False.  `pred_hyp` stays attached: to the final
+    weights' tau and T in mode 'linear' (:923-934), to the final weights in mode 'constant'.  t_rand / u_fine
+    inject the stratified draw and the importance draw for HIP-vs-oracle comparisons."""
     rays_o, rays_d = ray_batch[:, 0:3], ray_batch[:, 3:6]
     viewdirs = ray_batch[:, 8:11]
     near, far = ray_batch[:, 6:7], ray_batch[:, 7:8]
@@ -588,13 +586,17 @@ def render_rays_depth(ray_batch, sd_coarse, sd_fine, N_samples, mode, color_mode
                                                    pytest, white_bkgd)
     R = ray_batch.shape[0]
     ret = {}
+
+    def draw(z, w, tau, T, n, u=None, det=False, pyt=False):
+        if mode == "linear":
+            return sample_pdf_reformulation(z, w, tau, T, near, far, n, det=det, pytest=pyt, u=u)[0]
+        return sample_pdf(0.5 * (z[..., 1:] + z[..., :-1]), w[..., 1:-1], n, det=det, pytest=pyt, u=u)
     if N_importance == 0:
         u = _draw_u_depth(R, N_samples, perturb == 0.0, pytest, None)
-        hyp = sample_pdf_reformulation(z, w, tau, T, near, far, N_samples, u=u)[0]
+        hyp = draw(z, w, tau, T, N_samples, u=u)
     else:
         coarse = (rgb, disp, acc, depth, z, w)
-        z_new = sample_pdf_reformulation(z, w, tau, T, near, far, N_importance, det=(perturb == 0.0),
-                                         pytest=pytest, u=u_fine)[0].detach()
+        z_new = draw(z, w, tau, T, N_importance, u=u_fine, det=(perturb == 0.0), pyt=pytest).detach()
         z_new = torch.clamp(z_new, near, far)
         z, _ = torch.sort(torch.cat([z, z_new], -1), -1)
         pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
@@ -602,12 +604,12 @@ def render_rays_depth(ray_batch, sd_coarse, sd_fine, N_samples, mode, color_mode
         rgb, disp, acc, w, depth, tau, T = raw2outputs(raw, z, near, far, rays_d, mode, color_mode, raw_noise_std,
                                                        pytest, white_bkgd)
         u = _draw_u_depth(R, N_importance, perturb == 0.0, pytest, cached_u)
-        hyp = sample_pdf_reformulation(z, w, tau, T, near, far, N_importance, u=u)[0]
+        hyp = draw(z, w, tau, T, N_importance, u=u)
         ret.update({"rgb0": coarse[0], "disp0": coarse[1], "acc0": coarse[2], "depth0": coarse[3],
                     "z_vals0": coarse[4], "weights0": coarse[5],
                     "z_std": torch.std(hyp, dim=-1, unbiased=False)})
     ret.update({"rgb_map": rgb, "disp_map": disp, "acc_map": acc, "depth_map": depth, "z_vals": z,
-                "weights": w[..., 1:], "pred_hyp": hyp, "u": u, "raw": raw})
+                "weights": w[..., 1:] if mode == "linear" else w, "pred_hyp": hyp, "u": u, "raw": raw})
     return ret
 
 

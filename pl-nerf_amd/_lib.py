@@ -29,6 +29,7 @@ SIGNATURES = {
     "plnerf_quad_fwd": (c_i, [c_f] * 6 + [c_i] * 6 + [c_f] * 7 + [c_s]),
     "plnerf_quad_bwd": (c_i, [c_f] * 6 + [c_i] * 6 + [c_f] * 7 + [c_s]),
     "plnerf_sample_const": (c_i, [c_f] * 3 + [c_i] * 4 + [c_f] * 2 + [c_s]),
+    "plnerf_sample_const_bwd": (c_i, [c_f] * 3 + [c_i] + [c_f] * 2 + [c_i] * 3 + [c_f] + [c_s]),
     "plnerf_sample_pl": (c_i, [c_f] * 7 + [c_i] * 4 + [ctypes.c_float] * 2 + [c_f] * 5 + [c_s]),
     "plnerf_sample_pl_bwd": (c_i, [c_f] * 6 + [c_i] + [c_f] * 2 + [c_i] * 3 + [ctypes.c_float] * 2 + [c_f] * 2 + [c_s]),
     "plnerf_merge_sort": (c_i, [c_f] * 4 + [c_i] * 3 + [c_f] + [c_s]),

@@ -115,6 +115,101 @@ __global__ __launch_bounds__(256) void sample_const_kernel(SampleConstArgs a) {
     }
 }
 
+
+struct SampleConstBwdArgs {
+    const float* bins;
+    const float* weights;
+    const float* u;
+    int u_row_stride;
+    const int64_t* inds;
+    const float* g_samples;
+    int R, B, N;
+    int lds_stride;
+    float* g_weights;
+};
+
+// Backward of sample_const_kernel with respect to `weights` (what autograd derives for sample_pdf_return_u,
+// depth_supervised_exps/model/run_nerf_helpers.py:343-394, when pred_hyp carries a loss in constant mode):
+//   sample = b0 + t (b1 - b0),  t = (u - c0) / denom,  denom = c1 - c0 (or 1 where that is < 1e-5)
+//   cdf[j] = sum_{i<j} pdf[i],  pdf = w' / sum(w'),  w' = w + 1e-5
+// Per-knot sums run in sample order and the suffix sums are wave scans: deterministic, no atomics.
+__global__ __launch_bounds__(256) void sample_const_bwd_kernel(SampleConstBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int ray = blockIdx.x * WAVES + wave;
+    const bool live = ray < a.R;
+    if (!live) ray = a.R - 1;
+    const int B = a.B, n = a.B - 1, N = a.N;
+    float* cdf = smem + wave * a.lds_stride;   // B
+    float* bins = cdf + B;                      // B
+    float* wv = bins + B;                       // n  (weights + 1e-5), later g_pdf
+    float* g0 = wv + B;                         // N: gradient landing on cdf[below]
+    float* g1 = g0 + N;                         // N: on cdf[above]
+    int* lo = reinterpret_cast<int*>(g1 + N);   // N
+    int* hi = lo + N;                           // N
+    float* gc = reinterpret_cast<float*>(hi + N);   // B: g_cdf
+    for (int j = lane; j < B; j += 64) bins[j] = a.bins[(size_t)ray * B + j];
+    for (int j = lane; j < n; j += 64) wv[j] = a.weights[(size_t)ray * n + j] + 1e-5f;
+    __syncthreads();
+    const float total = torch_row_sum(wv, n, lane);
+    double carry = 0.0;
+    for (int base = 0; base < n; base += 64) {
+        const int j = base + lane;
+        const float pdf = (j < n) ? wv[j] / total : 0.0f;
+        const double incl = wave_incl_sum((double)pdf);
+        if (j < n) cdf[j + 1] = (float)(carry + incl);
+        carry = carry + __shfl(incl, 63);
+    }
+    if (lane == 0) cdf[0] = 0.0f;
+    __syncthreads();
+    const float* urow = a.u + (size_t)ray * a.u_row_stride;
+    for (int k = lane; k < N; k += 64) {
+        const size_t o = (size_t)ray * N + k;
+        const float u = urow[k];
+        const int ind = (int)a.inds[o];
+        const int below = ind - 1 > 0 ? ind - 1 : 0;
+        const int above = ind < B - 1 ? ind : B - 1;
+        const float c0 = cdf[below], c1 = cdf[above];
+        const float d = c1 - c0;
+        const bool active = !(d < 1e-5f);
+        const float denom = active ? d : 1.0f;
+        const float gt = a.g_samples[o] * (bins[above] - bins[below]);
+        const float q = (u - c0) / denom;            // = t
+        // dt/dc0 = -1/denom + [active] t/denom ;  dt/dc1 = -[active] t/denom
+        g0[k] = gt * ((-1.0f / denom) + (active ? q / denom : 0.0f));
+        g1[k] = active ? gt * (-(q / denom)) : 0.0f;
+        lo[k] = below; hi[k] = above;
+    }
+    __syncthreads();
+    for (int j = lane; j < B; j += 64) {
+        float sacc = 0.0f;
+        for (int k = 0; k < N; ++k) {
+            if (lo[k] == j) sacc += g0[k];
+            if (hi[k] == j) sacc += g1[k];
+        }
+        gc[j] = sacc;
+    }
+    __syncthreads();
+    // g_pdf[i] = sum_{j > i} g_cdf[j]  (i = 0..n-1): suffix sums, scanned from the top in fp64
+    double tail = 0.0, dot = 0.0;
+    for (int base = 0; base < n; base += 64) {
+        const int p = base + lane;                  // position from the top: i = n - 1 - p, adds g_cdf[i + 1]
+        const int i = n - 1 - p;
+        const double v = (p < n) ? (double)gc[i + 1] : 0.0;
+        const double incl = wave_incl_sum(v);
+        if (p < n) {
+            const float gp = (float)(tail + incl);
+            dot += (double)gp * (double)(wv[i] / total);   // sum_k g_pdf[k] pdf[k]
+            cdf[i] = gp;                                      // g_pdf (the cdf row is no longer needed)
+        }
+        tail = tail + __shfl(incl, 63);
+    }
+    dot = wave_sum(dot);
+    __syncthreads();
+    if (!live) return;
+    for (int i = lane; i < n; i += 64) a.g_weights[(size_t)ray * n + i] = (cdf[i] - (float)dot) / total;
+}
+
 struct SamplePlArgs {
     const float* z;
     const float* weights;
@@ -395,6 +490,25 @@ extern "C" int plnerf_sample_const(const float* bins, const float* weights, cons
     int rc = set_lds((const void*)sample_const_kernel, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(sample_const_kernel, dim3((R + WAVES - 1) / WAVES), dim3(WAVES * 64), lds,
+                       (hipStream_t)stream, a);
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}
+
+
+extern "C" int plnerf_sample_const_bwd(const float* bins, const float* weights, const float* u, int u_row_stride,
+                                       const int64_t* inds, const float* g_samples, int R, int B, int N,
+                                       float* g_weights, plnerf_stream_t stream) {
+    if (R < 0 || B < 2 || N < 1 || (u_row_stride != 0 && u_row_stride != N)) return PLNERF_EINVAL;
+    if (B > PLNERF_MAX_SAMPLES + 2) return PLNERF_ERANGE;
+    if (R == 0) return PLNERF_OK;
+    if (!bins || !weights || !u || !inds || !g_samples || !g_weights) return PLNERF_EINVAL;
+    SampleConstBwdArgs a{bins, weights, u, u_row_stride, inds, g_samples, R, B, N, 0, g_weights};
+    a.lds_stride = ((4 * B + 4 * N) + 3) & ~3;
+    const size_t lds = (size_t)WAVES * a.lds_stride * sizeof(float);
+    int rc = set_lds((const void*)sample_const_bwd_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sample_const_bwd_kernel, dim3((R + WAVES - 1) / WAVES), dim3(WAVES * 64), lds,
                        (hipStream_t)stream, a);
     PLNERF_CHECK_LAUNCH();
     return PLNERF_OK;

@@ -84,12 +84,8 @@ def sample_pdf_reformulation_return_u(bins, weights, tau, T, near, far, N_sample
 
 
 def sample_pdf_return_u(bins, weights, N_samples, det=False, pytest=False, load_u=None, joint=False):
-    """model/run_nerf_helpers.py:343-394 (piecewise-constant mode).  The kernel has no backward: the returned
-    samples carry no gradient (the reference's would, through the normalised cdf); constant-mode depth
-    supervision therefore fails loudly instead of training on a silently detached hypothesis."""
-    if torch.is_grad_enabled() and weights.requires_grad:
-        raise NotImplementedError("constant-mode pred_hyp is not differentiable on the HIP path; use mode='linear' "
-                                  "(the PL-NeRF configuration) or evaluate under torch.no_grad()")
+    """model/run_nerf_helpers.py:343-394 (piecewise-constant mode; :446- for joint=True).  Returns (samples, u);
+    `samples` is differentiable with respect to `weights` (plnerf_sample_const_bwd)."""
     u = _draw_u(bins.shape[0], N_samples, det, pytest, load_u, joint, bins.device).contiguous()
     return Fn.sample_const(bins, weights, u), u
 

@@ -178,19 +178,51 @@ class MlpFn(torch.autograd.Function):
         return (None,) * 6 + tuple(grads)
 
 
+class SampleConstFn(torch.autograd.Function):
+    """sample_pdf (run_nerf_helpers.py:241-284) -> plnerf_sample_const / plnerf_sample_const_bwd.  Differentiable
+    with respect to `weights` (through the normalised cdf), which only the depth-supervised variant's
+    piecewise-constant mode uses (depth_supervised_exps/model/run_nerf_helpers.py:343-394); on the NVS path the
+    result is detached."""
+
+    @staticmethod
+    def forward(ctx, bins, weights, u):
+        R, B = bins.shape
+        N = u.shape[-1]
+        dev = bins.device
+        bins_c, w_c, u_c = _f32c(bins), _f32c(weights), _f32c(u)
+        stride = N if u_c.dim() == 2 else 0
+        out = torch.empty(R, N, device=dev)
+        inds = torch.empty(R, N, device=dev, dtype=torch.int64)
+        if R > 0:
+            L.check(L.lib().plnerf_sample_const(
+                L.dptr(bins_c, "bins"), L.dptr(w_c, "weights"), L.dptr(u_c, "u"), stride, R, B, N, L.dptr(out),
+                L.dptr(inds, "inds", torch.int64), L.stream()), "plnerf_sample_const")
+        ctx.save_for_backward(bins_c, w_c, u_c, inds)
+        ctx.stride = stride
+        ctx.mark_non_differentiable(inds)
+        ctx.set_materialize_grads(False)
+        return out, inds
+
+    @staticmethod
+    def backward(ctx, g_samples, g_inds):
+        if g_samples is None:
+            return None, None, None
+        bins_c, w_c, u_c, inds = ctx.saved_tensors
+        R, B = bins_c.shape
+        N = inds.shape[-1]
+        g_c = _f32c(g_samples)
+        g_w = torch.empty(R, B - 1, device=bins_c.device)
+        if R > 0:
+            L.check(L.lib().plnerf_sample_const_bwd(
+                L.dptr(bins_c), L.dptr(w_c), L.dptr(u_c), ctx.stride, L.dptr(inds, "inds", torch.int64), L.dptr(g_c),
+                R, B, N, L.dptr(g_w), L.stream()), "plnerf_sample_const_bwd")
+        return None, g_w, None
+
+
 def sample_const(bins, weights, u, want_inds=False):
-    """plnerf_sample_const: bins [R,B], weights [R,B-1], u [R,N] or shared [N]."""
-    R, B = bins.shape
-    N = u.shape[-1]
-    dev = bins.device
-    bins_c, w_c, u_c = _f32c(bins), _f32c(weights), _f32c(u)
-    stride = N if u_c.dim() == 2 else 0
-    out = torch.empty(R, N, device=dev)
-    inds = torch.empty(R, N, device=dev, dtype=torch.int64) if want_inds else None
-    if R > 0:
-        L.check(L.lib().plnerf_sample_const(
-            L.dptr(bins_c, "bins"), L.dptr(w_c, "weights"), L.dptr(u_c, "u"), stride, R, B, N, L.dptr(out),
-            L.dptr(inds, "inds", torch.int64), L.stream()), "plnerf_sample_const")
+    """plnerf_sample_const: bins [R,B], weights [R,B-1], u [R,N] or shared [N].  `samples` is differentiable with
+    respect to `weights` (SampleConstFn)."""
+    out, inds = SampleConstFn.apply(bins, weights, u)
     return (out, inds) if want_inds else out
 
 

@@ -277,6 +277,37 @@ def test_sampler_backward_vs_oracle_autograd(P):
         assert e_hip <= 2 * e_orc + 1e-5, (e_hip, e_orc)
 
 
+def test_sample_const_backward_vs_oracle_autograd(P):
+    """plnerf_sample_const_bwd: d samples / d weights of sample_pdf (through the normalised cdf), which the
+    depth-supervised variant needs in piecewise-constant mode (depth_supervised_exps/model/run_nerf_helpers.py:
+    343-394), against torch autograd on the oracle's restatement -- fp64 as yardstick, like the PL sampler."""
+    from plnerf_amd import functional as Fn
+
+    def rel(a, b):
+        return float((a.detach().cpu().double() - b).abs().max()) / (float(b.abs().max()) + 1e-300)
+
+    for (R, B, N, seed) in [(64, 63, 128, 1), (33, 191, 64, 2), (16, 9, 40, 3)]:
+        gen = torch.Generator().manual_seed(seed)
+        bins = torch.sort(torch.rand(R, B, generator=gen) * 4 + 2, -1)[0]
+        w = torch.rand(R, B - 1, generator=gen) ** 3
+        w[:, ::7] = 0.0                                   # empty bins: the denom < 1e-5 branch
+        u = torch.rand(R, N, generator=gen)
+        cot = torch.randn(R, N, generator=gen)
+
+        def oracle(dt):
+            wr = w.to(dt).clone().requires_grad_(True)
+            s = orc.sample_pdf(bins.to(dt), wr, N, u=u.to(dt))
+            (s * cot.to(dt)).sum().backward()
+            return wr.grad
+        g64, g32 = oracle(torch.float64), oracle(torch.float32)
+        wh = g(w).requires_grad_(True)
+        s = Fn.sample_const(g(bins), wh, g(u))
+        (s * g(cot)).sum().backward()
+        e_hip, e_orc = rel(wh.grad, g64), rel(g32, g64)
+        print(f"sample_const bwd R={R} B={B} N={N}: err vs fp64 oracle: HIP {e_hip:.3e}, fp32 oracle {e_orc:.3e}")
+        assert e_hip <= 2 * e_orc + 1e-5, (e_hip, e_orc)
+
+
 def test_merge_sort(P):
     from plnerf_amd import functional as Fn
     for R, S, N in ((513, 64, 128), (64, 128, 64), (3, 1, 1), (7, 500, 524)):
@@ -737,6 +768,71 @@ def test_depth_variant_gradients_vs_oracle(P):
         flat_o = torch.cat([g64[name].reshape(-1) for name, _ in net.named_parameters()])
         cos = float(torch.dot(flat_h, flat_o) / (flat_h.norm() * flat_o.norm()))
         print(f"depth variant {tag} gradients vs fp64 oracle: HIP {e_hip:.3e}, fp32 oracle {e_orc:.3e}, cosine {cos:.7f}")
+        assert e_hip <= 2 * e_orc + 5e-4, (tag, e_hip, e_orc)
+        assert cos >= 0.9999, (tag, cos)
+
+
+def test_depth_variant_constant_mode_vs_oracle(P):
+    """The depth-supervised step in piecewise-constant mode (the depth script's argparse default): pred_hyp from
+    sample_pdf_return_u with gradients through plnerf_sample_const_bwd and the constant-mode quadrature, against
+    the oracle on shared draws (fp64 yardstick as in the linear-mode test).  Default-initialised (not
+    "sharpened") networks: with saturated rays most bins are empty, sample_pdf divides by cdf steps of ~1e-5, and
+    the fp32 gradient -- the reference's own included -- is cancellation noise (cosine 0.89 against fp64 for both
+    the oracle and this path)."""
+    import sys
+    from plnerf_amd import depth as Dp
+    R, Ns, Ni = 40, 32, 48
+    gdummy = {"N_importance": Ni, "N_samples": Ns, "space_carving_weight": 0.05}
+    Dp, kw, grad_vars, opt = _depth_setup(P, gdummy)
+    kw = dict(kw, mode="constant")
+    kw["network_fn"].load_state_dict(orc.closed_form_state_dict_depth(0, False))
+    kw["network_fine"].load_state_dict(orc.closed_form_state_dict_depth(1, False))
+    batch, target = orc.synthetic_blender_rays(R, seed=12)
+    gen = torch.Generator().manual_seed(12)
+    t_rand, u_fine, u_hyp = torch.rand(R, Ns, generator=gen), torch.rand(R, Ni, generator=gen), \
+        torch.rand(R, Ni, generator=gen)
+    target_h = 2.0 + 4.0 * torch.rand(3, R, 1, generator=gen)
+
+    def oracle(dt):
+        sd_c = {k: v.to(dt) for k, v in orc.closed_form_state_dict_depth(0, False).items()}
+        sd_f = {k: v.to(dt) for k, v in orc.closed_form_state_dict_depth(1, False).items()}
+        okw = dict(N_samples=Ns, N_importance=Ni, mode="constant", color_mode="midpoint", perturb=1.0, white_bkgd=True,
+                   t_rand=t_rand.to(dt), u_fine=u_fine.to(dt), cached_u=u_hyp.to(dt))
+        return orc.depth_train_step(sd_c, sd_f, batch.to(dt), target.to(dt), target_h.to(dt), okw,
+                                    space_carving_weight=0.05)
+    loss_o, sc_o, g_c32, g_f32 = oracle(torch.float32)
+    _, _, g_c64, g_f64 = oracle(torch.float64)
+    dmod = sys.modules[Dp.__name__]
+    rmod = sys.modules[Dp.__name__.rsplit(".", 1)[0] + ".render"]
+    orig_perturb, orig_draw = dmod.perturb_z_vals, rmod._draw_u
+    try:
+        def fixed_perturb(z_vals, pytest):
+            mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+            upper = torch.cat([mids, z_vals[..., -1:]], -1)
+            lower = torch.cat([z_vals[..., :1], mids], -1)
+            return lower + (upper - lower) * g(t_rand)
+        dmod.perturb_z_vals = fixed_perturb
+        rmod._draw_u = lambda *a, **k: g(u_fine)
+        ret = Dp.render_rays(g(batch), retraw=True, cached_u=g(u_hyp), **kw)
+    finally:
+        dmod.perturb_z_vals, rmod._draw_u = orig_perturb, orig_draw
+    assert ret["pred_hyp"].requires_grad and ret["weights"].shape == (R, Ns + Ni)
+    sc = Dp.compute_space_carving_loss(ret["pred_hyp"], g(target_h))
+    loss = P.img2mse(ret["rgb_map"], g(target)) + 0.05 * sc + P.img2mse(ret["rgb0"], g(target))
+    loss.backward()
+    print(f"constant-mode depth loss HIP {float(loss.detach()):.6f} oracle {float(loss_o):.6f}; space carving "
+          f"{float(sc.detach()):.5f} / {float(sc_o):.5f}")
+    assert abs(float(loss.detach()) - float(loss_o)) <= 2e-5 and abs(float(sc.detach()) - float(sc_o)) <= 2e-4
+
+    def rel(a, b):
+        return float((a.double() - b).abs().max()) / (float(b.abs().max()) + 1e-300)
+    for net, g32, g64, tag in ((kw["network_fn"], g_c32, g_c64, "coarse"), (kw["network_fine"], g_f32, g_f64, "fine")):
+        e_hip = max(rel(prm.grad.cpu(), g64[name]) for name, prm in net.named_parameters())
+        e_orc = max(rel(g32[name], g64[name]) for name in g64)
+        flat_h = torch.cat([prm.grad.cpu().double().reshape(-1) for _, prm in net.named_parameters()])
+        flat_o = torch.cat([g64[name].reshape(-1) for name, _ in net.named_parameters()])
+        cos = float(torch.dot(flat_h, flat_o) / (flat_h.norm() * flat_o.norm()))
+        print(f"constant-mode {tag} gradients vs fp64 oracle: HIP {e_hip:.3e}, fp32 oracle {e_orc:.3e}, cosine {cos:.7f}")
         assert e_hip <= 2 * e_orc + 5e-4, (tag, e_hip, e_orc)
         assert cos >= 0.9999, (tag, cos)
 
