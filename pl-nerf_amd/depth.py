@@ -199,6 +199,23 @@ def compute_space_carving_loss(pred_depth, target_hypothesis, is_joint=False, ma
     return torch.mean(torch.mean(best_hyp, dim=-1))
 
 
+def get_space_carving_idx(pred_depth, target_hypothesis, is_joint=False, mask=None, norm_p=2, threshold=0.0):
+    """model/run_nerf_helpers.py:19-49: index of the best depth hypothesis, per ray (or per image when is_joint), for
+    the caller's hypothesis cache.  pred_depth [H, W, n_points]; target_hypothesis [n_hyp, H, W, 1]."""
+    H, W, n_points = pred_depth.shape
+    target = target_hypothesis.repeat(1, 1, 1, n_points)
+    distances = torch.norm(pred_depth.unsqueeze(-1) - target.unsqueeze(-1), p=norm_p, dim=-1)
+    if mask is not None:
+        distances = distances * mask.unsqueeze(0).repeat(distances.shape[0], 1).unsqueeze(-1)
+    if threshold > 0:
+        distances = torch.where(distances < threshold, torch.zeros((), device=distances.device), distances)
+    if is_joint:
+        total_loss = torch.mean(torch.mean(distances, axis=1), axis=1)
+        best_idx = torch.argmin(total_loss, dim=0)
+        return best_idx.unsqueeze(0).unsqueeze(0).repeat(H, W, 1)
+    return torch.argmin(distances, dim=0)
+
+
 def create_nerf(args, scene_render_params=None, device=None):
     """run_nerf_sample_based_depth.py:547-644: (render_kwargs_train, render_kwargs_test, start, grad_vars,
     optimizer).  One Adam over the parameters of both networks; no nn.DataParallel (ray shards go through
