@@ -84,4 +84,8 @@ int bf16_dgrad(const void* packed, int ns, const float* g_raw, int n_rows, const
 extern "C" int plnerf_debug_trace(unsigned long long* out64) {
     return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(plnerf_h16_bf16::g_trace), 64 * sizeof(unsigned long long));
 }
+// the same for the half element type (forward kernels of f16x3 / f16; the dgrad kernel of every 16-bit mode)
+extern "C" int plnerf_debug_trace_f16(unsigned long long* out64) {
+    return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(plnerf_h16_f16::g_trace), 64 * sizeof(unsigned long long));
+}
 #endif

@@ -1,0 +1,28 @@
+"""Phase breakdown of the dgrad kernel (mlp_bwd_h16_kernel) from in-kernel clock stamps of wave 0 of one workgroup.
+Needs a library built with -DPLNERF_TRACE=<block> (tools/trace_fwd.sh builds one at /tmp/libplnerf_trace.so)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import plnerf_amd as P
+from plnerf_amd import _lib
+dev = torch.device("cuda:0")
+R = 4096
+torch.manual_seed(0)
+net = P.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True, precision="bf16").to(dev)
+pts = (torch.rand(R, 192, 3, device=dev) * 2 - 1) * 3
+vd = torch.nn.functional.normalize(torch.randn(R, 3, device=dev), dim=-1)
+lib = _lib.lib()
+lib.plnerf_debug_trace_f16.argtypes = [ctypes.c_void_p]
+lib.plnerf_debug_trace_f16.restype = ctypes.c_int
+for _ in range(3):
+    raw = net.query(pts, vd)       # bf16 forward: the f16 trace buffer is then written by the dgrad kernel only
+    raw.sum().backward()
+torch.cuda.synchronize()
+buf = np.zeros(64, dtype=np.uint64)
+assert lib.plnerf_debug_trace_f16(buf.ctypes.data) == 0
+t = buf.astype(np.int64)
+print(f"dgrad: total {t[42]-t[0]} clk;  views+feature+L7 part {t[1]-t[0]}")
+for k in range(7):
+    b = 2 + 5 * k
+    prev = t[1] if k == 0 else t[b - 1 - 0]
+    print(f"  layer {7-k}: mask load {t[b]-(t[1] if k == 0 else t[b-1]):6d}  K loop {t[b+1]-t[b]:6d}  barrier {t[b+2]-t[b+1]:6d}  store_dz {t[b+3]-t[b+2]:6d}  barrier {t[b+4]-t[b+3]:6d}")

@@ -5,6 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R/pl-nerf_amd/csrc
 out=/tmp/libplnerf_trace.so
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -w -DPLNERF_TRACE=${TRACE_BLOCK:-3000} -shared -o $out capi.hip quad.hip sampler.hip mlp_api.hip mlp_f32.hip mlp_bf16.hip
+if [ -n "$BWD" ]; then PLNERF_HIP_LIB=$out python $R/tools/trace_bwd.py; exit 0; fi
 for p in ${PRECS:-bf16 bf16x3}; do
   for m in ${MODES:-inference train}; do PLNERF_HIP_LIB=$out python $R/tools/trace_fwd.py $p $m; done
 done
