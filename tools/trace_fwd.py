@@ -15,8 +15,9 @@ net = P.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4],
 pts = (torch.rand(R, 192, 3, device=dev) * 2 - 1) * 3
 vd = torch.nn.functional.normalize(torch.randn(R, 3, device=dev), dim=-1)
 lib = _lib.lib()
-lib.plnerf_debug_trace.argtypes = [ctypes.c_void_p]
-lib.plnerf_debug_trace.restype = ctypes.c_int
+read_trace = lib.plnerf_debug_trace_f16 if prec in ("f16x3", "f16") else lib.plnerf_debug_trace   # element type
+read_trace.argtypes = [ctypes.c_void_p]
+read_trace.restype = ctypes.c_int
 for _ in range(3):
     if train:
         raw = net.query(pts, vd)
@@ -25,7 +26,7 @@ for _ in range(3):
             raw = net.query(pts, vd)
 torch.cuda.synchronize()
 buf = np.zeros(64, dtype=np.uint64)
-assert lib.plnerf_debug_trace(buf.ctypes.data) == 0
+assert read_trace(buf.ctypes.data) == 0
 t = buf.astype(np.int64)
 t0 = t[0]
 wall = (t[49] - t[48]) / 100.0  # us at the 100 MHz constant clock
