@@ -793,7 +793,7 @@ constexpr int HEAD_OUT = 644;   // dW_alpha 256, dW_rgb 384, b_alpha 1, b_rgb 3
 struct ReduceArgs {
     const float* part;
     const float* head_part;
-    int splits, n_head;
+    int splits, splits_thin, n_head;   // row ranges of the 256-wide jobs / of the three thin jobs
     const unsigned* gmax;   // 16-bit modes: the dz planes were scaled by 2^(DZH_TARGET_EXP - exponent(max |g_raw|))
     GradPtrs G;
 };
@@ -815,9 +815,13 @@ __global__ void wgrad_reduce_kernel(ReduceArgs a) {
         else a.G.p[P_BR][h - 641] = s;
         return;
     }
+    // the thin jobs (encoding columns of L0 / L5, direction columns of the view layer, and L0's bias, which
+    // rides on them) are launched over their own number of row ranges
+    const bool thin = (idx >= PART_PE0 && idx < PART_BIAS) || (idx >= PART_BIAS && idx < PART_BIAS + W);
+    const int ns = thin ? a.splits_thin : a.splits;
     float s = 0.0f;
 #pragma unroll 8
-    for (int sp = 0; sp < a.splits; ++sp) s += a.part[(size_t)sp * PART_PER_SPLIT + idx];
+    for (int sp = 0; sp < ns; ++sp) s += a.part[(size_t)sp * PART_PER_SPLIT + idx];
     if (a.gmax) {   // undo the power-of-two scale of the half dz planes (exact)
         const float gm = __uint_as_float(*a.gmax);
         if (gm > 0.0f && gm < __builtin_inff()) {
@@ -980,6 +984,10 @@ int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, co
     const int splits = splits_for(n_rows);
     int rps = (n_rows + splits - 1) / splits;
     rps = (rps + 15) & ~15;
+    int splits_thin = splits;
+    if (h16) { splits_thin = (n_rows + 1023) / 1024; splits_thin = splits_thin < 1 ? 1 : (splits_thin > 85 ? 85 : splits_thin); }
+    int rps_thin = (n_rows + splits_thin - 1) / splits_thin;
+    rps_thin = (rps_thin + 15) & ~15;
     const unsigned char* sv = (const unsigned char*)saved;
     const unsigned char* dz = (const unsigned char*)dzv;
     auto splane = [&](int p) { return (const void*)(sv + (size_t)p * W * N * es); };
@@ -1029,7 +1037,9 @@ int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, co
         for (int t = 0; t < 3; ++t) { a.tile_job[t] = t; a.tile_o0[t] = 0; }
         a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
         if (h16) {
-            launch_tr16<1>(dim3(3, splits), st, a);
+            // three tiles only: more row ranges than the main launch, to cover the 256 CUs (3 x 85 = 255)
+            a.rows_per_split = rps_thin;
+            launch_tr16<1>(dim3(3, splits_thin), st, a);
         } else {
             hipLaunchKernelGGL((wgrad_f32_kernel<4, 1, 2, 2, 4>), dim3(2, splits), dim3(256), 0, st, a);
             PLNERF_CHECK_LAUNCH();
@@ -1054,7 +1064,7 @@ int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, co
     PLNERF_CHECK_LAUNCH();
     {
         ReduceArgs a{};
-        a.part = part; a.head_part = head_part; a.splits = splits; a.n_head = n_head;
+        a.part = part; a.head_part = head_part; a.splits = splits; a.splits_thin = splits_thin; a.n_head = n_head;
         a.gmax = h16 ? gmax : nullptr;
         a.G.xyz_ch = xyz_ch; a.G.dir_ch = dir_ch;
         for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i) {
