@@ -179,6 +179,70 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
     return ret
 
 
+def get_ray_dirs(H, W, intrinsic, c2w, coords=None):
+    """model/run_nerf_helpers.py:243-257: intrinsic = (fx, fy, cx, cy); pixel CENTRES (+0.5) and a flipped image
+    row, unlike the NVS script's get_rays.  coords [n, 2] = (row, col) selects pixels."""
+    fx, fy, cx, cy = intrinsic[0], intrinsic[1], intrinsic[2], intrinsic[3]
+    if coords is None:
+        dev = c2w.device
+        cols, rows = torch.meshgrid(torch.linspace(0, W - 1, W, device=dev), torch.linspace(0, H - 1, H, device=dev),
+                                    indexing='ij')
+        cols, rows = cols.t(), rows.t()
+    else:
+        cols, rows = coords[:, 1], coords[:, 0]
+    dirs = torch.stack([((cols + 0.5) - cx) / fx, (H - (rows + 0.5) - cy) / fy, -torch.ones_like(cols)], -1)
+    return torch.sum(dirs[..., None, :] * c2w[:3, :3], -1)
+
+
+def get_rays(H, W, intrinsic, c2w, coords=None):
+    """model/run_nerf_helpers.py:259-263."""
+    rays_d = get_ray_dirs(H, W, intrinsic, c2w, coords)
+    return c2w[:3, -1].expand(rays_d.shape), rays_d
+
+
+def batchify_rays(rays_flat, chunk=1024 * 32, use_viewdirs=False, **kwargs):
+    """run_nerf_sample_based_depth.py:71-83."""
+    parts = [render_rays(rays_flat[i:i + chunk], use_viewdirs, **kwargs) for i in range(0, rays_flat.shape[0], chunk)]
+    return {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]}
+
+
+def render(H, W, intrinsic, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., with_5_9=False,
+           use_viewdirs=False, c2w_staticcam=None, rays_depth=None, **kwargs):
+    """run_nerf_sample_based_depth.py:85-160 (render_hyp, :162-248, is the same function).  Returns
+    [rgb_map, disp_map, acc_map, extras]; `ndc` is accepted and unused, as there."""
+    if c2w is not None:
+        rays_o, rays_d = get_rays(H, W, intrinsic, c2w)
+        if with_5_9:                       # centre crop to 5.33:9
+            W_full, W = W, int(H / 9. * 16. / 3.)
+            W -= W % 2
+            start = (W_full - W) // 2
+            rays_o, rays_d = rays_o[:, start:start + W, :], rays_d[:, start:start + W, :]
+    elif rays.shape[0] == 2:
+        rays_o, rays_d = rays
+    else:
+        rays_o, rays_d, rays_depth = rays
+    cols = []
+    if use_viewdirs:
+        viewdirs = rays_d
+        if c2w_staticcam is not None:
+            rays_o, rays_d = get_rays(H, W, intrinsic, c2w_staticcam)
+        viewdirs = torch.reshape(viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True), [-1, 3]).float()
+        cols.append(viewdirs)
+    sh = rays_d.shape
+    rays_o, rays_d = torch.reshape(rays_o, [-1, 3]).float(), torch.reshape(rays_d, [-1, 3]).float()
+    ones = torch.ones_like(rays_d[..., :1])
+    if rays_depth is not None:
+        cols.append(torch.reshape(rays_depth, [-1, 3]).float())
+    packed = torch.cat([rays_o, rays_d, near * ones, far * ones] + cols, -1)
+    all_ret = batchify_rays(packed, chunk, use_viewdirs, **kwargs)
+    all_ret = {k: torch.reshape(v, list(sh[:-1]) + list(v.shape[1:])) for k, v in all_ret.items()}
+    head = ['rgb_map', 'disp_map', 'acc_map']
+    return [all_ret[k] for k in head] + [{k: v for k, v in all_ret.items() if k not in head}]
+
+
+render_hyp = render
+
+
 def compute_space_carving_loss(pred_depth, target_hypothesis, is_joint=False, mask=None, norm_p=2, threshold=0.0):
     """model/run_nerf_helpers.py:52-86.  pred_depth [n_rays, n_points]; target_hypothesis
     [n_hyp, n_rays, 1 or n_points].  A handful of small reductions: torch ops on the device."""

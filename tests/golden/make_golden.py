@@ -355,6 +355,15 @@ def g8():
     for m, tag in ((coarse, "coarse"), (fine, "fine")):
         for name, prm in m.named_parameters():
             out[f"param_{tag}_{name}_sample"] = sample_elems(prm)
+    # ray helpers of the depth script (pixel centres, flipped rows)
+    Hh, Ww = 4, 6
+    intr = torch.tensor([7.5, 7.25, Ww / 2 - 0.25, Hh / 2 + 0.5])
+    c2w_h = orc.pose_spherical(37.0, -30.0, 4.0)[:3, :4]
+    ro, rd = DH.get_rays(Hh, Ww, intr, c2w_h)
+    coords = torch.tensor([[0, 1], [3, 5], [2, 2]])
+    ro_c, rd_c = DH.get_rays(Hh, Ww, intr, c2w_h, coords)
+    out.update({"rays_H": Hh, "rays_W": Ww, "rays_intrinsic": intr, "rays_c2w": c2w_h, "rays_o": ro, "rays_d": rd,
+                "rays_coords": coords, "rays_o_coords": ro_c, "rays_d_coords": rd_c})
     out.update({"ray_batch": batch, "target": target, "target_h": target_h, "N_samples": Ns, "N_importance": Ni,
                 "space_carving_weight": sc_w, "loss": loss.detach(), "space_carving_loss": sc.detach(),
                 "sample_stride": 97})

@@ -837,6 +837,32 @@ def test_depth_variant_constant_mode_vs_oracle(P):
         assert cos >= 0.9999, (tag, cos)
 
 
+def test_depth_variant_render_wrappers(P, golden):
+    """depth.render / render_hyp (run_nerf_sample_based_depth.py:85-248): ray packing from c2w or from a ray batch,
+    chunking, the 5.33:9 crop, reshape of every dict entry -- equal to render_rays on the packed batch."""
+    gd = golden("g8_depth_variant")
+    Dp, kw, _, _ = _depth_setup(P, gd)
+    kw = dict(kw, perturb=0.0)                    # deterministic draws: chunking must not change anything
+    H, W = 6, 16
+    intr = torch.tensor([14.0, 14.0, W / 2, H / 2], device=dev())
+    c2w = P.rays.pose_spherical(20.0, -30.0, 4.0)[:3, :4].to(dev())
+    with torch.no_grad():
+        rgb, disp, acc, extras = Dp.render(H, W, intr, chunk=40, c2w=c2w, near=2.0, far=6.0, **kw)
+        assert rgb.shape == (H, W, 3) and extras["pred_hyp"].shape == (H, W, int(gd["N_importance"]))
+        ro, rd = Dp.get_rays(H, W, intr, c2w)
+        vd = rd / rd.norm(dim=-1, keepdim=True)
+        packed = torch.cat([ro, rd, torch.full_like(rd[..., :1], 2.0), torch.full_like(rd[..., :1], 6.0), vd], -1)
+        ref = Dp.render_rays(packed.reshape(-1, 11), **kw)
+        assert torch.equal(rgb.reshape(-1, 3), ref["rgb_map"]) and torch.equal(extras["pred_hyp"].reshape(H * W, -1), ref["pred_hyp"])
+        rgb2 = Dp.render_hyp(H, W, intr, chunk=1 << 20, rays=torch.stack([ro.reshape(-1, 3), rd.reshape(-1, 3)]), near=2.0,
+                             far=6.0, **kw)[0]
+        assert torch.equal(rgb2, ref["rgb_map"])
+        crop = Dp.render(H, W, intr, c2w=c2w, near=2.0, far=6.0, with_5_9=True, **kw)[0]
+        Wc = int(H / 9. * 16. / 3.); Wc -= Wc % 2
+        s0 = (W - Wc) // 2
+        assert crop.shape == (H, Wc, 3) and torch.equal(crop, rgb[:, s0:s0 + Wc])
+
+
 def test_fused_adam_matches_torch(P):
     from plnerf_amd import _lib as L
     gen = torch.Generator().manual_seed(0)

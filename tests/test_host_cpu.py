@@ -5,6 +5,7 @@ import re
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -221,6 +222,12 @@ def test_depth_variant_host_logic(built):
     emb, ch = Dp.get_embedder(9, 0)
     embd, chv = Dp.get_embedder(0, 0)
     assert (ch, chv) == (57, 3)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g8_depth_variant.npz"))
+    T = torch.from_numpy
+    ro, rd = Dp.get_rays(int(g["rays_H"]), int(g["rays_W"]), T(g["rays_intrinsic"]), T(g["rays_c2w"]))
+    assert torch.equal(ro, T(g["rays_o"])) and torch.equal(rd, T(g["rays_d"]))
+    ro, rd = Dp.get_rays(int(g["rays_H"]), int(g["rays_W"]), T(g["rays_intrinsic"]), T(g["rays_c2w"]), T(g["rays_coords"]))
+    assert torch.equal(ro, T(g["rays_o_coords"])) and torch.equal(rd, T(g["rays_d_coords"]))
     x = torch.randn(11, 3, generator=torch.Generator().manual_seed(0)) * 2
     assert torch.equal(emb(x), orc.positional_encoding_pi(x, 9)) and torch.equal(embd(x), x)
     args = Namespace(multires=9, i_embed=0, use_viewdirs=True, multires_views=0, input_ch_cam=0, N_importance=8,
