@@ -111,10 +111,9 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
     depth_map, z_vals, weights, pred_hyp, u (+ raw; + rgb0, disp0, acc0, depth0, z_vals0, weights0, z_std)."""
     dev = ray_batch.device
     N_rays = ray_batch.shape[0]
-    rays_o, rays_d = ray_batch[:, 0:3], ray_batch[:, 3:6]
-    viewdirs = ray_batch[:, 8:11] if use_viewdirs else None
-    bounds = torch.reshape(ray_batch[..., 6:8], [-1, 1, 2])
-    near, far = bounds[..., 0], bounds[..., 1]
+    rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
+    viewdirs = ray_batch[:, 8:11].contiguous() if use_viewdirs else None
+    near, far = ray_batch[:, 6:7].contiguous(), ray_batch[:, 7:8].contiguous()
     t_vals = Fn.cpu_linspace(N_samples, dev)
     if not lindisp:
         z_vals = near * (1. - t_vals) + far * t_vals

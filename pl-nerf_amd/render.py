@@ -141,10 +141,11 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_
     + rgb0, disp0, depth0, acc0, z_std if N_importance > 0)."""
     dev = ray_batch.device
     N_rays = ray_batch.shape[0]
-    rays_o, rays_d = ray_batch[:, 0:3], ray_batch[:, 3:6]
-    viewdirs = ray_batch[:, -3:] if ray_batch.shape[-1] > 8 else None
-    bounds = torch.reshape(ray_batch[..., 6:8], [-1, 1, 2])
-    near, far = bounds[..., 0], bounds[..., 1]
+    # one contiguous copy of each column group: every kernel below takes them as they are (the slices of the
+    # packed batch would otherwise be re-copied by each of the ~12 launches that consume them)
+    rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
+    viewdirs = ray_batch[:, -3:].contiguous() if ray_batch.shape[-1] > 8 else None
+    near, far = ray_batch[:, 6:7].contiguous(), ray_batch[:, 7:8].contiguous()
 
     t_vals = Fn.cpu_linspace(N_samples, dev)
     if not lindisp:
