@@ -873,24 +873,32 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     p[i] = p[i] - step_size * (mi / denom);
 }
 
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, unsigned* out) {
+// max |x| over n4 float4 (g_raw rows): grid-stride rows, wave + workgroup reduction, ONE atomic per workgroup
+// (atomics on a single address serialise in the L2: one per wave of a one-row-per-thread grid measured slower
+// than the 16-loads-per-thread loop it was meant to replace)
+__global__ __launch_bounds__(256) void absmax_kernel(const float4* __restrict__ x, size_t n4, unsigned* out) {
+    __shared__ float wmax[4];
     float m = 0.0f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float v = fabsf(x[i]);
-        m = (v > m || v != v) ? v : m;          // a NaN sticks (and compares above every float as bits)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = x[i];
+        const float c[4] = {fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m = (c[k] > m || c[k] != c[k]) ? c[k] : m;   // a NaN sticks (and compares above every float as bits)
     }
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const float o = __shfl_xor(m, d);
         m = (o > m || o != o) ? o : m;
     }
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) m = (wmax[w] > m || wmax[w] != wmax[w]) ? wmax[w] : m;
+        if (m != 0.0f) atomicMax(out, __float_as_uint(m));
+    }
 }
 
-// Row ranges of the split-K weight gradient and rows per LDS stage, tuned together on the 4096-ray step
-// (bench.py, ms per step): stage 16 rows: 112 splits 9.21 | 32 rows: 112 -> 8.58, 56 -> 8.79 | 48 rows:
-// 56 -> 8.48, 28 -> 9.00 | 64 rows: 56 -> 8.45, 84 -> 8.48, 112 -> 8.77, 28 -> 8.84.  Longer contiguous
-// bursts per plane (64 rows x 512 B = 32 KB) are worth more to the HBM than a third resident workgroup.
 inline int splits_for(int n_rows) {
     int s = (n_rows + 1023) / 1024;
     if (s < 1) s = 1;
@@ -962,8 +970,11 @@ int f32_dgrad(const void* packed, const float* g_raw, int n_rows, const float* s
 // fp32 mode, half planes otherwise): split-K partials, head reductions, deterministic final sum into grads[24].
 int absmax(const float* x, size_t n, unsigned* out, hipStream_t st) {
     if (hipMemsetAsync(out, 0, sizeof(unsigned), st) != hipSuccess) return PLNERF_ELAUNCH;
-    const int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
-    hipLaunchKernelGGL(absmax_kernel, dim3(blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, x, n, out);
+    if (n % 4 != 0) return PLNERF_EINVAL;   // rows of four
+    const size_t n4 = n / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, st, (const float4*)x, n4, out);
     PLNERF_CHECK_LAUNCH();
     return PLNERF_OK;
 }
