@@ -863,6 +863,50 @@ def test_depth_variant_render_wrappers(P, golden):
         assert crop.shape == (H, Wc, 3) and torch.equal(crop, rgb[:, s0:s0 + Wc])
 
 
+def test_single_pass_variants_vs_oracle(P):
+    """N_importance = 0: render_rays returns the coarse pass only (run_plnerf.py:714, 744); the depth-supervised
+    variant then draws pred_hyp from the coarse weights with N_samples draws (run_nerf_sample_based_depth.py:
+    872-886).  Both against the oracle on the reference's deterministic pytest draws."""
+    from plnerf_amd import depth as Dp
+    R, Ns = 24, 48
+    batch, _ = orc.synthetic_blender_rays(R, seed=21)
+    # NVS path
+    sd = orc.closed_form_state_dict(0, True)
+    emb_fn, _ = P.get_embedder(10, 0)
+    embd_fn, _ = P.get_embedder(4, 0)
+    qfn = lambda inputs, viewdirs, fn: P.run_network(inputs, viewdirs, fn, emb_fn, embd_fn)
+    with torch.no_grad():
+        ret = P.render_rays(g(batch), make_net(P, sd), qfn, Ns, "linear", "midpoint", retraw=True, perturb=1.0,
+                            N_importance=0, white_bkgd=True, pytest=True)
+    ref = orc.render_rays(batch, sd, None, Ns, "linear", "midpoint", retraw=True, perturb=1.0, N_importance=0,
+                          white_bkgd=True, pytest=True)
+    assert set(ret) == {"rgb_map", "disp_map", "acc_map", "depth_map", "raw"}
+    for k in ("rgb_map", "acc_map", "depth_map", "disp_map"):
+        assert_close(ret[k], ref[k], what=f"single pass {k}")
+    # depth-supervised variant
+    gdummy = {"N_importance": 0, "N_samples": Ns, "space_carving_weight": 0.05}
+    Dp, kw, _, _ = _depth_setup_single(P, gdummy)
+    out = Dp.render_rays(g(batch), retraw=True, pytest=True, **kw)
+    sd_d = orc.closed_form_state_dict_depth(0, True)
+    refd = orc.render_rays_depth(batch, sd_d, None, Ns, "linear", "midpoint", perturb=1.0, N_importance=0,
+                                 white_bkgd=True, pytest=True)
+    assert set(out) == {"rgb_map", "disp_map", "acc_map", "depth_map", "z_vals", "weights", "pred_hyp", "u", "raw"}
+    assert out["pred_hyp"].shape == (R, Ns) and out["pred_hyp"].requires_grad
+    assert torch.equal(out["u"].cpu(), refd["u"])
+    for k in ("rgb_map", "acc_map", "depth_map", "z_vals", "weights"):
+        assert_close(out[k], refd[k], what=f"depth single pass {k}")
+    assert_close(out["pred_hyp"], refd["pred_hyp"], atol=1e-4, rtol=1e-4, what="depth single pass pred_hyp")
+
+
+def _depth_setup_single(P, gd):
+    """_depth_setup for N_importance = 0: one network."""
+    from plnerf_amd import depth as Dp
+    kw, kw_test, start, grad_vars, opt = Dp.create_nerf(_depth_args(gd), device=dev())
+    assert kw["network_fine"] is None and len(grad_vars) == 24
+    kw["network_fn"].load_state_dict(orc.closed_form_state_dict_depth(0, True))
+    return Dp, kw, grad_vars, opt
+
+
 def test_fused_adam_matches_torch(P):
     from plnerf_amd import _lib as L
     gen = torch.Generator().manual_seed(0)
