@@ -28,6 +28,7 @@
 #include "mlp_internal.h"
 #include "mlp_layout.h"
 #include "mlp_pack_src.h"
+#include "pe_sincos.h"
 
 namespace plnerf_h16_bf16 {
 using namespace plnerf;

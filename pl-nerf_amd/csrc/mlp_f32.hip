@@ -35,6 +35,7 @@
 #include "mlp_internal.h"
 #include "mlp_layout.h"
 #include "mlp_pack_src.h"
+#include "pe_sincos.h"
 
 using namespace plnerf;
 using namespace plnerf::lay;
@@ -47,6 +48,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
+
+// sin / cos of x * scale (scale = 2^f): the shared reduction of pe_sincos.h, library sincosf past its range
+__device__ __forceinline__ void pe_sincos_any(const float x, const PeTurns t, const float scale, float* s, float* c) {
+    if (__builtin_expect(fabsf(x) * scale < PE_FAST_LIMIT, 1)) pe_sincos(t, scale, s, c);
+    else sincosf(x * scale, s, c);
+}
+
 
 
 constexpr int LDA = 260;  // activation tile row stride (floats): == 4 mod 64 -> conflict-free b128 reads
@@ -206,12 +214,13 @@ __global__ __launch_bounds__(256) void mlp_fwd_f32_kernel(FwdArgs a) {
             const float px = a.pts[3 * (size_t)grow + 0], py = a.pts[3 * (size_t)grow + 1],
                         pz = a.pts[3 * (size_t)grow + 2];
             float* prow = pe + row * LDP;
+            const PeTurns tx = pe_turns(px), ty = pe_turns(py), tz = pe_turns(pz);   // one reduction per coordinate
             for (int f = q; f < XYZ_FREQS; f += 4) {
                 const float sc = (float)(1 << f);
                 float s, c;
-                sincosf(px * sc, &s, &c); prow[3 + 6 * f + 0] = s; prow[3 + 6 * f + 3] = c;
-                sincosf(py * sc, &s, &c); prow[3 + 6 * f + 1] = s; prow[3 + 6 * f + 4] = c;
-                sincosf(pz * sc, &s, &c); prow[3 + 6 * f + 2] = s; prow[3 + 6 * f + 5] = c;
+                pe_sincos_any(px, tx, sc, &s, &c); prow[3 + 6 * f + 0] = s; prow[3 + 6 * f + 3] = c;
+                pe_sincos_any(py, ty, sc, &s, &c); prow[3 + 6 * f + 1] = s; prow[3 + 6 * f + 4] = c;
+                pe_sincos_any(pz, tz, sc, &s, &c); prow[3 + 6 * f + 2] = s; prow[3 + 6 * f + 5] = c;
             }
             if (q == 0) { prow[0] = px; prow[1] = py; prow[2] = pz; prow[XYZ_CH] = 0.0f; }
             const int ray = grow / a.spr;
@@ -222,9 +231,9 @@ __global__ __launch_bounds__(256) void mlp_fwd_f32_kernel(FwdArgs a) {
                 const int f = q;  // DIR_FREQS == 4
                 const float sc = (float)(1 << f);
                 float s, c;
-                sincosf(dx * sc, &s, &c); drow[3 + 6 * f + 0] = s; drow[3 + 6 * f + 3] = c;
-                sincosf(dy * sc, &s, &c); drow[3 + 6 * f + 1] = s; drow[3 + 6 * f + 4] = c;
-                sincosf(dz * sc, &s, &c); drow[3 + 6 * f + 2] = s; drow[3 + 6 * f + 5] = c;
+                pe_sincos_any(dx, pe_turns(dx), sc, &s, &c); drow[3 + 6 * f + 0] = s; drow[3 + 6 * f + 3] = c;
+                pe_sincos_any(dy, pe_turns(dy), sc, &s, &c); drow[3 + 6 * f + 1] = s; drow[3 + 6 * f + 4] = c;
+                pe_sincos_any(dz, pe_turns(dz), sc, &s, &c); drow[3 + 6 * f + 2] = s; drow[3 + 6 * f + 5] = c;
             }
             if (q == 1) { drow[0] = dx; drow[1] = dy; drow[2] = dz; }
             if (q == 2) {

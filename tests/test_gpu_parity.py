@@ -907,6 +907,33 @@ def _depth_setup_single(P, gd):
     return Dp, kw, grad_vars, opt
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_empty_and_ragged_batches(P, precision):
+    """Ragged ends of a chunked image (batchify_rays run_plnerf.py:95-106 hands render_rays whatever is left):
+    an empty ray batch flows through forward and backward with zero gradients, and a single ray with odd sample
+    counts (9 + 5: nothing a multiple of a tile) matches the oracle."""
+    sd = orc.closed_form_state_dict(0, True)
+    nc, nf = make_net(P, sd, precision), make_net(P, sd, precision)
+    emb_fn, _ = P.get_embedder(10, 0)
+    embd_fn, _ = P.get_embedder(4, 0)
+    qfn = lambda inputs, viewdirs, fn: P.run_network(inputs, viewdirs, fn, emb_fn, embd_fn)
+    kw = dict(network_fine=nf, white_bkgd=True, perturb=1.0)
+    ret = P.render_rays(torch.zeros(0, 11, device=dev()), nc, qfn, 16, "linear", "midpoint", retraw=True,
+                        N_importance=8, **kw)
+    assert ret["rgb_map"].shape == (0, 3) and ret["raw"].shape == (0, 24, 4) and ret["z_std"].shape == (0,)
+    (ret["rgb_map"].sum() + ret["rgb0"].sum()).backward()
+    for net in (nc, nf):
+        assert all(p.grad is not None and float(p.grad.abs().sum()) == 0.0 for p in net.parameters())
+    batch, _ = orc.synthetic_blender_rays(1, seed=3)
+    with torch.no_grad():
+        ret = P.render_rays(g(batch), nc, qfn, 9, "linear", "midpoint", N_importance=5, pytest=True, **kw)
+    ref = orc.render_rays(batch, sd, sd, 9, "linear", "midpoint", perturb=1.0, N_importance=5, white_bkgd=True,
+                          pytest=True)
+    tol = 1e-5 if precision == "fp32" else 1e-4
+    for k in ("rgb_map", "rgb0", "acc_map", "depth_map"):
+        assert_close(ret[k], ref[k], atol=tol, rtol=tol, what=f"1 ray 9+5 {precision} {k}")
+
+
 def test_fused_adam_matches_torch(P):
     from plnerf_amd import _lib as L
     gen = torch.Generator().manual_seed(0)

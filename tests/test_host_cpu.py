@@ -36,6 +36,17 @@ def test_library_exports_every_declared_symbol(built):
     assert _lib.lib().plnerf_error_string(-3).decode().startswith("size outside")
 
 
+def test_pe_sincos_reduction_on_host(tmp_path):
+    """pl-nerf_amd/csrc/pe_sincos.h (the encoding's shared argument reduction) is plain C++: compile it for the
+    host and compare with double-precision sin / cos over scene-scale, large and near-k*pi/2 arguments (the
+    checker exits non-zero above 1.2e-7 absolute)."""
+    exe = str(tmp_path / "pe_check")
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "pl-nerf_amd", "csrc"),
+                    os.path.join(ROOT, "tools", "probes", "pe_sincos_check.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
 def test_buffer_size_queries(built):
     from plnerf_amd import _lib
     L = _lib.lib()
