@@ -739,39 +739,56 @@ struct HeadArgs {
 
 template <typename PT>
 __global__ __launch_bounds__(256) void wgrad_head_kernel(HeadArgs<PT> a) {
-    __shared__ float red[8][4];
-    __shared__ float rgbred[128][3];
+    // 16-byte loads: VEC plane elements per thread, so a row of h7 (hv) is read by T7 (TV) neighbouring threads and
+    // the workgroup covers R7 (RV) rows per pass; the row classes are summed through LDS at the end
+    constexpr int VEC = 16 / (int)sizeof(PT);
+    typedef PT vec_t __attribute__((ext_vector_type(VEC)));
+    constexpr int T7 = W / VEC, R7 = 256 / T7;
+    constexpr int TV = HV / VEC, RV = 256 / TV;
+    __shared__ float acc7[R7][W];
+    __shared__ float accv[RV][3][HV];
+    __shared__ float red[4][4];
     const int tid = threadIdx.x;
     const int m_begin = blockIdx.x * a.rows_per_wg;
     const int m_end = min(a.n_rows, m_begin + a.rows_per_wg);
     const float4* g4 = reinterpret_cast<const float4*>(a.g_raw);
-    float wa = 0.0f;                       // column tid of dW_alpha
-    float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f; // column (tid & 127) of dW_rgb, rows of parity (tid >> 7)
-    const int half = tid >> 7, ci = tid & 127;
-    // rows two at a time (this thread takes the row of its parity for the rgb part), unrolled so that
-    // ~16 independent loads are in flight per thread -- the loop is latency-, not bandwidth-bound otherwise
-    const int m_pairs = (m_end - m_begin) >> 1;
-#pragma unroll 8
-    for (int p = 0; p < m_pairs; ++p) {
-        const int m = m_begin + 2 * p;
-        const float4 g0 = g4[m], g1 = g4[m + 1];
-        wa = fmaf(g0.w, (float)a.h7[(size_t)m * W + tid], wa);
-        wa = fmaf(g1.w, (float)a.h7[(size_t)(m + 1) * W + tid], wa);
-        const float4 g = half ? g1 : g0;
-        const float h = (float)a.hv[(size_t)(m + half) * HV + ci];
-        r0 = fmaf(g.x, h, r0);
-        r1 = fmaf(g.y, h, r1);
-        r2 = fmaf(g.z, h, r2);
+    {   // dW_alpha[c] = sum_m g_sigma[m] h7[m][c]
+        const int c = tid % T7, r = tid / T7;
+        float w[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) w[e] = 0.0f;
+#pragma unroll 4
+        for (int m = m_begin + r; m < m_end; m += R7) {
+            const float gs = a.g_raw[4 * (size_t)m + 3];
+            const vec_t h = *reinterpret_cast<const vec_t*>(a.h7 + (size_t)m * W + c * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) w[e] = fmaf(gs, (float)h[e], w[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc7[r][c * VEC + e] = w[e];
     }
-    if ((m_end - m_begin) & 1) {
-        const int m = m_end - 1;
-        const float4 g = g4[m];
-        wa = fmaf(g.w, (float)a.h7[(size_t)m * W + tid], wa);
-        if (half == 0) {
-            const float h = (float)a.hv[(size_t)m * HV + ci];
-            r0 = fmaf(g.x, h, r0);
-            r1 = fmaf(g.y, h, r1);
-            r2 = fmaf(g.z, h, r2);
+    {   // dW_rgb[k][c] = sum_m g_k[m] hv[m][c]
+        const int c = tid % TV, r = tid / TV;
+        float w0[VEC], w1[VEC], w2[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { w0[e] = 0.0f; w1[e] = 0.0f; w2[e] = 0.0f; }
+#pragma unroll 4
+        for (int m = m_begin + r; m < m_end; m += RV) {
+            const float4 g = g4[m];
+            const vec_t h = *reinterpret_cast<const vec_t*>(a.hv + (size_t)m * HV + c * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float hf = (float)h[e];
+                w0[e] = fmaf(g.x, hf, w0[e]);
+                w1[e] = fmaf(g.y, hf, w1[e]);
+                w2[e] = fmaf(g.z, hf, w2[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            accv[r][0][c * VEC + e] = w0[e];
+            accv[r][1][c * VEC + e] = w1[e];
+            accv[r][2][c * VEC + e] = w2[e];
         }
     }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -781,14 +798,20 @@ __global__ __launch_bounds__(256) void wgrad_head_kernel(HeadArgs<PT> a) {
     }
     s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
     if ((tid & 63) == 0) { red[tid >> 6][0] = s0; red[tid >> 6][1] = s1; red[tid >> 6][2] = s2; red[tid >> 6][3] = s3; }
-    if (half == 1) { rgbred[ci][0] = r0; rgbred[ci][1] = r1; rgbred[ci][2] = r2; }
     __syncthreads();
     float* part = a.part + (size_t)blockIdx.x * HEAD_PART;
-    part[tid] = wa;
-    if (half == 0) {
-        part[256 + 0 * HV + ci] = r0 + rgbred[ci][0];
-        part[256 + 1 * HV + ci] = r1 + rgbred[ci][1];
-        part[256 + 2 * HV + ci] = r2 + rgbred[ci][2];
+    {
+        float wa = 0.0f;
+#pragma unroll
+        for (int r = 0; r < R7; ++r) wa += acc7[r][tid];
+        part[tid] = wa;
+    }
+    for (int o = tid; o < 3 * HV; o += 256) {
+        const int k = o / HV, c = o - k * HV;
+        float v = 0.0f;
+#pragma unroll
+        for (int r = 0; r < RV; ++r) v += accv[r][k][c];
+        part[256 + o] = v;
     }
     if (tid < 4) {
         const float s = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
