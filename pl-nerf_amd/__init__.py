@@ -8,6 +8,7 @@ in the hand-written gfx950 kernels of libplnerf_hip.so; there is no CPU fallback
 from . import _lib
 from .nerf import NeRF, Embedder, get_embedder
 from .rays import get_rays, get_rays_np, ndc_rays
+from .optim import FlatAdam
 from .train import TrainStep, checkpoint_path, save_checkpoint, select_rays
 from . import depth   # depth-supervised variant of the path (depth_supervised_exps/)
 from .render import (batchify, batchify_rays, compute_weights, compute_weights_piecewise_linear, create_nerf,
@@ -29,5 +30,5 @@ __all__ = [
     "NeRF", "Embedder", "get_embedder", "get_rays", "get_rays_np", "ndc_rays", "batchify", "batchify_rays",
     "compute_weights", "compute_weights_piecewise_linear", "create_nerf", "raw2outputs", "render", "render_path",
     "render_rays", "run_network", "sample_pdf", "sample_pdf_reformulation", "img2mse", "library_path",
-    "library_version", "depth", "TrainStep", "save_checkpoint", "checkpoint_path", "select_rays",
+    "library_version", "depth", "FlatAdam", "TrainStep", "save_checkpoint", "checkpoint_path", "select_rays",
 ]

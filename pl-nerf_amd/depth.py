@@ -20,6 +20,7 @@ import torch
 
 from . import functional as Fn
 from .nerf import Embedder, NeRF
+from .optim import FlatAdam
 from .render import batchify, raw2outputs as _raw2outputs, sample_pdf, sample_pdf_reformulation
 
 
@@ -309,8 +310,9 @@ def create_nerf(args, scene_render_params=None, device=None):
     def network_query_fn(inputs, viewdirs, embedded_cam, network_fn):
         return run_network(inputs, viewdirs, embedded_cam, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
                            bb_center=bb_center, bb_scale=bb_scale, netchunk=getattr(args, "netchunk", 1024 * 64))
-    fused = {"fused": True} if torch.device(device).type == "cuda" else {}
-    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999), **fused)
+    # one Adam over both networks (optim.FlatAdam on the GPU: one launch per network's gradient buffer)
+    Adam = FlatAdam if torch.device(device).type == "cuda" else torch.optim.Adam
+    optimizer = Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
     start = 0
     ckdir = os.path.join(getattr(args, "ckpt_dir", ""), getattr(args, "expname", ""))
     if not getattr(args, "no_reload", True) and os.path.isdir(ckdir):

@@ -59,11 +59,21 @@ class GradientBucket:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
 
+    def _pieces(self):
+        """The gradients as few flat tensors as their layout allows: functional.MlpFn.backward returns a network's
+        24 gradients as slices of one buffer, so this is normally one piece per network."""
+        from .optim import contiguous_runs
+        runs = contiguous_runs([p.grad for p in self.params])
+        return None if any(g is None for _, _, g in runs) else [g for _, _, g in runs]
+
     def gather(self):
         """All .grad tensors -> the flat bucket, in ONE kernel (torch.cat into the buffer)."""
         if all(p.grad is not None for p in self.params):
-            torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat)
+            self._scatter_to = self._pieces()
+            torch.cat(self._scatter_to if self._scatter_to is not None else
+                      [p.grad.reshape(-1) for p in self.params], out=self.flat)
             return
+        self._scatter_to = None
         for p, v in zip(self.params, self.views):
             if p.grad is None:
                 v.zero_()
@@ -72,6 +82,10 @@ class GradientBucket:
 
     def scatter(self):
         """Flat bucket -> the .grad tensors, in one multi-tensor kernel."""
+        pieces = getattr(self, "_scatter_to", None)
+        if pieces is not None:
+            torch._foreach_copy_(pieces, list(self.flat.split([t.numel() for t in pieces])))
+            return
         missing = [p for p in self.params if p.grad is None]
         for p in missing:
             p.grad = torch.empty_like(p)

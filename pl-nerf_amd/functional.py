@@ -159,9 +159,14 @@ class MlpFn(torch.autograd.Function):
         dev = g_raw.device
         if ctx.saved_acts is None and n_rows > 0:
             raise RuntimeError("plnerf_amd: backward through an MLP forward that ran without saved state")
-        grads = [torch.empty(s, device=dev, dtype=torch.float32) for s in ctx.param_shapes]
+        # the 24 gradients are consecutive slices of ONE buffer, in parameter order: optim.FlatAdam and
+        # dp.GradientBucket then see a network's gradient as a single flat tensor (one Adam launch, one all-reduce
+        # without gather / scatter copies)
+        sizes = [int(torch.Size(s).numel()) for s in ctx.param_shapes]
+        flat = (torch.zeros if n_rows == 0 else torch.empty)(sum(sizes), device=dev, dtype=torch.float32)
+        grads = [t.view(s) for t, s in zip(flat.split(sizes), ctx.param_shapes)]
         if n_rows == 0:
-            return (None,) * 6 + tuple(torch.zeros_like(g) for g in grads)
+            return (None,) * 6 + tuple(grads)
         g = _f32c(g_raw)
         ws = torch.empty(L.lib().plnerf_mlp_bwd_workspace_bytes(n_rows, prec) // 4, device=dev,
                          dtype=torch.float32)

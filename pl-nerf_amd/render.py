@@ -12,6 +12,7 @@ import torch
 
 from . import functional as Fn
 from .nerf import NeRF, Embedder, get_embedder
+from .optim import FlatAdam
 from .rays import get_rays, ndc_rays
 
 DEBUG = False
@@ -310,10 +311,11 @@ def create_nerf(args, device=None):
                            netchunk=args.netchunk)
 
     # `optimizer` drives the fine network, `optimizer_coarse` the coarse one (:438, :446-447)
-    # same Adam as the reference; on the GPU its fused (single-kernel) implementation
-    fused = {"fused": True} if torch.device(device).type == "cuda" else {}
-    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999), **fused)
-    optimizer_coarse = torch.optim.Adam(params=coarse_grad_vars, lr=args.coarse_lrate, betas=(0.9, 0.999), **fused)
+    # same Adam as the reference (a torch.optim.Adam with the same state_dict); on the GPU one plnerf_adam_step
+    # launch per network over flat parameter / moment buffers (optim.FlatAdam)
+    Adam = FlatAdam if torch.device(device).type == "cuda" else torch.optim.Adam
+    optimizer = Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    optimizer_coarse = Adam(params=coarse_grad_vars, lr=args.coarse_lrate, betas=(0.9, 0.999))
 
     start = 0
     if args.ft_path is not None and args.ft_path != 'None':

@@ -951,6 +951,63 @@ def test_fused_adam_matches_torch(P):
 
 
 # ----------------------------------------------------------------------------- full-size properties
+def test_flat_adam_is_torch_adam(P, tmp_path):
+    """optim.FlatAdam (what create_nerf hands out on the GPU) against torch.optim.Adam on the same gradients:
+    per-step parameters over a changing learning rate (run_plnerf.py:1311-1315), parameters without a gradient
+    skipped, gradients in one buffer / two buffers / scattered tensors, and the checkpoint's optimizer_state_dict
+    (run_plnerf.py:1324-1332) crossing over in both directions."""
+    from plnerf_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    shapes = [(256, 63), (256,), (256, 256), (256,), (3, 128), (3,)]
+    mk = lambda: [torch.nn.Parameter(torch.randn(*s, generator=torch.Generator().manual_seed(i)).to(dev()))
+                  for i, s in enumerate(shapes)]
+    pa, pb = mk(), mk()
+    oa = FlatAdam(pa, lr=5e-4, betas=(0.9, 0.999))
+    ob = torch.optim.Adam(pb, lr=5e-4, betas=(0.9, 0.999))
+    assert isinstance(oa, torch.optim.Adam)
+    sizes = [p.numel() for p in pa]
+    gen = torch.Generator(device=dev()).manual_seed(1)
+    for it in range(6):
+        flat = torch.randn(sum(sizes), device=dev(), generator=gen) * (10.0 ** (it - 3))
+        if it % 3 == 0:      # one buffer (what MlpFn.backward produces)
+            ga = [t.view(s) for t, s in zip(flat.split(sizes), shapes)]
+        elif it % 3 == 1:    # two buffers (two networks under one optimizer, depth-supervised variant)
+            a, b = flat[:sum(sizes[:3])].clone(), flat[sum(sizes[:3]):].clone()
+            ga = [t.view(s) for t, s in zip(list(a.split(sizes[:3])) + list(b.split(sizes[3:])), shapes)]
+        else:                # unrelated tensors
+            ga = [t.clone().view(s) for t, s in zip(flat.split(sizes), shapes)]
+        skip = 4 if it == 4 else -1          # a parameter without a gradient is left alone
+        for k, (x, y) in enumerate(zip(pa, pb)):
+            x.grad = None if k == skip else ga[k]
+            y.grad = None if k == skip else ga[k].clone()
+        lr = 5e-4 * 0.1 ** (it / 3.0)
+        for o in (oa, ob):
+            for grp in o.param_groups:
+                grp["lr"] = lr
+            o.step()
+        for k, (x, y) in enumerate(zip(pa, pb)):
+            assert_close(x, y, atol=1e-7, rtol=2e-6, what=f"FlatAdam step {it} param {k}")
+    assert float(oa.state[pa[4]]["step"]) == 5.0 and float(oa.state[pa[0]]["step"]) == 6.0
+    # wire format: each loads the other's state and they keep agreeing
+    path = str(tmp_path / "opt.tar")
+    torch.save({"a": oa.state_dict(), "b": ob.state_dict()}, path)
+    ck = torch.load(path, map_location=dev())
+    pc, pd = mk(), mk()
+    for src, dst in ((pa, pc), (pb, pd)):
+        for x, y in zip(src, dst):
+            y.data.copy_(x.data)
+    oc = FlatAdam(pc, lr=5e-4, betas=(0.9, 0.999)); oc.load_state_dict(ck["b"])     # torch -> flat
+    od = torch.optim.Adam(pd, lr=5e-4, betas=(0.9, 0.999)); od.load_state_dict(ck["a"])   # flat -> torch
+    flat = torch.randn(sum(sizes), device=dev(), generator=gen)
+    for ps, o in ((pc, oc), (pd, od)):
+        for x, t, s_ in zip(ps, flat.split(sizes), shapes):
+            x.grad = t.clone().view(s_)
+        o.step()
+    for k, (x, y) in enumerate(zip(pc, pd)):
+        assert_close(x, y, atol=1e-7, rtol=2e-6, what=f"after state_dict crossing, param {k}")
+    assert float(oc.state[pc[0]]["step"]) == 7.0 and float(oc.state[pc[4]]["step"]) == 6.0
+
+
 def test_full_size_properties(P):
     """BASELINE config 2 sizes (4096 rays, 64+128): size-independent invariants."""
     from plnerf_amd import functional as Fn
