@@ -11,7 +11,7 @@ PEAK = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "f16x3": 2500.0, "f16":
 ap = argparse.ArgumentParser()
 ap.add_argument("--rays", type=int, default=65536)
 ap.add_argument("--samples", type=int, default=192)
-ap.add_argument("--precisions", default="fp32,bf16x3,bf16")
+ap.add_argument("--precisions", default="fp32,f16x3,bf16x3,f16,bf16")
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--train-rays", type=int, default=8192)
 a = ap.parse_args()

@@ -7,7 +7,7 @@ import torch
 import plnerf_amd as P
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--precisions", default="fp32,bf16x3,bf16")
+ap.add_argument("--precisions", default="fp32,f16x3,f16")
 ap.add_argument("--frames", type=int, default=2)
 ap.add_argument("--chunk", type=int, default=32768)
 a = ap.parse_args()
