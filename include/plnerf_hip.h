@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PLNERF_VERSION 200 /* major*10000 + minor*100 + patch */
+#define PLNERF_VERSION 210 /* major*10000 + minor*100 + patch */
 
 /* error codes */
 #define PLNERF_OK 0
@@ -143,6 +143,19 @@ int plnerf_sample_pl_bwd(const float* z, const float* tau, const float* T, const
                          const float* far, const float* u, int u_row_stride, const int64_t* inds,
                          const float* g_samples, int R, int S, int N, float zero_tol, float epsilon,
                          float* g_tau, float* g_T, plnerf_stream_t stream);
+
+/* Coarse sample depths of a ray batch (run_plnerf.py:683-705): z = near (1 - t) + far t over the table
+ * t_vals [S] (= torch.linspace(0, 1, S), supplied by the caller), or the `lindisp` form 1 / (1/near (1 - t) +
+ * 1/far t); with t_rand [R,S] (nullable) the stratified jitter z = lower + (upper - lower) t_rand between the
+ * mid-points.  near, far [R]; z_vals [R,S].  Operation order and rounding are the reference's, so the result is
+ * bit-identical to its torch expressions. */
+int plnerf_stratified_z(const float* near, const float* far, const float* t_vals, const float* t_rand,
+                        int R, int S, int lindisp, float* z_vals, plnerf_stream_t stream);
+
+/* Sample positions pts[r,s,:] = rays_o[r,:] + rays_d[r,:] * z_vals[r,s] (run_plnerf.py:708, :735).
+ * rays_o, rays_d [R,3]; z_vals [R,S]; pts [R,S,3]. */
+int plnerf_ray_points(const float* rays_o, const float* rays_d, const float* z_vals, int R, int S,
+                      float* pts, plnerf_stream_t stream);
 
 /* clamp(z_new, near, far) ++ z, sorted ascending per ray (run_plnerf.py:731-734).
  * z [R,S], z_new [R,N] -> out [R,S+N]; S+N <= 1024. */

@@ -572,3 +572,72 @@ extern "C" int plnerf_merge_sort(const float* z, const float* z_new, const float
     PLNERF_CHECK_LAUNCH();
     return PLNERF_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// Coarse sample depths (run_plnerf.py:683-705) and sample positions (:708, :735) of a ray batch: the dozen
+// element-wise torch launches of the reference's prologue as two kernels.  Every product and sum is rounded
+// separately, in the reference's order (the file is built with -ffp-contract=off), so z and pts are bit-identical
+// to the torch expressions.
+// ------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ float coarse_depth(const float nr, const float fr, const float t, const int lindisp) {
+    const float omt = 1.0f - t;
+    if (!lindisp) return nr * omt + fr * t;                 // near * (1 - t) + far * t
+    return 1.0f / (1.0f / nr * omt + 1.0f / fr * t);        // 1 / (1/near * (1 - t) + 1/far * t)
+}
+
+__global__ __launch_bounds__(256) void stratified_z_kernel(const float* __restrict__ near, const float* __restrict__ far,
+                                                           const float* __restrict__ t_vals,
+                                                           const float* __restrict__ t_rand, const int R, const int S,
+                                                           const int lindisp, float* __restrict__ z_out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)R * S) return;
+    const int r = (int)(idx / S), s = (int)(idx - (size_t)r * S);
+    const float nr = near[r], fr = far[r];
+    const float z = coarse_depth(nr, fr, t_vals[s], lindisp);
+    if (!t_rand) { z_out[idx] = z; return; }
+    // mids = .5 * (z[1:] + z[:-1]); upper = [mids, z[-1]]; lower = [z[0], mids]; z = lower + (upper - lower) * t_rand
+    const float zl = s > 0 ? coarse_depth(nr, fr, t_vals[s - 1], lindisp) : z;
+    const float zu = s + 1 < S ? coarse_depth(nr, fr, t_vals[s + 1], lindisp) : z;
+    const float lower = s > 0 ? 0.5f * (z + zl) : z;
+    const float upper = s + 1 < S ? 0.5f * (zu + z) : z;
+    z_out[idx] = lower + (upper - lower) * t_rand[idx];
+}
+
+__global__ __launch_bounds__(256) void ray_points_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                         const float* __restrict__ z, const int R, const int S,
+                                                         float* __restrict__ pts) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // one (ray, sample, coordinate)
+    if (idx >= (size_t)R * S * 3) return;
+    const size_t rs = idx / 3;
+    const int c = (int)(idx - rs * 3);
+    const int r = (int)(rs / S);
+    pts[idx] = rays_o[3 * (size_t)r + c] + rays_d[3 * (size_t)r + c] * z[rs];
+}
+
+}  // namespace
+
+extern "C" int plnerf_stratified_z(const float* near, const float* far, const float* t_vals, const float* t_rand,
+                                   int R, int S, int lindisp, float* z_vals, plnerf_stream_t stream) {
+    if (R < 0 || S < 1) return PLNERF_EINVAL;
+    if (R == 0) return PLNERF_OK;
+    if (!near || !far || !t_vals || !z_vals) return PLNERF_EINVAL;
+    const size_t n = (size_t)R * S;
+    hipLaunchKernelGGL(stratified_z_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, near,
+                       far, t_vals, t_rand, R, S, lindisp, z_vals);
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}
+
+extern "C" int plnerf_ray_points(const float* rays_o, const float* rays_d, const float* z_vals, int R, int S,
+                                 float* pts, plnerf_stream_t stream) {
+    if (R < 0 || S < 1) return PLNERF_EINVAL;
+    if (R == 0) return PLNERF_OK;
+    if (!rays_o || !rays_d || !z_vals || !pts) return PLNERF_EINVAL;
+    const size_t n = (size_t)R * S * 3;
+    hipLaunchKernelGGL(ray_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rays_o,
+                       rays_d, z_vals, R, S, pts);
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}

@@ -307,6 +307,31 @@ def merge_sort(z, z_new, near, far):
     return out
 
 
+def stratified_z(near, far, t_vals, t_rand, lindisp=False):
+    """plnerf_stratified_z: the coarse sample depths of run_plnerf.py:683-705 (no gradient: the ray batch carries
+    none on this path).  near, far [R] or [R,1]; t_vals [S]; t_rand [R,S] or None."""
+    near_c, far_c = _f32c(near).reshape(-1), _f32c(far).reshape(-1)
+    t_c = _f32c(t_vals)
+    r_c = _f32c(t_rand) if t_rand is not None else None
+    R, S = near_c.shape[0], t_c.shape[0]
+    out = torch.empty(R, S, device=near_c.device)
+    L.check(L.lib().plnerf_stratified_z(
+        L.dptr(near_c, "near"), L.dptr(far_c, "far"), L.dptr(t_c, "t_vals"), L.dptr(r_c, "t_rand"), R, S,
+        int(bool(lindisp)), L.dptr(out), L.stream()), "plnerf_stratified_z")
+    return out
+
+
+def ray_points(rays_o, rays_d, z_vals):
+    """plnerf_ray_points: pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+    (run_plnerf.py:708, :735), no gradient."""
+    o_c, d_c, z_c = _f32c(rays_o), _f32c(rays_d), _f32c(z_vals)
+    R, S = z_c.shape
+    out = torch.empty(R, S, 3, device=z_c.device)
+    L.check(L.lib().plnerf_ray_points(L.dptr(o_c, "rays_o"), L.dptr(d_c, "rays_d"), L.dptr(z_c, "z_vals"), R, S,
+                                      L.dptr(out), L.stream()), "plnerf_ray_points")
+    return out
+
+
 _LINSPACE_CACHE = {}
 
 

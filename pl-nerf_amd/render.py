@@ -149,23 +149,36 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_
     near, far = ray_batch[:, 6:7].contiguous(), ray_batch[:, 7:8].contiguous()
 
     t_vals = Fn.cpu_linspace(N_samples, dev)
-    if not lindisp:
-        z_vals = near * (1. - t_vals) + far * t_vals
+    # The ray batch carries no gradient on this path (the reference never differentiates through the rays and
+    # the kernels downstream give none to positions), so the prologue's element-wise chain runs as two kernels,
+    # bit-identical to the torch expressions below -- which stay for a batch that does require grad, so that z_vals
+    # remains on the caller's tape.
+    fused_glue = ray_batch.is_cuda and N_rays > 0 and not (torch.is_grad_enabled() and ray_batch.requires_grad)
+    if fused_glue:
+        t_rand = None
+        if perturb > 0.:
+            shape = [N_rays, N_samples]
+            t_rand = Fn.numpy_uniform(shape, dev) if pytest else torch.rand(shape, device=dev)
+        z_vals = Fn.stratified_z(near, far, t_vals, t_rand, lindisp)
+        pts = Fn.ray_points(rays_o, rays_d, z_vals)
     else:
-        z_vals = 1. / (1. / near * (1. - t_vals) + 1. / far * t_vals)
-    z_vals = z_vals.expand([N_rays, N_samples])
-
-    if perturb > 0.:
-        mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
-        upper = torch.cat([mids, z_vals[..., -1:]], -1)
-        lower = torch.cat([z_vals[..., :1], mids], -1)
-        if pytest:
-            t_rand = Fn.numpy_uniform(list(z_vals.shape), dev)
+        if not lindisp:
+            z_vals = near * (1. - t_vals) + far * t_vals
         else:
-            t_rand = torch.rand(z_vals.shape, device=dev)
-        z_vals = lower + (upper - lower) * t_rand
+            z_vals = 1. / (1. / near * (1. - t_vals) + 1. / far * t_vals)
+        z_vals = z_vals.expand([N_rays, N_samples])
 
-    pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+        if perturb > 0.:
+            mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+            upper = torch.cat([mids, z_vals[..., -1:]], -1)
+            lower = torch.cat([z_vals[..., :1], mids], -1)
+            if pytest:
+                t_rand = Fn.numpy_uniform(list(z_vals.shape), dev)
+            else:
+                t_rand = torch.rand(z_vals.shape, device=dev)
+            z_vals = lower + (upper - lower) * t_rand
+
+        pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
 
     if constant_init:   # run_plnerf.py:710-711: overrides the mode for the whole call
         mode = "constant"
@@ -189,7 +202,10 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_
         # clamp + cat + sort (run_plnerf.py:731-734) in one kernel; z_samples clamped for z_std
         z_vals = Fn.merge_sort(z_vals, z_samples, near, far)
         z_samples = torch.clamp(z_samples, near, far)
-        pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+        if fused_glue:
+            pts = Fn.ray_points(rays_o, rays_d, z_vals)
+        else:
+            pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
 
         run_fn = network_fn if network_fine is None else network_fine
         raw = network_query_fn(pts, viewdirs, run_fn)

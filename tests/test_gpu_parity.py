@@ -308,6 +308,36 @@ def test_sample_const_backward_vs_oracle_autograd(P):
         assert e_hip <= 2 * e_orc + 1e-5, (e_hip, e_orc)
 
 
+@pytest.mark.parametrize("S", [64, 128, 37, 1])
+def test_ray_sampling_prologue_bit_exact(P, S):
+    """plnerf_stratified_z / plnerf_ray_points against the reference's torch expressions (run_plnerf.py:683-708):
+    the same operations in the same order, each rounded once, so the results are bit-identical -- with and without
+    the stratified jitter, in depth and in disparity (`lindisp`)."""
+    from plnerf_amd import functional as Fn
+    R = 777
+    gen = torch.Generator().manual_seed(S)
+    near = g(0.5 + 2.0 * torch.rand(R, 1, generator=gen))
+    far = near + g(0.5 + 5.0 * torch.rand(R, 1, generator=gen))
+    rays_o, rays_d = g(torch.randn(R, 3, generator=gen)), g(torch.randn(R, 3, generator=gen))
+    t_vals = Fn.cpu_linspace(S, dev())
+    t_rand = g(torch.rand(R, S, generator=gen))
+    for lindisp in (False, True):
+        if not lindisp:
+            z_ref = near * (1. - t_vals) + far * t_vals
+        else:
+            z_ref = 1. / (1. / near * (1. - t_vals) + 1. / far * t_vals)
+        z_ref = z_ref.expand([R, S])
+        assert torch.equal(Fn.stratified_z(near, far, t_vals, None, lindisp), z_ref)
+        mids = .5 * (z_ref[..., 1:] + z_ref[..., :-1])
+        upper = torch.cat([mids, z_ref[..., -1:]], -1)
+        lower = torch.cat([z_ref[..., :1], mids], -1)
+        z_jit = lower + (upper - lower) * t_rand
+        z = Fn.stratified_z(near, far, t_vals, t_rand, lindisp)
+        assert torch.equal(z, z_jit)
+        pts_ref = rays_o[..., None, :] + rays_d[..., None, :] * z_jit[..., :, None]
+        assert torch.equal(Fn.ray_points(rays_o, rays_d, z), pts_ref)
+
+
 def test_merge_sort(P):
     from plnerf_amd import functional as Fn
     for R, S, N in ((513, 64, 128), (64, 128, 64), (3, 1, 1), (7, 500, 524)):

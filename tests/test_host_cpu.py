@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(built):
     for name in sorted(declared):
         assert hasattr(handle, name), f"{name} declared in plnerf_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert built.library_version() == 200
+    assert built.library_version() == 210
     assert _lib.lib().plnerf_error_string(-3).decode().startswith("size outside")
 
 
