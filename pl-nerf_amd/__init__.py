@@ -9,13 +9,12 @@ from . import _lib
 from .nerf import NeRF, Embedder, get_embedder
 from .rays import get_rays, get_rays_np, ndc_rays
 from .optim import FlatAdam
-from .train import TrainStep, checkpoint_path, save_checkpoint, select_rays
+from .train import TrainStep, checkpoint_path, img2mse, save_checkpoint, select_rays
 from . import depth   # depth-supervised variant of the path (depth_supervised_exps/)
 from .render import (batchify, batchify_rays, compute_weights, compute_weights_piecewise_linear, create_nerf,
                      raw2outputs, render, render_path, render_rays, run_network, sample_pdf,
                      sample_pdf_reformulation)
 
-img2mse = lambda x, y: ((x - y) ** 2).mean()   # run_nerf_helpers.py:17
 
 
 def library_path():
