@@ -1,0 +1,22 @@
+#!/bin/bash
+# Same-box A/B of a compile-time flag: builds the working tree twice (with / without -D$FLAG) and alternates.
+#   gpurun -- 'FLAG=PLNERF_NT_WEIGHTS bash tools/ab_flag.sh'
+set -e
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R/pl-nerf_amd/csrc
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -w -D${FLAG} -shared -o /tmp/flag.so capi.hip quad.hip sampler.hip mlp_api.hip mlp_f32.hip mlp_bf16.hip
+cd $R
+for i in 1 2 3; do for v in off on; do
+  if [ $v = on ]; then export PLNERF_HIP_LIB=/tmp/flag.so; else unset PLNERF_HIP_LIB; fi
+  python bench.py --no-cpu-baseline --steps 10 --warmup 3 ${BENCH_ARGS} 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('${FLAG} $v: step ms', round(d['ms_per_step'], 3), 'fwd', round(d['roofline']['launch_ms'],3), 'bwd ms', round(d['roofline']['mlp_bwd_launch_ms'], 3))"
+done; done
+if [ -n "$MLP" ]; then for v in off on; do
+  if [ $v = on ]; then export PLNERF_HIP_LIB=/tmp/flag.so; else unset PLNERF_HIP_LIB; fi
+  python tools/bench_mlp.py --precisions f16x3,bf16 --iters 5 2>/dev/null | grep inference | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); print('${FLAG} $v', d['precision'], round(d['ms'], 2), 'ms', round(d['tflops']), 'TFLOP/s')"
+done; fi
