@@ -964,6 +964,51 @@ def test_empty_and_ragged_batches(P, precision):
         assert_close(ret[k], ref[k], atol=tol, rtol=tol, what=f"1 ray 9+5 {precision} {k}")
 
 
+def test_render_rays_random_configurations(P):
+    """Differential sweep of render_rays' argument space against the oracle on the reference's deterministic
+    (pytest=True) draws: sample counts, mode / colour mode, background, noise, disparity sampling, constant_init,
+    farcolorfix.  Coarse-pass outputs to 1e-5 on every ray; the final maps to 3e-5 on all but a few rays and to 5e-3
+    on those (they sit behind the sampler's discontinuities)."""
+    rng = np.random.default_rng(1234)
+    # the "sharpened" weights (acc ~ 1): with near-zero densities 1 - exp(-sigma dist) cancels to ~4 digits in ANY
+    # fp32 evaluation (the reference's included), and the sampler turns that into 1e-3 shifts of the fine samples
+    sd = orc.closed_form_state_dict(0, True)
+    nc, nf = make_net(P, sd), make_net(P, sd)
+    emb_fn, _ = P.get_embedder(10, 0)
+    embd_fn, _ = P.get_embedder(4, 0)
+    qfn = lambda inputs, viewdirs, fn: P.run_network(inputs, viewdirs, fn, emb_fn, embd_fn)
+    for case in range(14):
+        mode = ["linear", "constant"][int(rng.integers(2))]
+        cfg = dict(
+            N_samples=int(rng.choice([8, 17, 32, 64])), N_importance=int(rng.choice([4, 9, 32, 128])),
+            mode=mode, color_mode=["midpoint", "left"][int(rng.integers(2))], white_bkgd=bool(rng.integers(2)),
+            raw_noise_std=float(rng.choice([0.0, 1.0])), lindisp=bool(rng.integers(2)),
+            # jittered draws only: det=True puts u = 1.0 on the searchsorted knife edge (SURVEY a8), where a 1-ulp
+            # difference in a coarse weight moves the last draw of EVERY ray by a bin -- the det path is pinned
+            # bit-exactly on identical inputs by the sampler tests instead
+            perturb=1.0,
+            constant_init=bool(rng.integers(4) == 0), farcolorfix=bool(rng.integers(2)))
+        R = int(rng.choice([1, 7, 33]))
+        batch, _ = orc.synthetic_blender_rays(R, seed=100 + case)
+        kw = dict(cfg)
+        Ns, mo, cm = kw.pop("N_samples"), kw.pop("mode"), kw.pop("color_mode")
+        with torch.no_grad():
+            ret = P.render_rays(g(batch), nc, qfn, Ns, mo, cm, retraw=True, network_fine=nf, pytest=True, **kw)
+        ref = orc.render_rays(batch, sd, sd, Ns, mo, cm, retraw=True, pytest=True, **kw)
+        assert set(ret) == set(ref), (cfg, set(ret) ^ set(ref))
+        for k in ("rgb0", "acc0", "depth0"):
+            assert_close(ret[k], ref[k], what=f"case {case} {cfg} {k}")
+        # behind the sampler a 1e-7 difference in a coarse weight can move a draw into the neighbouring bin (flat
+        # stretches of the cdf where relu(sigma + noise) = 0): a few fine samples then differ between ANY two fp32
+        # implementations.  A wrong flag or a wrong operand would move every ray.
+        assert ret["raw"].shape == ref["raw"].shape and ret["z_std"].shape == ref["z_std"].shape
+        for k in ("rgb_map", "acc_map", "depth_map"):
+            a, b = ret[k].detach().cpu().double(), ref[k].double()
+            err = ((a - b).abs() / (1.0 + b.abs())).reshape(a.shape[0], -1).amax(dim=1)
+            assert float(err.max()) <= 5e-3, f"case {case} {cfg} {k}: max error {float(err.max()):.2e}"
+            assert int((err > 3e-5).sum()) <= max(1, a.shape[0] // 4), f"case {case} {cfg} {k}: {int((err > 3e-5).sum())} rays off"
+
+
 def test_fused_adam_matches_torch(P):
     from plnerf_amd import _lib as L
     gen = torch.Generator().manual_seed(0)
