@@ -727,6 +727,138 @@ __global__ __launch_bounds__(512) void wgrad_tr16_kernel(WgradArgs a) {
     }
 }
 
+// The thin jobs (256 x 64 encoding columns of L0 / L5, 128 x 32 direction columns of the view layer) on their own
+// kernel.  A stage costs its HBM latency whatever its width, and a thin job's stage is only 20-40 KB per CU, so
+// ONE stage ahead left the launch at 3.9 TB/s.  Here two stages are in flight, in two register sets -- which
+// only works if the compiler can COUNT the outstanding loads: gfx9 retires loads in order on one vmcnt, and a load
+// issued under a run-time predicate (slot in range? row in range?) makes the count unknown, so every wait becomes
+// vmcnt(0) and the younger stage's latency is back on the critical path (a first attempt inside the generic
+// kernel measured +-0 for exactly that reason).  O and I are therefore template parameters (slot counts static),
+// rows past the range are loaded from the clamped last row and zeroed by a select.
+template <int O, int I>
+__device__ __forceinline__ void wgrad_thin_body(const WgradArgs& a, const WJob& job, unsigned char* smem_raw) {
+    constexpr int NO = 2, WI = 2, KST = TR_STEPS, SROWS = TR_ROWS * KST, SPLANE = SROWS * TR_RS;
+    constexpr int A_C8 = O / 8, B_C8 = I / 8;
+    constexpr int SA = SROWS * A_C8 / 512;                  // A chunks per thread and stage: 4 (O = 256) or 2
+    constexpr int B_THREADS = SROWS * B_C8;                 // threads that hold a B chunk: 512 (I = 64) or 256
+    static_assert(SROWS * A_C8 % 512 == 0 && B_THREADS <= 512 && 512 % B_THREADS == 0, "slot layout");
+    _Float16* lds = reinterpret_cast<_Float16*>(smem_raw);   // [buffer 2][operand A,B][SROWS][TR_RS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const _Float16* Ag = (const _Float16*)job.A;
+    const _Float16* Bg = (const _Float16*)job.B;
+    const int wo = wave / WI, wi = wave % WI;
+    const int o_base = wo * NO * 32, i_base = wi * 32;
+    const bool live = o_base < O && i_base < I;
+    const int split = blockIdx.y;
+    const int m_begin = split * a.rows_per_split;
+    const int m_end = min(a.n_rows, m_begin + a.rows_per_split);
+    int a_row[SA], a_col[SA];
+#pragma unroll
+    for (int j = 0; j < SA; ++j) {
+        const int q = tid + 512 * j;
+        a_row[j] = q / A_C8; a_col[j] = (q % A_C8) * 8;
+    }
+    const int bq = tid % B_THREADS, b_row = bq / B_C8, b_col = (bq % B_C8) * 8;   // (threads past B_THREADS reload a
+    const bool b_owner = tid < B_THREADS;                                          //  neighbour's chunk, unused)
+    struct Set { wh8 a[SA]; wh8 b; };
+    Set s0, s1;
+    float bs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs[e] = 0.0f;
+    const wh8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // (the zeroing select lives in stash, not here: a consumer right behind the load would put the new stage's
+    // latency back in front of this stage's MFMAs)
+    auto fetch = [&](Set& s, const int m) {
+        const int last = m_end - 1;
+#pragma unroll
+        for (int j = 0; j < SA; ++j)
+            s.a[j] = *reinterpret_cast<const wh8*>(Ag + (size_t)min(m + a_row[j], last) * O + a_col[j]);
+        s.b = *reinterpret_cast<const wh8*>(Bg + (size_t)min(m + b_row, last) * I + b_col);
+    };
+    auto stash = [&](const Set& s, const int buf, const int m) {
+        _Float16* A0 = lds + (size_t)buf * 2 * SPLANE;
+        _Float16* B0 = A0 + SPLANE;
+#pragma unroll
+        for (int j = 0; j < SA; ++j) {
+            const wh8 v = m + a_row[j] < m_end ? s.a[j] : zero8;
+            *reinterpret_cast<wh8*>(A0 + a_row[j] * TR_RS + a_col[j]) = v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bs[e] += (float)v[e];
+        }
+        if (b_owner) *reinterpret_cast<wh8*>(B0 + b_row * TR_RS + b_col) = m + b_row < m_end ? s.b : zero8;
+    };
+    f32x16 acc[NO][1];
+    zero_acc(acc);
+    auto compute = [&](const int buf) {
+        if (!live) return;
+        const _Float16* A0 = lds + (size_t)buf * 2 * SPLANE;
+        const _Float16* B0 = A0 + SPLANE;
+#pragma unroll
+        for (int k = 0; k < KST; ++k) {
+            wh8 af[NO];
+#pragma unroll
+            for (int o = 0; o < NO; ++o) af[o] = tr_frag(A0 + k * TR_PLANE, lane, o_base + 32 * o);
+            const wh8 bf = tr_frag(B0 + k * TR_PLANE, lane, i_base);
+#pragma unroll
+            for (int o = 0; o < NO; ++o)
+                acc[o][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[o], bf, acc[o][0], 0, 0, 0);
+        }
+    };
+    // stage i is computed from LDS buffer i & 1 while stage i+1 sits in a register set (requested one iteration ago)
+    // and stage i+2 is requested into the other set; two iterations per trip keep the sets static
+    // Fetches are UNCONDITIONAL (a stage past the range re-reads the clamped last row and is never stashed): a
+    // branch around a fetch would again leave the number of outstanding loads unknown at the next wait.
+    if (m_begin >= m_end) return;     // (uniform; only when there are more row ranges than rows)
+    fetch(s0, m_begin);
+    fetch(s1, m_begin + SROWS);
+    stash(s0, 0, m_begin);
+    __syncthreads();
+    for (int m = m_begin; m < m_end; m += 2 * SROWS) {
+        fetch(s0, m + 2 * SROWS);
+        compute(0);
+        if (m + SROWS < m_end) stash(s1, 1, m + SROWS);
+        __syncthreads();
+        if (m + SROWS >= m_end) break;
+        fetch(s1, m + 3 * SROWS);
+        compute(1);
+        if (m + 2 * SROWS < m_end) stash(s0, 0, m + 2 * SROWS);
+        __syncthreads();
+    }
+    float* part = a.part + (size_t)split * PART_PER_SPLIT;
+    if (live) {
+        float* cpart = part + job.part_off;
+        const int ll = lane & 31;
+#pragma unroll
+        for (int o = 0; o < NO; ++o)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                cpart[(size_t)(o_base + o * 32 + frag_row(r, lane)) * I + i_base + ll] = acc[o][0][r];
+    }
+    if (job.bias_off >= 0) {
+        // bias partial = column sums of the dz slabs: a thread's slots share one chunk column (512 % A_C8 == 0)
+        float* red = reinterpret_cast<float*>(smem_raw);      // [512 / A_C8 rows][O] floats, reusing the LDS
+        constexpr int RED_ROWS = 512 / A_C8;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[a_row[0] * O + a_col[0] + e] = bs[e];
+        __syncthreads();
+        for (int f = tid; f < O; f += 512) {
+            float sum = 0.0f;
+            for (int r = 0; r < RED_ROWS; ++r) sum += red[r * O + f];
+            part[job.bias_off + f] = sum;
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void wgrad_thin_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int j = a.tile_job[blockIdx.x];
+    const WJob job = a.jobs[j];
+    if (job.O == W) wgrad_thin_body<W, PE_K>(a, job, smem_raw);      // encoding columns of L0 / L5
+    else wgrad_thin_body<HV, DPE_K>(a, job, smem_raw);               // direction columns of the view layer
+}
+
 // sigma / rgb heads: dW_alpha = sum_m g_sigma h7, dW_rgb[c] = sum_m g_c hv, and their biases
 template <typename PT>
 struct HeadArgs {
@@ -1084,7 +1216,9 @@ int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, co
             // (Equal ROW counts per workgroup, not equal bytes: a stage costs its latency whatever its width, so
             // giving the 128 x 32 job half as many, twice as long ranges measured 0.27 ms slower per step.)
             a.rows_per_split = rps_thin;
-            launch_tr16<1>(dim3(3, splits_thin), st, a);
+            const size_t lds = (size_t)2 * 2 * TR_STEPS * TR_PLANE * sizeof(_Float16);
+            (void)hipFuncSetAttribute((const void*)wgrad_thin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(wgrad_thin_kernel, dim3(3, splits_thin), dim3(512), lds, st, a);
         } else {
             hipLaunchKernelGGL((wgrad_f32_kernel<4, 1, 2, 2, 4>), dim3(2, splits), dim3(256), 0, st, a);
             PLNERF_CHECK_LAUNCH();
