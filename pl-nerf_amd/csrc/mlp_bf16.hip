@@ -20,7 +20,7 @@
 // consecutive k of the next layer: the bias+ReLU epilogue converts them and writes one 8-byte LDS store per plane,
 // in place.  A 512-thread workgroup owns a tile of TM samples (128 plain, 64 split) and walks all 12 layers without
 // leaving the CU.  State saved for the backward: IEEE-half planes + ReLU bit masks (mlp_layout.h); the weight-
-// gradient stage (mlp_f32.hip: wgrad_tr16_kernel) is shared by all four modes.
+// gradient stage (mlp_f32.hip: wgrad_main_kernel, wgrad_thin_kernel) is shared by all four modes.
 #include <cstdlib>
 #include <type_traits>
 

@@ -25,7 +25,7 @@
 // wgrad_reduce_kernel sums the split-K partials deterministically into the 24 gradient
 // tensors in their original [out][in] layout.
 //
-// This file also holds the weight-gradient stage of the 16-bit modes (wgrad_tr16_kernel on the half planes,
+// This file also holds the weight-gradient stage of the 16-bit modes (wgrad_main_kernel, wgrad_thin_kernel on the half planes,
 // absmax_kernel for their scale): launcher, head and reduction kernels are shared with the fp32 mode.
 //
 // Numerics: f32 MFMA is bit-for-bit an fmaf chain; only the summation order differs from
@@ -578,9 +578,8 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradArgs a) {
 // the gfx950 transposing LDS read (lane = feature column, 4 consecutive rows per read; row stride
 // 576 B puts the 4 rows of a read on disjoint banks; semantics pinned by tools/probes/tr16_probe.hip).
 // A stage is TR_STEPS k-steps (64 rows): stage k+1 is fetched into registers before stage k's MFMAs and
-// written to LDS after them; one barrier per stage.  (Fetching two 16-row stages ahead into a second
-// register set measured 11 % slower.)  8 waves as 4(o) x 2(i), each 64(o) x 32 NI(i): a 256 x 256 workgroup tile
-// reads every plane once.  (History: a register-only version re-split fp32 operands in every wave
+// written to LDS after them; one barrier per stage.  8 waves as 4(o) x 2(i), each 64(o) x 32 NI(i): a 256 x 256
+// workgroup tile reads every plane once.  (History: a register-only version re-split fp32 operands in every wave
 // and was VALU-bound, 24 % MFMA busy -- profiles/r01_bf16x3_pmc_sq_tcp_before_lds_wgrad.txt.)
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 typedef _Float16 wh8 __attribute__((ext_vector_type(8)));
@@ -606,149 +605,31 @@ __device__ __forceinline__ wh8 tr_frag(const _Float16* plane, int lane, int col0
     return u.v;
 }
 
-template <int NI>
-__global__ __launch_bounds__(512) void wgrad_tr16_kernel(WgradArgs a) {
-    constexpr int NO = 2, WI = 2;
-    constexpr int KST = TR_STEPS, SROWS = TR_ROWS * KST;      // k-steps / rows per stage
-    constexpr int SPLANE = SROWS * TR_RS;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    _Float16* lds = reinterpret_cast<_Float16*>(smem_raw);   // [buffer 2][operand A,B][SROWS][TR_RS]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const WJob job = a.jobs[a.tile_job[blockIdx.x]];
-    const _Float16* Ag = (const _Float16*)job.A;
-    const _Float16* Bg = (const _Float16*)job.B;
-    const int wo = wave / WI, wi = wave % WI;
-    const int o_base = a.tile_o0[blockIdx.x] + wo * NO * 32;
-    const int i_base = wi * NI * 32;
-    const bool live = o_base < job.O && i_base < job.I;
-    const int split = blockIdx.y;
-    const int m_begin = split * a.rows_per_split;
-    const int m_end = min(a.n_rows, m_begin + a.rows_per_split);
-    // this thread's (row, 8-half chunk) slots in the stage's slab of each operand (O, I <= 256: KST each)
-    const int a_c8 = job.O >> 3, b_c8 = job.I >> 3;
-    int a_row[KST], a_col[KST], b_row[KST], b_col[KST];
-#pragma unroll
-    for (int j = 0; j < KST; ++j) {
-        const int q = tid + 512 * j;
-        a_row[j] = q / a_c8; a_col[j] = (q - a_row[j] * a_c8) * 8;
-        b_row[j] = q / b_c8; b_col[j] = (q - b_row[j] * b_c8) * 8;
-    }
-    wh8 ra[KST], rb[KST];
-    float bs[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bs[e] = 0.0f;
-    auto fetch = [&](int m) {
-#pragma unroll
-        for (int j = 0; j < KST; ++j) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { ra[j][e] = (_Float16)0.0f; rb[j][e] = (_Float16)0.0f; }
-            if (a_row[j] < SROWS && m + a_row[j] < m_end)
-                ra[j] = *reinterpret_cast<const wh8*>(Ag + (size_t)(m + a_row[j]) * job.lda + a_col[j]);
-            if (b_row[j] < SROWS && m + b_row[j] < m_end)
-                rb[j] = *reinterpret_cast<const wh8*>(Bg + (size_t)(m + b_row[j]) * job.ldb + b_col[j]);
-        }
-    };
-    auto stash = [&](int buf) {
-        _Float16* A0 = lds + (size_t)buf * 2 * SPLANE;
-        _Float16* B0 = A0 + SPLANE;
-#pragma unroll
-        for (int j = 0; j < KST; ++j) {
-            if (a_row[j] < SROWS) {
-                *reinterpret_cast<wh8*>(A0 + a_row[j] * TR_RS + a_col[j]) = ra[j];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bs[e] += (float)ra[j][e];
-            }
-            if (b_row[j] < SROWS) *reinterpret_cast<wh8*>(B0 + b_row[j] * TR_RS + b_col[j]) = rb[j];
-        }
-    };
-    f32x16 acc[NO][NI];
-    zero_acc(acc);
-    if (m_begin < m_end) {
-        fetch(m_begin);
-        stash(0);
-    }
-    __syncthreads();
-    int buf = 0;
-    for (int m = m_begin; m < m_end; m += SROWS, buf ^= 1) {
-        const bool more = m + SROWS < m_end;
-        if (more) fetch(m + SROWS);
-        if (live) {
-            const _Float16* A0 = lds + (size_t)buf * 2 * SPLANE;
-            const _Float16* B0 = A0 + SPLANE;
-#pragma unroll
-            for (int k = 0; k < KST; ++k) {
-                wh8 af[NO], bf[NI];
-#pragma unroll
-                for (int o = 0; o < NO; ++o) af[o] = tr_frag(A0 + k * TR_PLANE, lane, o_base + 32 * o);
-#pragma unroll
-                for (int i = 0; i < NI; ++i) bf[i] = tr_frag(B0 + k * TR_PLANE, lane, i_base + 32 * i);
-#pragma unroll
-                for (int o = 0; o < NO; ++o)
-#pragma unroll
-                    for (int i = 0; i < NI; ++i)
-                        acc[o][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[o], bf[i], acc[o][i], 0, 0, 0);
-            }
-        }
-        if (more) stash(buf ^ 1);
-        __syncthreads();
-    }
-    float* part = a.part + (size_t)split * PART_PER_SPLIT;
-    if (live) {
-        float* cpart = part + job.part_off;
-        const int ll = lane & 31;
-#pragma unroll
-        for (int o = 0; o < NO; ++o)
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int orow = o_base + o * 32 + frag_row(r, lane);
-                    const int icol = i_base + i * 32 + ll;
-                    cpart[(size_t)orow * job.I + icol] = acc[o][i][r];
-                }
-    }
-    if (job.bias_off >= 0) {
-        // bias partial = column sums of the dz slabs: every thread summed its chunk column over its row slots
-        // (the slots of one thread share a_col only when O/8 divides 512, i.e. O = 256 or 128: true for all jobs)
-        float* red = reinterpret_cast<float*>(smem_raw);      // [512 * 8 / O rows][O] floats, reusing the LDS
-        const int red_rows = 512 / a_c8;
-        __syncthreads();
-        if (a_row[0] < red_rows) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) red[a_row[0] * job.O + a_col[0] + e] = bs[e];
-        }
-        __syncthreads();
-        for (int f = tid; f < job.O; f += 512) {
-            float sum = 0.0f;
-            for (int r = 0; r < red_rows; ++r) sum += red[r * job.O + f];
-            part[job.bias_off + f] = sum;
-        }
-    }
-}
-
-// The thin jobs (256 x 64 encoding columns of L0 / L5, 128 x 32 direction columns of the view layer) on their own
-// kernel.  A stage costs its HBM latency whatever its width, and a thin job's stage is only 20-40 KB per CU, so
+// One body for every job shape.  The thin jobs (256 x 64 encoding columns of L0 / L5, 128 x 32 direction columns
+// of the view layer) run it DEEP: a stage costs its HBM latency whatever its width, and a thin job's stage is only 20-40 KB per CU, so
 // ONE stage ahead left the launch at 3.9 TB/s.  Here two stages are in flight, in two register sets -- which
 // only works if the compiler can COUNT the outstanding loads: gfx9 retires loads in order on one vmcnt, and a load
 // issued under a run-time predicate (slot in range? row in range?) makes the count unknown, so every wait becomes
 // vmcnt(0) and the younger stage's latency is back on the critical path (a first attempt inside the generic
 // kernel measured +-0 for exactly that reason).  O and I are therefore template parameters (slot counts static),
 // rows past the range are loaded from the clamped last row and zeroed by a select.
-template <int O, int I>
-__device__ __forceinline__ void wgrad_thin_body(const WgradArgs& a, const WJob& job, unsigned char* smem_raw) {
+template <int O, int I, int NI, bool DEEP>
+__device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& job, unsigned char* smem_raw) {
     constexpr int NO = 2, WI = 2, KST = TR_STEPS, SROWS = TR_ROWS * KST, SPLANE = SROWS * TR_RS;
     constexpr int A_C8 = O / 8, B_C8 = I / 8;
     constexpr int SA = SROWS * A_C8 / 512;                  // A chunks per thread and stage: 4 (O = 256) or 2
-    constexpr int B_THREADS = SROWS * B_C8;                 // threads that hold a B chunk: 512 (I = 64) or 256
-    static_assert(SROWS * A_C8 % 512 == 0 && B_THREADS <= 512 && 512 % B_THREADS == 0, "slot layout");
+    constexpr int B_CHUNKS = SROWS * B_C8;                  // B chunks per stage: 2048 (I = 256), 512 (64), 256 (32)
+    constexpr int SB = B_CHUNKS >= 512 ? B_CHUNKS / 512 : 1;
+    constexpr int B_THREADS = B_CHUNKS >= 512 ? 512 : B_CHUNKS;   // threads that own a B chunk
+    static_assert(SROWS * A_C8 % 512 == 0 && B_CHUNKS % B_THREADS == 0 && 512 % B_THREADS == 0, "slot layout");
+    static_assert(I == NI * 32 * WI || I == 32, "two waves across I");
     _Float16* lds = reinterpret_cast<_Float16*>(smem_raw);   // [buffer 2][operand A,B][SROWS][TR_RS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const _Float16* Ag = (const _Float16*)job.A;
     const _Float16* Bg = (const _Float16*)job.B;
     const int wo = wave / WI, wi = wave % WI;
-    const int o_base = wo * NO * 32, i_base = wi * 32;
+    const int o_base = wo * NO * 32, i_base = wi * NI * 32;
     const bool live = o_base < O && i_base < I;
     const int split = blockIdx.y;
     const int m_begin = split * a.rows_per_split;
@@ -759,10 +640,15 @@ __device__ __forceinline__ void wgrad_thin_body(const WgradArgs& a, const WJob& 
         const int q = tid + 512 * j;
         a_row[j] = q / A_C8; a_col[j] = (q % A_C8) * 8;
     }
-    const int bq = tid % B_THREADS, b_row = bq / B_C8, b_col = (bq % B_C8) * 8;   // (threads past B_THREADS reload a
-    const bool b_owner = tid < B_THREADS;                                          //  neighbour's chunk, unused)
-    struct Set { wh8 a[SA]; wh8 b; };
-    Set s0, s1;
+    int b_row[SB], b_col[SB];
+#pragma unroll
+    for (int j = 0; j < SB; ++j) {
+        const int q = tid % B_THREADS + 512 * j;           // (threads past B_THREADS reload a neighbour's chunk, unused)
+        b_row[j] = q / B_C8; b_col[j] = (q % B_C8) * 8;
+    }
+    const bool b_owner = tid < B_THREADS;
+    struct Set { wh8 a[SA]; wh8 b[SB]; };
+    Set s0, s1;      // (s1 only in the DEEP variant)
     float bs[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bs[e] = 0.0f;
@@ -774,7 +660,9 @@ __device__ __forceinline__ void wgrad_thin_body(const WgradArgs& a, const WJob& 
 #pragma unroll
         for (int j = 0; j < SA; ++j)
             s.a[j] = *reinterpret_cast<const wh8*>(Ag + (size_t)min(m + a_row[j], last) * O + a_col[j]);
-        s.b = *reinterpret_cast<const wh8*>(Bg + (size_t)min(m + b_row, last) * I + b_col);
+#pragma unroll
+        for (int j = 0; j < SB; ++j)
+            s.b[j] = *reinterpret_cast<const wh8*>(Bg + (size_t)min(m + b_row[j], last) * I + b_col[j]);
     };
     auto stash = [&](const Set& s, const int buf, const int m) {
         _Float16* A0 = lds + (size_t)buf * 2 * SPLANE;
@@ -786,9 +674,13 @@ __device__ __forceinline__ void wgrad_thin_body(const WgradArgs& a, const WJob& 
 #pragma unroll
             for (int e = 0; e < 8; ++e) bs[e] += (float)v[e];
         }
-        if (b_owner) *reinterpret_cast<wh8*>(B0 + b_row * TR_RS + b_col) = m + b_row < m_end ? s.b : zero8;
+        if (b_owner) {
+#pragma unroll
+            for (int j = 0; j < SB; ++j)
+                *reinterpret_cast<wh8*>(B0 + b_row[j] * TR_RS + b_col[j]) = m + b_row[j] < m_end ? s.b[j] : zero8;
+        }
     };
-    f32x16 acc[NO][1];
+    f32x16 acc[NO][NI];
     zero_acc(acc);
     auto compute = [&](const int buf) {
         if (!live) return;
@@ -799,10 +691,13 @@ __device__ __forceinline__ void wgrad_thin_body(const WgradArgs& a, const WJob& 
             wh8 af[NO];
 #pragma unroll
             for (int o = 0; o < NO; ++o) af[o] = tr_frag(A0 + k * TR_PLANE, lane, o_base + 32 * o);
-            const wh8 bf = tr_frag(B0 + k * TR_PLANE, lane, i_base);
 #pragma unroll
-            for (int o = 0; o < NO; ++o)
-                acc[o][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[o], bf, acc[o][0], 0, 0, 0);
+            for (int i = 0; i < NI; ++i) {      // one B fragment live at a time (register budget of the two sets)
+                const wh8 bf = tr_frag(B0 + k * TR_PLANE, lane, i_base + 32 * i);
+#pragma unroll
+                for (int o = 0; o < NO; ++o)
+                    acc[o][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[o], bf, acc[o][i], 0, 0, 0);
+            }
         }
     };
     // stage i is computed from LDS buffer i & 1 while stage i+1 sits in a register set (requested one iteration ago)
@@ -811,19 +706,33 @@ __device__ __forceinline__ void wgrad_thin_body(const WgradArgs& a, const WJob& 
     // branch around a fetch would again leave the number of outstanding loads unknown at the next wait.
     if (m_begin >= m_end) return;     // (uniform; only when there are more row ranges than rows)
     fetch(s0, m_begin);
-    fetch(s1, m_begin + SROWS);
-    stash(s0, 0, m_begin);
-    __syncthreads();
-    for (int m = m_begin; m < m_end; m += 2 * SROWS) {
-        fetch(s0, m + 2 * SROWS);
-        compute(0);
-        if (m + SROWS < m_end) stash(s1, 1, m + SROWS);
+    if constexpr (DEEP) {
+        fetch(s1, m_begin + SROWS);
+        stash(s0, 0, m_begin);
         __syncthreads();
-        if (m + SROWS >= m_end) break;
-        fetch(s1, m + 3 * SROWS);
-        compute(1);
-        if (m + 2 * SROWS < m_end) stash(s0, 0, m + 2 * SROWS);
+        for (int m = m_begin; m < m_end; m += 2 * SROWS) {
+            fetch(s0, m + 2 * SROWS);
+            compute(0);
+            if (m + SROWS < m_end) stash(s1, 1, m + SROWS);
+            __syncthreads();
+            if (m + SROWS >= m_end) break;
+            fetch(s1, m + 3 * SROWS);
+            compute(1);
+            if (m + 2 * SROWS < m_end) stash(s0, 0, m + 2 * SROWS);
+            __syncthreads();
+        }
+    } else {
+        // one stage ahead (the 256-wide jobs: their 64 KB stages already run at the HBM's read ceiling, and the
+        // second register set measured +-0 there at 256 VGPR with spills)
+        stash(s0, 0, m_begin);
         __syncthreads();
+        int buf = 0;
+        for (int m = m_begin; m < m_end; m += SROWS, buf ^= 1) {
+            fetch(s0, m + SROWS);
+            compute(buf);
+            if (m + SROWS < m_end) stash(s0, buf ^ 1, m + SROWS);
+            __syncthreads();
+        }
     }
     float* part = a.part + (size_t)split * PART_PER_SPLIT;
     if (live) {
@@ -832,8 +741,10 @@ __device__ __forceinline__ void wgrad_thin_body(const WgradArgs& a, const WJob& 
 #pragma unroll
         for (int o = 0; o < NO; ++o)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                cpart[(size_t)(o_base + o * 32 + frag_row(r, lane)) * I + i_base + ll] = acc[o][0][r];
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    cpart[(size_t)(o_base + o * 32 + frag_row(r, lane)) * I + i_base + i * 32 + ll] = acc[o][i][r];
     }
     if (job.bias_off >= 0) {
         // bias partial = column sums of the dz slabs: a thread's slots share one chunk column (512 % A_C8 == 0)
@@ -855,8 +766,16 @@ __global__ __launch_bounds__(512) void wgrad_thin_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int j = a.tile_job[blockIdx.x];
     const WJob job = a.jobs[j];
-    if (job.O == W) wgrad_thin_body<W, PE_K>(a, job, smem_raw);      // encoding columns of L0 / L5
-    else wgrad_thin_body<HV, DPE_K>(a, job, smem_raw);               // direction columns of the view layer
+    if (job.O == W) wgrad_half_body<W, PE_K, 1, true>(a, job, smem_raw);      // encoding columns of L0 / L5
+    else wgrad_half_body<HV, DPE_K, 1, true>(a, job, smem_raw);               // direction columns of the view layer
+}
+
+// the 256-wide jobs on the same body (256 x 256 layers, 128 x 256 feature columns of the view layer)
+__global__ __launch_bounds__(512) void wgrad_main_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const WJob job = a.jobs[a.tile_job[blockIdx.x]];
+    if (job.O == W) wgrad_half_body<W, W, 4, false>(a, job, smem_raw);
+    else wgrad_half_body<HV, W, 4, false>(a, job, smem_raw);
 }
 
 // sigma / rgb heads: dW_alpha = sum_m g_sigma h7, dW_rgb[c] = sum_m g_c hv, and their biases
@@ -1143,14 +1062,6 @@ int absmax(const float* x, size_t n, unsigned* out, hipStream_t st) {
     return PLNERF_OK;
 }
 
-template <int NI>
-inline void launch_tr16(dim3 grid, hipStream_t st, const WgradArgs& a) {
-    const size_t lds = (size_t)2 * 2 * TR_STEPS * TR_PLANE * sizeof(_Float16);   // 2 buffers x {A, B}
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)wgrad_tr16_kernel<NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((wgrad_tr16_kernel<NI>), grid, dim3(512), lds, st, a);
-}
-
 int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, const unsigned* gmax, float* part,
           float* const* grads, int xyz_ch, int dir_ch, bool h16, hipStream_t st) {
     const size_t N = (size_t)n_rows;
@@ -1199,7 +1110,11 @@ int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, co
         a.tile_job[nt] = 8; a.tile_o0[nt++] = 0;
         a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
         if (!h16) hipLaunchKernelGGL((wgrad_f32_kernel<2, 2, 2, 4, 4>), dim3(nt, splits), dim3(256), 0, st, a);
-        else launch_tr16<4>(dim3(nt, splits), st, a);
+        else {
+            const size_t lds = (size_t)2 * 2 * TR_STEPS * TR_PLANE * sizeof(_Float16);
+            (void)hipFuncSetAttribute((const void*)wgrad_main_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(wgrad_main_kernel, dim3(nt, splits), dim3(512), lds, st, a);
+        }
         PLNERF_CHECK_LAUNCH();
     }
     {
