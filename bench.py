@@ -189,8 +189,8 @@ def main():
             "roofline": {
                 "bound": "hbm" if hbm_bound else "mfma",
                 "kernel": {"fp32": "mlp_fwd_f32_kernel<2,true>", "f16x3": "mlp_fwd_pp_kernel<2,true>",
-                           "f16": "mlp_fwd_pp_kernel<1,true>", "bf16x3": "mlp_fwd_train_kernel<2>",
-                           "bf16": "mlp_fwd_train_kernel<1>"}[a.precision]
+                           "f16": "mlp_fwd_pp_kernel<1,true>", "bf16x3": "mlp_fwd_pp_kernel<2,true>",
+                           "bf16": "mlp_fwd_pp_kernel<1,true>"}[a.precision]
                           + " (fine network, fused PE+12-layer MLP forward, saves backward state)",
                 "achieved": ach_gbs if hbm_bound else ach, "peak": HBM_PEAK_GBS if hbm_bound else peak,
                 "unit": "GB/s" if hbm_bound else "TFLOP/s",

@@ -9,8 +9,8 @@
 //
 // The kernel source lives in mlp_h16_body.inc (+ mlp_h16_fwd_pp.inc) and is compiled once per element type:
 //   forward, inference            mlp_fwd_pp_kernel<NS, false>      both element types
-//   forward, training             mlp_fwd_pp_kernel<NS, true>       half elements (the tile's hi plane IS the saved plane)
-//                                 mlp_fwd_train_kernel<NS>          bf16 elements (8 compute + 4 converting copy waves)
+//   forward, training             mlp_fwd_pp_kernel<NS, true>       both element types (half: the tile's hi plane IS the
+//                                                                   saved plane; bf16: hi (+ lo) converted in the copy)
 //   backward, dgrad chain         mlp_bwd_h16_kernel                half elements only, shared by every mode
 // Formulation: OUT^T[feature][sample] = W[feature][k] . X^T[k][sample].  The MFMA "A" operand is the weight tile
 // (pre-packed in fragment order, owned by the one wave that computes that 32-feature slab -- no LDS staging, no
