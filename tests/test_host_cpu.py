@@ -104,6 +104,32 @@ def test_rays_match_golden(built, golden):
     assert torch.allclose(d2, torch.from_numpy(g["ndc_d"]), atol=1e-6, rtol=1e-6)
 
 
+def test_contiguous_runs_of_gradient_slices(built):
+    """optim.contiguous_runs / flat_view_of (host logic of FlatAdam and of the DP bucket): consecutive slices of one
+    buffer merge into one flat view; separate allocations, gaps, non-contiguous and non-fp32 tensors do not."""
+    from plnerf_amd.optim import contiguous_runs, flat_view_of
+    flat = torch.arange(100, dtype=torch.float32)
+    a, b, c = flat[0:12].view(3, 4), flat[12:20], flat[20:50].view(5, 6)
+    runs = contiguous_runs([a, b, c])
+    assert len(runs) == 1 and runs[0][:2] == (0, 3) and torch.equal(runs[0][2], flat[:50])
+    runs[0][2].mul_(2.0)                                   # it is a view, not a copy
+    assert float(b[0]) == 24.0
+    assert flat_view_of([a, b, c]).data_ptr() == flat.data_ptr()
+    # a gap (slice 50:60 skipped) and an unrelated allocation split the list
+    d, e = flat[60:70], torch.zeros(7)
+    runs = contiguous_runs([a, b, c, d, e])
+    assert [(r[0], r[1]) for r in runs] == [(0, 3), (3, 4), (4, 5)] and flat_view_of([a, b, c, d]) is None
+    # order matters; non-contiguous / non-fp32 members stand alone without a flat view
+    assert flat_view_of([b, a]) is None
+    t = flat[70:90].view(4, 5).t()
+    runs = contiguous_runs([t, torch.zeros(3, dtype=torch.float64)])
+    assert [r[2] is None for r in runs] == [True, True]
+    assert flat_view_of([]) is None and flat_view_of([a, None]) is None
+    # two neighbouring allocations that merely touch must not merge: emulate with views of distinct storages
+    x, y = torch.zeros(8), torch.zeros(8)
+    assert len(contiguous_runs([x, y])) == 2
+
+
 def test_shard_rays():
     from plnerf_amd import dp
     spans = [dp.shard_rays(32768, r, 8) for r in range(8)]
