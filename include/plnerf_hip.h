@@ -45,6 +45,9 @@ extern "C" {
 #define PLNERF_PREC_BF16 2   /* plain bf16 operands, fp32 accumulate                              */
 #define PLNERF_PREC_F16X3 3  /* 3-term IEEE-half split on v_mfma_f32_32x32x16_f16 (22 bits)        */
 #define PLNERF_PREC_F16 4    /* plain half operands, fp32 accumulate                              */
+/* Range of the half-element modes (3, 4): conversions saturate; activations and weights are represented up to
+ * |x| = 131,008 in mode 3 (hi + lo) and 65,504 in mode 4, and clamp silently beyond.  Modes 0-2 carry fp32's
+ * exponent range. */
 /* Backward of modes 1-4: the saved activations and the pre-activation gradients are IEEE-half
  * planes, the latter under one power-of-two scale per launch (max |g_raw| -> [8,16), saturating
  * conversion); dgrad chain and weight gradients are single half MFMAs with fp32 accumulation.
