@@ -353,6 +353,18 @@ def test_merge_sort(P):
         rb = g(torch.cat([torch.zeros(R, 6), near, far, torch.zeros(R, 3)], -1))
         out = Fn.merge_sort(g(z), g(zn), rb[:, 6:7], rb[:, 7:8])
         assert torch.equal(out.cpu(), ref), f"merge_sort (strided bounds) R={R} S={S} N={N}"
+    # a general sort, not a merge: unsorted first list, negative values, a NaN (last, as torch.sort puts it), and row
+    # lengths that land in every padded size of the register sort (64 / 128 / 256 / 512 / 1024 keys)
+    for R, S, N in ((5, 30, 35), (9, 3, 60), (4, 200, 100), (6, 100, 28), (3, 700, 100)):
+        gen = torch.Generator().manual_seed(S + N)
+        z = 8 * torch.rand(R, S, generator=gen) - 4
+        zn = 8 * torch.rand(R, N, generator=gen) - 4
+        z[0, 0] = float("nan")
+        near, far = torch.full((R, 1), -3.0), torch.full((R, 1), 3.0)
+        ref, _ = torch.sort(torch.cat([z, torch.clamp(zn, near, far)], -1), -1)
+        out = Fn.merge_sort(g(z), g(zn), g(near), g(far)).cpu()
+        assert torch.equal(torch.isnan(out), torch.isnan(ref)) and torch.equal(torch.nan_to_num(out, nan=9.0),
+                                                                           torch.nan_to_num(ref, nan=9.0)), (R, S, N)
 
 
 # ----------------------------------------------------------------------------- MLP
