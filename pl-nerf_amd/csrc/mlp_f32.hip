@@ -40,8 +40,15 @@
 using namespace plnerf;
 using namespace plnerf::lay;
 
+// row ranges of the 256-wide weight-gradient jobs.  Half planes: 9 tiles x 28 = 252 workgroups, ONE round on the
+// 256 CUs (each keeps its 256 x 256 partial in registers for twice as many rows as with 56, and the partial sums
+// written and re-read by the reduction halve: 134 -> 67 MB per network; step -1.5 %).  The fp32 kernel (17 tiles of
+// 256 threads, several workgroups per CU) wants the 56 it was tuned with (28: +8 % step).
 #ifndef PLNERF_WG_SPLITS
-#define PLNERF_WG_SPLITS 56
+#define PLNERF_WG_SPLITS 28
+#endif
+#ifndef PLNERF_WG_SPLITS_F32
+#define PLNERF_WG_SPLITS_F32 56
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -982,10 +989,11 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float4* __restrict__ 
     }
 }
 
-inline int splits_for(int n_rows) {
+inline int splits_for(int n_rows, bool h16) {
+    const int cap = h16 ? WG_SPLITS : PLNERF_WG_SPLITS_F32;
     int s = (n_rows + 1023) / 1024;
     if (s < 1) s = 1;
-    if (s > WG_SPLITS) s = WG_SPLITS;
+    if (s > cap) s = cap;
     return s;
 }
 inline int head_wgs_for(int n_rows) {
@@ -1067,7 +1075,7 @@ int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, co
     const size_t N = (size_t)n_rows;
     const size_t es = h16 ? sizeof(_Float16) : sizeof(float);        // plane element size
     float* head_part = part + (size_t)MAX_SPLITS * PART_PER_SPLIT;
-    const int splits = splits_for(n_rows);
+    const int splits = splits_for(n_rows, h16);
     int rps = (n_rows + splits - 1) / splits;
     rps = (rps + 15) & ~15;
     int splits_thin = splits;
