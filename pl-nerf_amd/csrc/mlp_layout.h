@@ -113,7 +113,10 @@ constexpr int PART_BIAS = PART_VDIR + HV * DPE_K;              // b0..b7, bf: 9 
 constexpr int PART_PER_SPLIT = PART_BIAS + 9 * W + HV;
 constexpr int MAX_SPLITS = 128;
 constexpr int HEAD_PART = 648;               // per-workgroup partial of the sigma/rgb heads
-constexpr int MAX_HEAD_WGS = 512;
+#ifndef PLNERF_MAX_HEAD_WGS
+#define PLNERF_MAX_HEAD_WGS 512
+#endif
+constexpr int MAX_HEAD_WGS = PLNERF_MAX_HEAD_WGS;
 
 }  // namespace lay
 }  // namespace plnerf
