@@ -58,9 +58,10 @@ namespace impl {
 size_t bf16_packed_bytes(int ns) { return plnerf_h16_bf16::h16_packed_bytes(ns); }
 
 int bf16_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, int f16, void* packed, hipStream_t st) {
-    // forward section in the mode's element type (ns planes), dgrad section always one half plane
-    const int rc = f16 ? plnerf_h16_f16::h16_pack(params, xyz_ch, dir_ch, ns, 1, ns, packed, st)
-                       : plnerf_h16_bf16::h16_pack(params, xyz_ch, dir_ch, ns, 1, ns, packed, st);
+    // forward section in the mode's element type (ns planes), dgrad section always one half plane: one launch
+    // when the forward section is half too, two otherwise
+    if (f16) return plnerf_h16_f16::h16_pack(params, xyz_ch, dir_ch, ns, 3, ns, packed, st);
+    const int rc = plnerf_h16_bf16::h16_pack(params, xyz_ch, dir_ch, ns, 1, ns, packed, st);
     return rc ? rc : plnerf_h16_f16::h16_pack(params, xyz_ch, dir_ch, 1, 2, ns, packed, st);
 }
 
