@@ -426,10 +426,12 @@ def pack_ray_batch(rays_o, rays_d, near, far):
 # ----------------------------------------------------------------------------
 # a13: one optimisation step (run_plnerf.py:1283-1316)
 # ----------------------------------------------------------------------------
-def train_step(sd_coarse, sd_fine, ray_batch, target, render_kwargs, lr=5e-4, adam_state=None):
+def train_step(sd_coarse, sd_fine, ray_batch, target, render_kwargs, lr=5e-4, adam_state=None, return_psnr=False):
     """loss = mse(rgb_map, target) + mse(rgb0, target); Adam(0.9, 0.999) on both
     nets.  Parameters are updated IN PLACE; returns (loss, grads_coarse,
-    grads_fine).  `adam_state` persists optimiser state across calls."""
+    grads_fine[, psnr]) -- psnr = mse2psnr(img2mse(rgb_map, target)) as the reference
+    prints it (run_plnerf.py:1288-1290) when return_psnr.  `adam_state` persists
+    optimiser state across calls."""
     params_c = [p.requires_grad_(True) for p in sd_coarse.values()]
     params_f = [p.requires_grad_(True) for p in sd_fine.values()]
     if adam_state is None or "opt_f" not in adam_state:
@@ -445,7 +447,8 @@ def train_step(sd_coarse, sd_fine, ray_batch, target, render_kwargs, lr=5e-4, ad
     ret = render_rays(ray_batch, sd_coarse, sd_fine, retraw=True, **render_kwargs)
     opt_f.zero_grad()
     opt_c.zero_grad()
-    loss = torch.mean((ret["rgb_map"] - target) ** 2)
+    img_loss = torch.mean((ret["rgb_map"] - target) ** 2)
+    loss = img_loss
     if "rgb0" in ret:
         loss = loss + torch.mean((ret["rgb0"] - target) ** 2)
     loss.backward()
@@ -453,6 +456,8 @@ def train_step(sd_coarse, sd_fine, ray_batch, target, render_kwargs, lr=5e-4, ad
     g_f = {k: (v.grad.clone() if v.grad is not None else torch.zeros_like(v)) for k, v in sd_fine.items()}
     opt_f.step()
     opt_c.step()
+    if return_psnr:
+        return loss.detach(), g_c, g_f, -10.0 * torch.log10(img_loss.detach())
     return loss.detach(), g_c, g_f
 
 

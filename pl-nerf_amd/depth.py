@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from . import functional as Fn
+from . import raybatch as RB
 from .nerf import Embedder, NeRF
 from .optim import FlatAdam
 from .render import batchify, raw2outputs as _raw2outputs, sample_pdf, sample_pdf_reformulation
@@ -34,18 +35,16 @@ def get_embedder(multires, i=0):
 
 
 def run_network(inputs, viewdirs, embedded_cam, fn, embed_fn, embeddirs_fn, bb_center, bb_scale, netchunk=1024 * 64):
-    """run_nerf_sample_based_depth.py:52-68."""
-    inputs_flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
-    inputs_flat = (inputs_flat - bb_center) * bb_scale
-    embedded = embed_fn(inputs_flat)
+    """run_nerf_sample_based_depth.py:52-68: bounding-box affine, encodings (positions | per-ray direction | per-image
+    camera code, each repeated over the ray's samples), then the MLP in row chunks.  inputs [R, S, 3]."""
+    R, S = inputs.shape[0], inputs.shape[1]
+    columns = [embed_fn(((inputs.reshape(-1, inputs.shape[-1]) - bb_center) * bb_scale))]
     if viewdirs is not None:
-        input_dirs = viewdirs[:, None].expand(inputs.shape)
-        input_dirs_flat = torch.reshape(input_dirs, [-1, input_dirs.shape[-1]])
-        embedded_dirs = embeddirs_fn(input_dirs_flat)
-        embedded = torch.cat([embedded, embedded_dirs,
-                              embedded_cam.unsqueeze(0).expand(embedded_dirs.shape[0], embedded_cam.shape[0])], -1)
-    outputs_flat = batchify(fn, netchunk)(embedded)
-    return torch.reshape(outputs_flat, list(inputs.shape[:-1]) + [outputs_flat.shape[-1]])
+        per_ray = embeddirs_fn(viewdirs)                              # row-wise encoder: encode once per ray ...
+        columns.append(per_ray[:, None, :].expand(R, S, per_ray.shape[-1]).reshape(R * S, -1))   # ... then repeat
+        columns.append(embedded_cam.reshape(1, -1).expand(R * S, embedded_cam.shape[0]))
+    raw = batchify(fn, netchunk)(torch.cat(columns, -1))
+    return raw.reshape(*inputs.shape[:-1], raw.shape[-1])
 
 
 def raw2outputs(raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std=0, pytest=False, white_bkgd=False,
@@ -202,42 +201,34 @@ def get_rays(H, W, intrinsic, c2w, coords=None):
 
 def batchify_rays(rays_flat, chunk=1024 * 32, use_viewdirs=False, **kwargs):
     """run_nerf_sample_based_depth.py:71-83."""
-    parts = [render_rays(rays_flat[i:i + chunk], use_viewdirs, **kwargs) for i in range(0, rays_flat.shape[0], chunk)]
-    return {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]}
+    return RB.map_row_chunks(lambda rows: render_rays(rows, use_viewdirs, **kwargs), rays_flat, chunk)
 
 
 def render(H, W, intrinsic, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., with_5_9=False,
            use_viewdirs=False, c2w_staticcam=None, rays_depth=None, **kwargs):
     """run_nerf_sample_based_depth.py:85-160 (render_hyp, :162-248, is the same function).  Returns
-    [rgb_map, disp_map, acc_map, extras]; `ndc` is accepted and unused, as there."""
+    [rgb_map, disp_map, acc_map, extras]; `ndc` is accepted and unused, as there.  `rays` = (origins, directions) or
+    (origins, directions, depth columns); a full view comes from `c2w`, optionally centre-cropped to 5.33:9."""
     if c2w is not None:
         rays_o, rays_d = get_rays(H, W, intrinsic, c2w)
-        if with_5_9:                       # centre crop to 5.33:9
-            W_full, W = W, int(H / 9. * 16. / 3.)
-            W -= W % 2
-            start = (W_full - W) // 2
-            rays_o, rays_d = rays_o[:, start:start + W, :], rays_d[:, start:start + W, :]
+        if with_5_9:
+            crop = int(H / 9. * 16. / 3.)
+            crop -= crop % 2
+            first = (W - crop) // 2
+            rays_o, rays_d, W = rays_o[:, first:first + crop, :], rays_d[:, first:first + crop, :], crop
     elif rays.shape[0] == 2:
         rays_o, rays_d = rays
     else:
         rays_o, rays_d, rays_depth = rays
-    cols = []
+    extra = []
     if use_viewdirs:
-        viewdirs = rays_d
+        extra.append(RB.unit_directions(rays_d))
         if c2w_staticcam is not None:
             rays_o, rays_d = get_rays(H, W, intrinsic, c2w_staticcam)
-        viewdirs = torch.reshape(viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True), [-1, 3]).float()
-        cols.append(viewdirs)
-    sh = rays_d.shape
-    rays_o, rays_d = torch.reshape(rays_o, [-1, 3]).float(), torch.reshape(rays_d, [-1, 3]).float()
-    ones = torch.ones_like(rays_d[..., :1])
     if rays_depth is not None:
-        cols.append(torch.reshape(rays_depth, [-1, 3]).float())
-    packed = torch.cat([rays_o, rays_d, near * ones, far * ones] + cols, -1)
-    all_ret = batchify_rays(packed, chunk, use_viewdirs, **kwargs)
-    all_ret = {k: torch.reshape(v, list(sh[:-1]) + list(v.shape[1:])) for k, v in all_ret.items()}
-    head = ['rgb_map', 'disp_map', 'acc_map']
-    return [all_ret[k] for k in head] + [{k: v for k, v in all_ret.items() if k not in head}]
+        extra.append(rays_depth.reshape(-1, 3).float())
+    rows, lead = RB.pack_rays(rays_o, rays_d, near, far, extra)
+    return RB.unflatten_outputs(batchify_rays(rows, chunk, use_viewdirs, **kwargs), lead)
 
 
 render_hyp = render
@@ -284,59 +275,38 @@ def create_nerf(args, scene_render_params=None, device=None):
     """run_nerf_sample_based_depth.py:547-644: (render_kwargs_train, render_kwargs_test, start, grad_vars,
     optimizer).  One Adam over the parameters of both networks; no nn.DataParallel (ray shards go through
     dp.py instead, one process per GPU)."""
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() \
-            else torch.device("cpu")
-    precision = getattr(args, "precision", "fp32")
+    device = RB.default_device(device)
     embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
-    input_ch_views, embeddirs_fn = 0, None
-    if args.use_viewdirs:
-        embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
-    output_ch = 5 if args.N_importance > 0 else 4
-    input_ch_cam = getattr(args, "input_ch_cam", 0)
+    embeddirs_fn, input_ch_views = (get_embedder(args.multires_views, args.i_embed) if args.use_viewdirs
+                                    else (None, 0))
 
-    def make(D, W):
-        return NeRF(D=D, W=W, input_ch=input_ch, output_ch=output_ch, skips=[4], input_ch_views=input_ch_views,
-                    input_ch_cam=input_ch_cam, use_viewdirs=args.use_viewdirs, precision=precision,
+    def network(depth, width):
+        return NeRF(D=depth, W=width, input_ch=input_ch, output_ch=5 if args.N_importance > 0 else 4, skips=[4],
+                    input_ch_views=input_ch_views, input_ch_cam=getattr(args, "input_ch_cam", 0),
+                    use_viewdirs=args.use_viewdirs, precision=getattr(args, "precision", "fp32"),
                     density_activation="softplus", dense_layer_init=True).to(device)
-    model = make(args.netdepth, args.netwidth)
-    grad_vars = list(model.parameters())
-    model_fine = None
-    if args.N_importance > 0:
-        model_fine = make(args.netdepth_fine, args.netwidth_fine)
-        grad_vars += list(model_fine.parameters())
-    bb_center, bb_scale = getattr(args, "bb_center", 0.0), getattr(args, "bb_scale", 1.0)
+    model = network(args.netdepth, args.netwidth)
+    model_fine = network(args.netdepth_fine, args.netwidth_fine) if args.N_importance > 0 else None
+    grad_vars = list(model.parameters()) + (list(model_fine.parameters()) if model_fine is not None else [])
+    box = (getattr(args, "bb_center", 0.0), getattr(args, "bb_scale", 1.0))
 
     def network_query_fn(inputs, viewdirs, embedded_cam, network_fn):
         return run_network(inputs, viewdirs, embedded_cam, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
-                           bb_center=bb_center, bb_scale=bb_scale, netchunk=getattr(args, "netchunk", 1024 * 64))
-    # one Adam over both networks (optim.FlatAdam on the GPU: one launch per network's gradient buffer)
-    Adam = FlatAdam if torch.device(device).type == "cuda" else torch.optim.Adam
-    optimizer = Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+                           bb_center=box[0], bb_scale=box[1], netchunk=getattr(args, "netchunk", 1024 * 64))
+    # (optim.FlatAdam on the GPU: one launch per network's gradient buffer)
+    optimizer = (FlatAdam if device.type == "cuda" else torch.optim.Adam)(params=grad_vars, lr=args.lrate,
+                                                                           betas=(0.9, 0.999))
     start = 0
-    ckdir = os.path.join(getattr(args, "ckpt_dir", ""), getattr(args, "expname", ""))
-    if not getattr(args, "no_reload", True) and os.path.isdir(ckdir):
-        ckpts = [os.path.join(ckdir, f) for f in sorted(os.listdir(ckdir)) if f.endswith('.tar')]
-        if ckpts:
-            ckpt = torch.load(ckpts[-1], map_location=device)
-            start = ckpt['global_step']
-            optimizer.load_state_dict(ckpt['optimizer_state_dict'])
-            model.load_state_dict(ckpt['network_fn_state_dict'])
-            if model_fine is not None:
-                model_fine.load_state_dict(ckpt['network_fine_state_dict'])
-    render_kwargs_train = {
-        'network_query_fn': network_query_fn, 'embedded_cam': torch.tensor((), device=device),
-        'perturb': args.perturb, 'N_importance': args.N_importance, 'network_fine': model_fine,
-        'N_samples': args.N_samples, 'network_fn': model, 'use_viewdirs': args.use_viewdirs,
-        'raw_noise_std': args.raw_noise_std, 'white_bkgd': args.white_bkgd, 'mode': args.mode,
-        'color_mode': args.color_mode,
-    }
+    if not getattr(args, "no_reload", True) and os.path.isdir(os.path.join(getattr(args, "ckpt_dir", ""),
+                                                                           getattr(args, "expname", ""))):
+        found = [f for f in RB.checkpoint_candidates(args) if f.endswith('.tar')]
+        if found:
+            start = RB.restore_checkpoint(found[-1], device, model, model_fine, optimizer)
+    render_kwargs_train = RB.base_render_kwargs(args, network_query_fn, model, model_fine,
+                                                embedded_cam=torch.tensor((), device=device))
     render_kwargs_train.update(scene_render_params or {})
     render_kwargs_train['lindisp'] = getattr(args, "lindisp", False)
-    render_kwargs_test = dict(render_kwargs_train)
-    render_kwargs_test['perturb'] = False
-    render_kwargs_test['raw_noise_std'] = 0.
-    return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer
+    return render_kwargs_train, RB.test_time_kwargs(render_kwargs_train, perturb=False), start, grad_vars, optimizer
 
 
 class DepthTrainStep:
@@ -350,7 +320,10 @@ class DepthTrainStep:
         self.global_step = 0
         nets = [n for n in (self.kw["network_fn"], self.kw.get("network_fine")) if n is not None]
         distributed = torch.distributed.is_initialized() if distributed is None else distributed
-        self.bucket = dp.GradientBucket(nets) if distributed and torch.distributed.get_world_size() > 1 else None
+        self.bucket = None
+        if distributed and torch.distributed.get_world_size() > 1:
+            dp.broadcast_parameters(nets)      # replicas start from rank 0's weights (see train.TrainStep)
+            self.bucket = dp.GradientBucket(nets)
 
     def __call__(self, ray_batch, target_s, target_h, space_carving_mask=None, cached_u=None, pytest=False):
         a = self.args

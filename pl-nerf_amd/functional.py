@@ -13,6 +13,11 @@ def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
 
+def _expect(cond, what):
+    if not cond:
+        raise ValueError(f"plnerf_amd: {what}")
+
+
 class KernelTimer:
     """Optional per-launch timing with HIP events recorded on the launch stream (the stream
     the kernels are enqueued on is torch's current stream).  bench.py installs one to measure
@@ -51,8 +56,13 @@ class QuadratureFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, raw, z, near, far, rays_d, noise, mode, color_mode, white_bkgd, farcolorfix):
+        _expect(z.dim() == 2, f"z_vals must be [rays, samples], got {tuple(z.shape)}")
         R, S = z.shape
         dev = raw.device
+        _expect(tuple(raw.shape) == (R, S, 4), f"raw must be [{R}, {S}, 4] (rgb, sigma), got {tuple(raw.shape)}")
+        _expect(near.numel() == R and far.numel() == R, f"near / far must hold one value per ray ({R})")
+        _expect(tuple(rays_d.shape) == (R, 3), f"rays_d must be [{R}, 3], got {tuple(rays_d.shape)}")
+        _expect(noise is None or tuple(noise.shape) == (R, S), f"noise must be [{R}, {S}]")
         raw_c, z_c = _f32c(raw), _f32c(z)
         near_c, far_c = _f32c(near).reshape(-1), _f32c(far).reshape(-1)
         d_c = _f32c(rays_d)
@@ -121,6 +131,14 @@ class MlpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pts, viewdirs, embedded, spr, net, want_grad, *params):
         prec = L.PRECISION[net.precision]
+        # The kernels produce parameter gradients only (the sample positions carry no gradient
+        # on the reference's path).  A gradient requested for an MLP *input* would be dropped silently by returning
+        # None from backward -- refuse instead.
+        if bool(want_grad) and any(ctx.needs_input_grad[0:3]):
+            raise NotImplementedError(
+                "plnerf_amd: the fused MLP has no input gradient (pts / viewdirs / embedded require grad); the HIP "
+                "path differentiates with respect to the network parameters only -- detach the inputs "
+                "(e.g. a trainable camera embedding, input_ch_cam > 0, is not supported)")
         packed = net.packed_weights()
         if embedded is not None:
             emb_c = _f32c(embedded)
@@ -191,9 +209,12 @@ class SampleConstFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, bins, weights, u):
+        _expect(bins.dim() == 2, f"bins must be [rays, knots], got {tuple(bins.shape)}")
         R, B = bins.shape
         N = u.shape[-1]
         dev = bins.device
+        _expect(tuple(weights.shape) == (R, B - 1), f"weights must be [{R}, {B - 1}], got {tuple(weights.shape)}")
+        _expect(tuple(u.shape) in ((N,), (R, N)), f"u must be [{N}] or [{R}, {N}], got {tuple(u.shape)}")
         bins_c, w_c, u_c = _f32c(bins), _f32c(weights), _f32c(u)
         stride = N if u_c.dim() == 2 else 0
         out = torch.empty(R, N, device=dev)
@@ -239,9 +260,14 @@ class SamplePlFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, weights, tau, T, near, far, u, zero_tol, eps):
+        _expect(z.dim() == 2, f"z_vals must be [rays, samples], got {tuple(z.shape)}")
         R, S = z.shape
         N = u.shape[-1]
         dev = z.device
+        _expect(tuple(weights.shape) == (R, S + 1), f"weights must be [{R}, {S + 1}], got {tuple(weights.shape)}")
+        _expect(tuple(tau.shape) == (R, S + 2) and tuple(T.shape) == (R, S + 2), f"tau / T must be [{R}, {S + 2}]")
+        _expect(near.numel() == R and far.numel() == R, f"near / far must hold one value per ray ({R})")
+        _expect(tuple(u.shape) in ((N,), (R, N)), f"u must be [{N}] or [{R}, {N}], got {tuple(u.shape)}")
         z_c, w_c, tau_c, T_c = _f32c(z), _f32c(weights), _f32c(tau), _f32c(T)
         near_c, far_c, u_c = _f32c(near).reshape(-1), _f32c(far).reshape(-1), _f32c(u)
         stride = N if u_c.dim() == 2 else 0

@@ -101,16 +101,21 @@ class FlatAdam(torch.optim.Adam):
         if any(fl is None for fl in self._flat):
             if grad_scale != 1.0:
                 raise RuntimeError("FlatAdam: grad_scale needs flat (GPU fp32) parameter groups")
-            return super().step(closure=None) if closure is None else loss
+            super().step(closure=None)      # (the closure, if any, was evaluated above)
+            return loss
         for group, fl in zip(self.param_groups, self._flat):
             ps = group['params']
             if all(p.grad is None for p in ps):
                 continue
             if group.get('weight_decay', 0) or group.get('amsgrad') or group.get('maximize'):
                 raise RuntimeError("FlatAdam implements the reference's Adam: no weight decay / amsgrad / maximize")
-            if flat_view_of([p.data for p in ps]) is None:
-                raise RuntimeError("FlatAdam: a parameter was re-allocated after the optimizer was built "
-                                   "(build the optimizer after .to(device))")
+            view = flat_view_of([p.data for p in ps])
+            if view is None or view.data_ptr() != fl['param'].data_ptr():
+                # not this optimizer's buffer any more: .to(device) after construction, or a second FlatAdam built over
+                # the same parameters re-homed them into ITS buffer -- stepping fl['param'] would update dead memory
+                raise RuntimeError("FlatAdam: the parameters no longer live in this optimizer's flat buffer (they were "
+                                   "re-allocated, or another FlatAdam was built over them afterwards); build one "
+                                   "optimizer per parameter set, after .to(device)")
             # parameters without a gradient are skipped, as torch.optim.Adam does; the others are stepped run by
             # run: a run = consecutive parameters whose gradients are consecutive slices of one buffer and whose
             # step counts agree (one network's backward = one run)

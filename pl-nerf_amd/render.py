@@ -5,12 +5,11 @@ function), so a caller of the reference's `create_nerf` / `render` / `render_ray
 switch to this module unchanged.  Everything numerical happens in libplnerf_hip.so via
 `functional.py`; torch is used for allocation, the random draws and the autograd tape.
 """
-import os
-
 import numpy as np
 import torch
 
 from . import functional as Fn
+from . import raybatch as RB
 from .nerf import NeRF, Embedder, get_embedder
 from .optim import FlatAdam
 from .rays import get_rays, ndc_rays
@@ -20,13 +19,10 @@ MAX_ROWS_PER_LAUNCH = 1 << 21   # MLP rows per kernel launch when activations ar
 
 
 def batchify(fn, chunk):
-    """run_plnerf.py:68-75."""
+    """run_plnerf.py:68-75: apply `fn` to row blocks of at most `chunk` rows (None = all at once)."""
     if chunk is None:
         return fn
-
-    def ret(inputs):
-        return torch.cat([fn(inputs[i:i + chunk]) for i in range(0, inputs.shape[0], chunk)], 0)
-    return ret
+    return lambda inputs: torch.cat([fn(block) for block in torch.split(inputs, chunk, dim=0)], 0)
 
 
 def _fusable(fn, embed_fn, embeddirs_fn, viewdirs):
@@ -64,16 +60,23 @@ def compute_weights(raw, z_vals, rays_d, noise=0.):
     """run_plnerf.py:504-513 (piecewise-constant opacity)."""
     near = z_vals[..., :1]
     noise_t = _noise_tensor(noise, raw)
-    return Fn.QuadratureFn.apply(raw, z_vals, near, near, rays_d, noise_t, "constant", "midpoint", False, False)[3]
+    return Fn.QuadratureFn.apply(_rgb_sigma(raw), z_vals, near, near, rays_d, noise_t, "constant", "midpoint", False,
+                                 False)[3]
 
 
 def compute_weights_piecewise_linear(raw, z_vals, near, far, rays_d, noise=0., return_tau=False):
     """run_plnerf.py:516-550."""
     noise_t = _noise_tensor(noise, raw)
-    out = Fn.QuadratureFn.apply(raw, z_vals, near, far, rays_d, noise_t, "linear", "midpoint", False, False)
+    out = Fn.QuadratureFn.apply(_rgb_sigma(raw), z_vals, near, far, rays_d, noise_t, "linear", "midpoint", False, False)
     if return_tau:
         return out[3], out[5], out[6]
     return out[3]
+
+
+def _rgb_sigma(raw):
+    """The reference reads channels 0..3 of raw (rgb, sigma) and ignores any further ones (run_plnerf.py:566-570);
+    the kernels take exactly four.  (A slice here stays on the autograd tape.)"""
+    return raw if raw.shape[-1] == 4 else raw[..., :4]
 
 
 def _noise_tensor(noise, raw):
@@ -100,8 +103,8 @@ def raw2outputs(raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std=
         else:
             noise = torch.randn(shape, device=raw.device) * raw_noise_std
     cm = color_mode if mode == "linear" else "midpoint"
-    rgb, disp, acc, w, depth, tau, T = Fn.QuadratureFn.apply(raw, z_vals, near, far, rays_d, noise, mode, cm,
-                                                             white_bkgd, farcolorfix)
+    rgb, disp, acc, w, depth, tau, T = Fn.QuadratureFn.apply(_rgb_sigma(raw), z_vals, near, far, rays_d, noise, mode,
+                                                             cm, white_bkgd, farcolorfix)
     if mode == "constant":
         tau, T = None, None
     return rgb, disp, acc, w, depth, tau, T
@@ -231,49 +234,25 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_
 
 
 def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
-    """run_plnerf.py:95-107."""
-    all_ret = {}
-    for i in range(0, rays_flat.shape[0], chunk):
-        ret = render_rays(rays_flat[i:i + chunk], **kwargs)
-        for k in ret:
-            all_ret.setdefault(k, []).append(ret[k])
-    return {k: torch.cat(all_ret[k], 0) for k in all_ret}
+    """run_plnerf.py:95-107: render_rays over chunks of the flat ray rows."""
+    return RB.map_row_chunks(lambda rows: render_rays(rows, **kwargs), rays_flat, chunk)
 
 
 def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
            c2w_staticcam=None, **kwargs):
-    """run_plnerf.py:110-175.  Returns [rgb_map, disp_map, acc_map, extras]."""
-    if c2w is not None:
-        rays_o, rays_d = get_rays(H, W, K, c2w)
-    else:
-        rays_o, rays_d = rays
-
+    """run_plnerf.py:110-175.  Rays come from `rays` = (origins, directions) or from a full view `c2w`; returns
+    [rgb_map, disp_map, acc_map, extras] shaped like the ray arrays."""
+    rays_o, rays_d = get_rays(H, W, K, c2w) if c2w is not None else rays
+    extra = []
     if use_viewdirs:
-        viewdirs = rays_d
-        if c2w_staticcam is not None:
+        extra.append(RB.unit_directions(rays_d))                # of the ORIGINAL directions (:146-150) ...
+        if c2w_staticcam is not None:                            # ... while the geometry may come from a fixed camera
             rays_o, rays_d = get_rays(H, W, K, c2w_staticcam)
-        viewdirs = viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True)
-        viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
-
-    sh = rays_d.shape
-    if ndc:
+    lead_shape = rays_d.shape[:-1]
+    if ndc:                                                       # forward-facing scenes (:153-155)
         rays_o, rays_d = ndc_rays(H, W, K[0][0], 1., rays_o, rays_d)
-
-    rays_o = torch.reshape(rays_o, [-1, 3]).float()
-    rays_d = torch.reshape(rays_d, [-1, 3]).float()
-    near, far = near * torch.ones_like(rays_d[..., :1]), far * torch.ones_like(rays_d[..., :1])
-    rays = torch.cat([rays_o, rays_d, near, far], -1)
-    if use_viewdirs:
-        rays = torch.cat([rays, viewdirs], -1)
-
-    all_ret = batchify_rays(rays, chunk, **kwargs)
-    for k in all_ret:
-        all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
-
-    k_extract = ['rgb_map', 'disp_map', 'acc_map']
-    ret_list = [all_ret[k] for k in k_extract]
-    ret_dict = {k: all_ret[k] for k in all_ret if k not in k_extract}
-    return ret_list + [ret_dict]
+    rows, _ = RB.pack_rays(rays_o, rays_d, near, far, extra)
+    return RB.unflatten_outputs(batchify_rays(rows, chunk, **kwargs), tuple(lead_shape))
 
 
 def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0):
@@ -296,79 +275,48 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
 
 
 def create_nerf(args, device=None):
-    """run_plnerf.py:417-502: (render_kwargs_train, render_kwargs_test, start, grad_vars,
-    optimizer, optimizer_coarse).  `device` (extension) defaults to cuda:<current>; optional
-    `args.precision` picks the MLP arithmetic ("fp32" default)."""
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() \
-            else torch.device("cpu")
+    """run_plnerf.py:417-502: (render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer,
+    optimizer_coarse).  `device` (extension) defaults to cuda:<current>; optional `args.precision` picks the MLP
+    arithmetic ("fp32" default).
+
+    `optimizer` drives the fine network and is the one a checkpoint restores; `optimizer_coarse` the coarse network
+    (:438, :446-447).  Both are the reference's Adam (lr, betas (0.9, 0.999)): optim.FlatAdam on the GPU -- a
+    torch.optim.Adam with the same state_dict that steps a network in one plnerf_adam_step launch."""
+    device = RB.default_device(device)
     precision = getattr(args, "precision", "fp32")
     embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
-    input_ch_views = 0
-    embeddirs_fn = None
-    if args.use_viewdirs:
-        embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
-    output_ch = 5 if args.N_importance > 0 else 4
-    skips = [4]
-    model = NeRF(D=args.netdepth, W=args.netwidth, input_ch=input_ch, output_ch=output_ch, skips=skips,
-                 input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs, precision=precision).to(device)
-    coarse_grad_vars = list(model.parameters())
-    grad_vars = coarse_grad_vars
+    embeddirs_fn, input_ch_views = (get_embedder(args.multires_views, args.i_embed) if args.use_viewdirs
+                                    else (None, 0))
 
-    model_fine = None
-    if args.N_importance > 0:
-        model_fine = NeRF(D=args.netdepth_fine, W=args.netwidth_fine, input_ch=input_ch, output_ch=output_ch,
-                          skips=skips, input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs,
-                          precision=precision).to(device)
-        grad_vars = list(model_fine.parameters())
+    def network(depth, width):
+        return NeRF(D=depth, W=width, input_ch=input_ch, output_ch=5 if args.N_importance > 0 else 4, skips=[4],
+                    input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs, precision=precision).to(device)
+    model = network(args.netdepth, args.netwidth)
+    model_fine = network(args.netdepth_fine, args.netwidth_fine) if args.N_importance > 0 else None
+    coarse_vars = list(model.parameters())
+    grad_vars = coarse_vars if model_fine is None else list(model_fine.parameters())
 
     def network_query_fn(inputs, viewdirs, network_fn):
         return run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
                            netchunk=args.netchunk)
 
-    # `optimizer` drives the fine network, `optimizer_coarse` the coarse one (:438, :446-447)
-    # same Adam as the reference (a torch.optim.Adam with the same state_dict); on the GPU one plnerf_adam_step
-    # launch per network over flat parameter / moment buffers (optim.FlatAdam)
-    Adam = FlatAdam if torch.device(device).type == "cuda" else torch.optim.Adam
-    optimizer = Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
-    optimizer_coarse = Adam(params=coarse_grad_vars, lr=args.coarse_lrate, betas=(0.9, 0.999))
+    on_gpu = device.type == "cuda"
+    optimizer = (FlatAdam if on_gpu else torch.optim.Adam)(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    # Single-pass configuration (N_importance == 0): the reference builds BOTH Adams over the same (coarse)
+    # parameters and steps them one after the other.  A second FlatAdam would re-home the weights into its own flat
+    # buffer and orphan the first one's; torch's Adam steps the same views in place, which is the reference's
+    # behaviour.
+    coarse_adam = FlatAdam if (on_gpu and model_fine is not None) else torch.optim.Adam
+    optimizer_coarse = coarse_adam(params=coarse_vars, lr=args.coarse_lrate, betas=(0.9, 0.999))
 
     start = 0
-    if args.ft_path is not None and args.ft_path != 'None':
-        ckpts = [args.ft_path]
-    else:
-        ckdir = os.path.join(args.ckpt_dir, args.expname)
-        ckpts = [os.path.join(ckdir, f) for f in sorted(os.listdir(ckdir)) if 'tar' in f]
-    print('Found ckpts', ckpts)
-    if len(ckpts) > 0 and not args.no_reload:
-        ckpt_path = ckpts[-1]
-        print('Reloading from', ckpt_path)
-        ckpt = torch.load(ckpt_path, map_location=device)
-        start = ckpt['global_step']
-        optimizer.load_state_dict(ckpt['optimizer_state_dict'])
-        model.load_state_dict(ckpt['network_fn_state_dict'])
-        if model_fine is not None:
-            model_fine.load_state_dict(ckpt['network_fine_state_dict'])
+    candidates = RB.checkpoint_candidates(args)
+    if candidates and not args.no_reload:
+        start = RB.restore_checkpoint(candidates[-1], device, model, model_fine, optimizer)
 
-    render_kwargs_train = {
-        'network_query_fn': network_query_fn,
-        'perturb': args.perturb,
-        'N_importance': args.N_importance,
-        'network_fine': model_fine,
-        'N_samples': args.N_samples,
-        'network_fn': model,
-        'use_viewdirs': args.use_viewdirs,
-        'white_bkgd': args.white_bkgd,
-        'raw_noise_std': args.raw_noise_std,
-        'mode': args.mode,
-        'color_mode': args.color_mode,
-    }
-    if args.dataset != 'llff' or args.no_ndc:
-        print('Not ndc!')
+    render_kwargs_train = RB.base_render_kwargs(args, network_query_fn, model, model_fine)
+    if args.dataset != 'llff' or args.no_ndc:      # NDC only for forward-facing LLFF data (:490-493)
         render_kwargs_train['ndc'] = False
         render_kwargs_train['lindisp'] = args.lindisp
-
-    render_kwargs_test = {k: render_kwargs_train[k] for k in render_kwargs_train}
-    render_kwargs_test['perturb'] = True
-    render_kwargs_test['raw_noise_std'] = 0.
+    render_kwargs_test = RB.test_time_kwargs(render_kwargs_train, perturb=True)
     return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer, optimizer_coarse

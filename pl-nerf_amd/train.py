@@ -80,8 +80,13 @@ class TrainStep:
         self.global_step = start
         self.nets = [n for n in (self.kw["network_fn"], self.kw.get("network_fine")) if n is not None]
         distributed = torch.distributed.is_initialized() if distributed is None else distributed
-        self.bucket = dp.GradientBucket(self.nets) if distributed and torch.distributed.get_world_size() > 1 \
-            else None
+        self.bucket = None
+        if distributed and torch.distributed.get_world_size() > 1:
+            # replicas must start from the same weights (create_nerf initialises from each process's own RNG, and a
+            # checkpoint may have been loaded on one rank only): averaged gradients applied to different weights
+            # diverge silently
+            dp.broadcast_parameters(self.nets)
+            self.bucket = dp.GradientBucket(self.nets)
 
     def learning_rate(self):
         decay_rate, decay_steps = 0.1, self.args.lrate_decay * 1000

@@ -7,7 +7,8 @@ _ref_import.py):
 
 Fixtures are data only: inputs and the reference's outputs.  Network weights
 come from oracle.plnerf_oracle.closed_form_state_dict (an RNG-free recipe), so
-they are not stored.  Fixture ids follow SURVEY.md section 8c (G1..G8).
+they are not stored.  Fixture ids follow SURVEY.md section 8c (G1..G8); G8b = G8's step at configs[4]'s 128+64 sampling, G9 = the
+reference's checkpoint file and what the reference computes after re-loading it.
 """
 import os
 import sys
@@ -300,38 +301,20 @@ def import_depth_reference():
     return D, DH
 
 
-def g8():
-    """The depth-supervised variant (SURVEY.md section 8f-1): pi-scaled encoder + softplus density network
-    (57 | 3 input channels), render_rays with the attached `pred_hyp`, space-carving loss, and one clipped
-    Adam step over both networks -- all from the reference's own functions."""
-    D, DH = import_depth_reference()
-    out = {}
-    embed_fn, input_ch = DH.get_embedder(9, 0)
-    embeddirs_fn, input_ch_views = DH.get_embedder(0, 0)
-    assert (input_ch, input_ch_views) == (57, 3)
-
+def _depth_nets(DH, input_ch, input_ch_views):
     def net(seed):
         m = DH.NeRF(D=8, W=256, input_ch=input_ch, output_ch=5, skips=[4], input_ch_views=input_ch_views,
                     input_ch_cam=0, use_viewdirs=True)
         m.load_state_dict(orc.closed_form_state_dict_depth(seed, sharpen=True))
         return m
-    coarse, fine = net(0), net(1)
+    return net(0), net(1)
 
-    def query(inputs, viewdirs, embedded_cam, fn):
-        return D.run_network(inputs, viewdirs, embedded_cam, fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
-                             bb_center=0.0, bb_scale=1.0, netchunk=65536)
-    # (a) the network on its own
-    gen = torch.Generator().manual_seed(8)
-    pts = (torch.rand(6, 16, 3, generator=gen) * 2 - 1) * 2.5
-    vd = torch.nn.functional.normalize(torch.randn(6, 3, generator=gen), dim=-1)
-    with torch.no_grad():
-        raw = query(pts, vd, torch.tensor(()), coarse)
-        emb = torch.cat([embed_fn(pts.reshape(-1, 3)), embeddirs_fn(vd[:, None].expand(pts.shape).reshape(-1, 3))], -1)
-    out.update({"mlp_pts": pts, "mlp_viewdirs": vd, "mlp_embedded": emb, "mlp_raw": raw})
-    # (b) render_rays + (c) one training step
-    R, Ns, Ni, n_hyp, sc_w = 24, 32, 48, 3, 0.007
-    batch, target = scene_rays(R, seed=8)
-    rng = np.random.default_rng(8)
+
+def _depth_render_and_step(D, DH, coarse, fine, query, R, Ns, Ni, seed, n_hyp=3, sc_w=0.007):
+    """render_rays of the depth script (with the attached pred_hyp) and one clipped Adam step over both networks."""
+    out = {}
+    batch, target = scene_rays(R, seed=seed)
+    rng = np.random.default_rng(seed)
     target_h = torch.from_numpy(rng.uniform(2.0, 6.0, size=(n_hyp, R, 1)).astype(np.float32))
     params = list(coarse.parameters()) + list(fine.parameters())
     opt = torch.optim.Adam(params=params, lr=5e-4, betas=(0.9, 0.999))
@@ -355,6 +338,110 @@ def g8():
     for m, tag in ((coarse, "coarse"), (fine, "fine")):
         for name, prm in m.named_parameters():
             out[f"param_{tag}_{name}_sample"] = sample_elems(prm)
+    out.update({"ray_batch": batch, "target": target, "target_h": target_h, "N_samples": Ns, "N_importance": Ni,
+                "space_carving_weight": sc_w, "loss": loss.detach(), "space_carving_loss": sc.detach(),
+                "sample_stride": 97})
+    return out
+
+
+def g8b():
+    """G8 at BASELINE.json configs[4]'s sampling: N_samples = 128, N_importance = 64 (depth-supervised, mode=linear)."""
+    D, DH = import_depth_reference()
+    embed_fn, input_ch = DH.get_embedder(9, 0)
+    embeddirs_fn, input_ch_views = DH.get_embedder(0, 0)
+    coarse, fine = _depth_nets(DH, input_ch, input_ch_views)
+
+    def query(inputs, viewdirs, embedded_cam, fn):
+        return D.run_network(inputs, viewdirs, embedded_cam, fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
+                             bb_center=0.0, bb_scale=1.0, netchunk=65536)
+    npz("g8b_depth_variant_128_64", **_depth_render_and_step(D, DH, coarse, fine, query, R=16, Ns=128, Ni=64, seed=88))
+
+
+# ---------------------------------------------------------------- G9: checkpoint wire format
+def g9():
+    """The reference's checkpoint (run_plnerf.py:1324-1332) written after G6 case 0's optimisation step, re-loaded by
+    the reference's own create_nerf (run_plnerf.py:454-471), then: a render on G5-style rays with the re-loaded
+    networks and one more optimisation step from the re-loaded optimizer state.  The .tar is committed next to the
+    fixture: it is what a user of the reference has on disk."""
+    import shutil
+    args = make_args(64, 128, "linear")
+    kw, _, opt, opt_c = ref_nets(args, 0, 1, sharpen=False)
+    batch, target = scene_rays(24, seed=60)
+    rays = (batch[:, 0:3], batch[:, 3:6])
+    Kb = [[1111.111, 0, 400], [0, 1111.111, 400], [0, 0, 1]]
+
+    def step(kw, opt, opt_c):
+        rgb, disp, acc, extras = R_.render(800, 800, Kb, chunk=32768, rays=rays, near=2.0, far=6.0, retraw=True,
+                                           pytest=True, **kw)
+        opt.zero_grad()
+        opt_c.zero_grad()
+        loss = H_.img2mse(rgb, target) + H_.img2mse(extras["rgb0"], target)
+        loss.backward()
+        grads = {(tag, name): prm.grad.clone() for net, tag in ((kw["network_fn"], "coarse"), (kw["network_fine"], "fine"))
+                 for name, prm in net.named_parameters()}
+        opt.step()
+        opt_c.step()
+        return loss.detach(), grads
+    step(kw, opt, opt_c)
+    global_step = 1
+    path = os.path.join(args.ckpt_dir, args.expname, '{:06d}.tar'.format(global_step))
+    torch.save({      # the dict of run_plnerf.py:1326-1331, from the reference's own objects
+        'global_step': global_step,
+        'network_fn_state_dict': kw['network_fn'].state_dict(),
+        'network_fine_state_dict': kw['network_fine'].state_dict(),
+        'optimizer_state_dict': opt.state_dict(),
+    }, path)
+    shutil.copyfile(path, os.path.join(HERE, "g9_reference_checkpoint.tar"))
+    # the reference re-loads it
+    args2 = Namespace(**dict(vars(args), no_reload=False))
+    kw2, _, start2, _, opt2, opt_c2 = R_.create_nerf(args2)
+    assert start2 == global_step
+    out = {"global_step": start2, "ray_batch": batch, "target": target, "N_samples": 64, "N_importance": 128,
+           "sample_stride": 97}
+    rbatch, _ = scene_rays(12, seed=90)
+    rr = (rbatch[:, 0:3], rbatch[:, 3:6])
+    with torch.no_grad():
+        rgb, disp, acc, extras = R_.render(800, 800, Kb, chunk=32768, rays=rr, near=2.0, far=6.0, retraw=True,
+                                           pytest=True, **kw2)
+    out.update({"render_batch": rbatch, "render_rgb_map": rgb, "render_disp_map": disp, "render_acc_map": acc})
+    for k, v in extras.items():
+        out["render_" + k] = v
+    loss2, grads2 = step(kw2, opt2, opt_c2)
+    out["loss"] = loss2
+    for (tag, name), gr in grads2.items():
+        out[f"grad_{tag}_{name}_norm"] = gr.norm()
+        out[f"grad_{tag}_{name}_sample"] = sample_elems(gr)
+    for net, tag in ((kw2["network_fn"], "coarse"), (kw2["network_fine"], "fine")):
+        for name, prm in net.named_parameters():
+            out[f"param_{tag}_{name}_sample"] = sample_elems(prm)
+    npz("g9_checkpoint", **out)
+    print(f"wrote g9_reference_checkpoint.tar ({os.path.getsize(os.path.join(HERE, 'g9_reference_checkpoint.tar'))/1e6:.1f} MB)")
+
+
+def g8():
+    """The depth-supervised variant (SURVEY.md section 8f-1): pi-scaled encoder + softplus density network
+    (57 | 3 input channels), render_rays with the attached `pred_hyp`, space-carving loss, and one clipped
+    Adam step over both networks -- all from the reference's own functions."""
+    D, DH = import_depth_reference()
+    out = {}
+    embed_fn, input_ch = DH.get_embedder(9, 0)
+    embeddirs_fn, input_ch_views = DH.get_embedder(0, 0)
+    assert (input_ch, input_ch_views) == (57, 3)
+    coarse, fine = _depth_nets(DH, input_ch, input_ch_views)
+
+    def query(inputs, viewdirs, embedded_cam, fn):
+        return D.run_network(inputs, viewdirs, embedded_cam, fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
+                             bb_center=0.0, bb_scale=1.0, netchunk=65536)
+    # (a) the network on its own
+    gen = torch.Generator().manual_seed(8)
+    pts = (torch.rand(6, 16, 3, generator=gen) * 2 - 1) * 2.5
+    vd = torch.nn.functional.normalize(torch.randn(6, 3, generator=gen), dim=-1)
+    with torch.no_grad():
+        raw = query(pts, vd, torch.tensor(()), coarse)
+        emb = torch.cat([embed_fn(pts.reshape(-1, 3)), embeddirs_fn(vd[:, None].expand(pts.shape).reshape(-1, 3))], -1)
+    out.update({"mlp_pts": pts, "mlp_viewdirs": vd, "mlp_embedded": emb, "mlp_raw": raw})
+    # (b) render_rays + (c) one training step
+    out.update(_depth_render_and_step(D, DH, coarse, fine, query, R=24, Ns=32, Ni=48, seed=8))
     # ray helpers of the depth script (pixel centres, flipped rows)
     Hh, Ww = 4, 6
     intr = torch.tensor([7.5, 7.25, Ww / 2 - 0.25, Hh / 2 + 0.5])
@@ -364,13 +451,10 @@ def g8():
     ro_c, rd_c = DH.get_rays(Hh, Ww, intr, c2w_h, coords)
     out.update({"rays_H": Hh, "rays_W": Ww, "rays_intrinsic": intr, "rays_c2w": c2w_h, "rays_o": ro, "rays_d": rd,
                 "rays_coords": coords, "rays_o_coords": ro_c, "rays_d_coords": rd_c})
-    out.update({"ray_batch": batch, "target": target, "target_h": target_h, "N_samples": Ns, "N_importance": Ni,
-                "space_carving_weight": sc_w, "loss": loss.detach(), "space_carving_loss": sc.detach(),
-                "sample_stride": 97})
     npz("g8_depth_variant", **out)
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g8b", "g9"]
     for name in which:
         globals()[name]()

@@ -225,6 +225,34 @@ def test_checkpoint_wire_format_roundtrip(built, tmp_path, capsys):
         assert torch.equal(a, b)
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree exists in the build container only")
+def test_reference_reloads_a_checkpoint_written_here(built, tmp_path, capsys):
+    """Wire format, the other direction (run_plnerf.py:454-471): the reference's own create_nerf resumes from a file
+    written by plnerf_amd.save_checkpoint -- step counter, both networks and the fine optimizer's Adam state."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from _ref_import import import_reference
+    R_, _ = import_reference()
+    (tmp_path / "exp").mkdir()
+    args = _args(str(tmp_path), no_reload=True)
+    cpu = torch.device("cpu")
+    kw, _, _, grad_vars, opt, opt_c = built.create_nerf(args, device=cpu)
+    for i, p in enumerate(grad_vars):      # a non-trivial optimizer state: one step on synthetic gradients
+        p.grad = torch.full_like(p, 1e-3 * (i + 1))
+    opt.step()
+    built.save_checkpoint(built.checkpoint_path(str(tmp_path), "exp", 77), 77, kw["network_fn"], kw["network_fine"], opt)
+    args_ref = _args(str(tmp_path), no_reload=False)
+    kw_r, _, start_r, grad_vars_r, opt_r, _ = R_.create_nerf(args_ref)
+    assert start_r == 77
+    for a, b in zip(kw["network_fn"].parameters(), kw_r["network_fn"].parameters()):
+        assert torch.equal(a.detach(), b.detach().cpu())
+    for a, b in zip(kw["network_fine"].parameters(), kw_r["network_fine"].parameters()):
+        assert torch.equal(a.detach(), b.detach().cpu())
+    for p, q in zip(grad_vars, grad_vars_r):
+        sa, sb = opt.state[p], opt_r.state[q]
+        assert float(sa["step"]) == float(sb["step"]) == 1.0
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"].cpu()) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"].cpu())
+
+
 def test_select_rays_matches_get_rays(built):
     H, W, f = 20, 30, 25.0
     K = [[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]]

@@ -147,6 +147,71 @@ def test_g8_depth_variant(golden):
             close(sd[name].detach().reshape(-1)[::stride], g[f"param_{tag}_{name}_sample"], atol=2e-6, rtol=1e-5)
 
 
+def test_g8b_depth_variant_config5_sampling(golden):
+    """G8's render + step at BASELINE configs[4]'s sampling (N_samples 128, N_importance 64)."""
+    g = golden("g8b_depth_variant_128_64")
+    assert (int(g["N_samples"]), int(g["N_importance"])) == (128, 64)
+    stride = int(g["sample_stride"])
+    sd_c, sd_f = orc.closed_form_state_dict_depth(0, True), orc.closed_form_state_dict_depth(1, True)
+    kw = dict(N_samples=128, N_importance=64, mode="linear", color_mode="midpoint", perturb=1.0, white_bkgd=True,
+              raw_noise_std=0.0, pytest=True)
+    with torch.no_grad():
+        ret = orc.render_rays_depth(T(g["ray_batch"]), sd_c, sd_f, **kw)
+    assert torch.equal(ret["u"], T(g["render_u"]))
+    for k in ("rgb_map", "disp_map", "acc_map", "depth_map", "z_vals", "weights", "pred_hyp", "raw", "rgb0", "disp0",
+              "acc0", "depth0", "z_vals0", "weights0", "z_std"):
+        close(ret[k], g["render_" + k], atol=2e-6, rtol=2e-5)
+    loss, sc, g_c, g_f = orc.depth_train_step(sd_c, sd_f, T(g["ray_batch"]), T(g["target"]), T(g["target_h"]), kw,
+                                              space_carving_weight=float(g["space_carving_weight"]))
+    close(loss, g["loss"], atol=1e-6, rtol=1e-6)
+    close(sc, g["space_carving_loss"], atol=1e-6, rtol=1e-6)
+    for tag, grads, sd in (("coarse", g_c, sd_c), ("fine", g_f, sd_f)):
+        for name, gr in grads.items():
+            ref_norm = float(g[f"grad_{tag}_{name}_norm"])
+            assert abs(float(gr.norm()) - ref_norm) <= 1e-5 * max(ref_norm, 1e-6) + 1e-9, (tag, name)
+            close(gr.reshape(-1)[::stride], g[f"grad_{tag}_{name}_sample"], atol=1e-7, rtol=2e-4)
+
+
+def test_g9_reference_checkpoint(golden):
+    """The reference-written checkpoint (tests/golden/g9_reference_checkpoint.tar, run_plnerf.py:1324-1332): its
+    dict layout, and that the oracle -- started from the file's weights and Adam state -- reproduces what the
+    reference computed after re-loading it: a render and one more optimisation step."""
+    import os
+    g = golden("g9_checkpoint")
+    ck = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g9_reference_checkpoint.tar"),
+                    map_location="cpu")
+    assert set(ck) == {"global_step", "network_fn_state_dict", "network_fine_state_dict", "optimizer_state_dict"}
+    assert ck["global_step"] == int(g["global_step"]) == 1
+    names = [k for k, _ in orc.param_shapes()]
+    assert list(ck["network_fn_state_dict"]) == names and list(ck["network_fine_state_dict"]) == names
+    ost = ck["optimizer_state_dict"]
+    assert len(ost["state"]) == 24 and set(ost["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    assert ost["param_groups"][0]["lr"] == 5e-4 and tuple(ost["param_groups"][0]["betas"]) == (0.9, 0.999)
+    sd_c = {k: v.clone() for k, v in ck["network_fn_state_dict"].items()}
+    sd_f = {k: v.clone() for k, v in ck["network_fine_state_dict"].items()}
+    kw = dict(N_samples=64, N_importance=128, mode="linear", color_mode="midpoint", perturb=1.0, white_bkgd=True,
+              raw_noise_std=0.0, pytest=True)
+    with torch.no_grad():
+        ret = orc.render_rays(T(g["render_batch"]), sd_c, sd_f, retraw=True, **kw)
+    for k in ("rgb_map", "disp_map", "acc_map", "depth_map", "rgb0", "acc0", "depth0", "z_std", "raw"):
+        close(ret[k], g["render_" + k], atol=5e-6, rtol=2e-5)
+    # one more step: the fine optimizer resumes from the file's state, the coarse one restarts (the reference does
+    # not store it)
+    state = {}
+    params_f = [p.requires_grad_(True) for p in sd_f.values()]
+    params_c = [p.requires_grad_(True) for p in sd_c.values()]
+    state["opt_f"] = torch.optim.Adam(params_f, lr=5e-4, betas=(0.9, 0.999))
+    state["opt_c"] = torch.optim.Adam(params_c, lr=5e-4, betas=(0.9, 0.999))
+    state["opt_f"].load_state_dict(ost)
+    loss, g_c, g_f = orc.train_step(sd_c, sd_f, T(g["ray_batch"]), T(g["target"]), kw, adam_state=state)
+    close(loss, g["loss"], atol=1e-6, rtol=1e-6)
+    stride = int(g["sample_stride"])
+    for tag, grads, sd in (("coarse", g_c, sd_c), ("fine", g_f, sd_f)):
+        for name, gr in grads.items():
+            close(gr.reshape(-1)[::stride], g[f"grad_{tag}_{name}_sample"], atol=1e-7, rtol=2e-4)
+            close(sd[name].detach().reshape(-1)[::stride], g[f"param_{tag}_{name}_sample"], atol=2e-6, rtol=1e-5)
+
+
 def test_g7_rays(golden):
     g = golden("g7_rays")
     H, W, f = int(g["H"]), int(g["W"]), float(g["focal"])
