@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PLNERF_VERSION 210 /* major*10000 + minor*100 + patch */
+#define PLNERF_VERSION 220 /* major*10000 + minor*100 + patch */
 
 /* error codes */
 #define PLNERF_OK 0
@@ -164,6 +164,62 @@ int plnerf_ray_points(const float* rays_o, const float* rays_d, const float* z_v
  * z [R,S], z_new [R,N] -> out [R,S+N]; S+N <= 1024. */
 int plnerf_merge_sort(const float* z, const float* z_new, const float* near, const float* far,
                       int R, int S, int N, float* out, plnerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * The coarse pass's epilogue as one launch (run_plnerf.py:714-735, piecewise-linear mode):
+ * raw2outputs -> sample_pdf_reformulation -> clamp -> sort(cat) -> sample positions, plus
+ * z_std = std(clamped samples, unbiased=False) (:752).  Results are bit-identical to the sequence
+ * plnerf_quad_fwd, plnerf_sample_pl, plnerf_merge_sort, plnerf_ray_points on the same inputs;
+ * weights, tau, T and the cdf stay on chip (their output pointers may be NULL).
+ *   u: [R,N] draws (u_row_stride == N), one shared row (0), or NULL = drawn in the kernel from the
+ *      counter-based generator below (stream id 1) for global ray ids ray_id0 .. ray_id0 + R - 1.
+ *   outputs: rgb_map [R,3], disp_map, acc_map, depth_map [R] (the coarse maps rgb0, ...),
+ *            z_fine [R,S+N] sorted, pts [R,S+N,3], z_std [R].   S + N <= 1024. */
+int plnerf_coarse_epilogue(const float* raw, const float* z, const float* near, const float* far,
+                           const float* rays_o, const float* rays_d, const float* noise, const float* u,
+                           int u_row_stride, uint64_t seed, uint32_t step, int ray_id0, int R, int S, int N,
+                           int color_mode, int white_bkgd, int farcolorfix, float zero_tol, float epsilon,
+                           float* rgb_map, float* disp_map, float* acc_map, float* depth_map, float* weights,
+                           float* tau, float* T, float* z_fine, float* pts, float* z_std,
+                           plnerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * The caller side of the path (run_plnerf.py:1259-1296), device-side.
+ *
+ * Random draws: Philox4x32-10 keyed by `seed`, counter = (global ray id, column / 4, stream id,
+ * step) -> 24-bit uniforms in [0, 1) like torch.rand.  A draw depends on the ray's GLOBAL id only,
+ * so a batch rendered by one rank or sharded over eight sees the same numbers.
+ * Stream ids: 0 = t_rand (stratified jitter, :700-705), 1 = u (importance samples). */
+int plnerf_uniform(uint64_t seed, uint32_t stream_id, uint32_t step, int ray_id0, int R, int n,
+                   float* out /* [R,n] */, plnerf_stream_t stream);
+
+/* Training rays of one view (run_plnerf.py:1259-1281 + run_nerf_helpers.py:162-171 + the ray
+ * packing of render, run_plnerf.py:146-164): ray i (global id ray_id0 + i) looks through pixel
+ * perm(ray_id0 + i) of the window [crop_r0, crop_r0 + crop_rows) x [crop_c0, crop_c0 + crop_cols),
+ * where perm is a bijection of the window's pixels keyed by (seed, step) -- distinct pixels, as
+ * np.random.choice(..., replace=False) gives, without building the H x W grid.  c2w_host: 12 floats
+ * in HOST memory (rows of the 3x4 camera-to-world matrix, read during the call).
+ * Outputs (device): rays_o, rays_d [R,3]; viewdirs [R,3] = rays_d / |rays_d| (nullable); near_out,
+ * far_out [R]; target [R,3] = image[row, col, :] (nullable, image [H,W,3]); pixels [R,2] int32
+ * (row, col; nullable). */
+int plnerf_select_rays(int H, int W, float fx, float fy, float cx, float cy, const float* c2w_host,
+                       const float* image, int crop_r0, int crop_c0, int crop_rows, int crop_cols,
+                       uint64_t seed, uint32_t step, int ray_id0, int R, float near, float far,
+                       float* rays_o, float* rays_d, float* viewdirs, float* near_out, float* far_out,
+                       float* target, int* pixels, plnerf_stream_t stream);
+
+/* plnerf_stratified_z + plnerf_ray_points in one launch (run_plnerf.py:683-708), bit-identical to
+ * them.  perturb != 0: jitter from t_rand [R,S], or (t_rand == NULL) drawn in the kernel (stream 0). */
+int plnerf_coarse_samples(const float* rays_o, const float* rays_d, const float* near, const float* far,
+                          const float* t_vals, const float* t_rand, uint64_t seed, uint32_t step,
+                          int ray_id0, int R, int S, int lindisp, int perturb, float* z_vals, float* pts,
+                          plnerf_stream_t stream);
+
+/* img2mse(rgb, target) + img2mse(rgb0, target) (run_plnerf.py:1287-1296; run_nerf_helpers.py:17):
+ * loss3 = {total, fine, coarse}; g_rgb, g_rgb0 [R,3] = d total / d rgb, d total / d rgb0.
+ * rgb0 may be NULL (single-pass configuration).  Deterministic (one workgroup, fp64 partial sums). */
+int plnerf_image_loss(const float* rgb, const float* rgb0, const float* target, int R, float* loss3,
+                      float* g_rgb, float* g_rgb0, plnerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * The MLP: run_network (run_plnerf.py:78-92) = Embedder (run_nerf_helpers.py:24-54) +

@@ -35,6 +35,14 @@ SIGNATURES = {
     "plnerf_stratified_z": (c_i, [c_f] * 4 + [c_i] * 3 + [c_f] + [c_s]),
     "plnerf_ray_points": (c_i, [c_f] * 3 + [c_i] * 2 + [c_f] + [c_s]),
     "plnerf_merge_sort": (c_i, [c_f] * 4 + [c_i] * 3 + [c_f] + [c_s]),
+    "plnerf_coarse_epilogue": (c_i, [c_f] * 8 + [c_i, ctypes.c_uint64, ctypes.c_uint32] + [c_i] * 7 +
+                               [ctypes.c_float] * 2 + [c_f] * 10 + [c_s]),
+    "plnerf_uniform": (c_i, [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_i, c_i, c_i, c_f, c_s]),
+    "plnerf_select_rays": (c_i, [c_i, c_i] + [ctypes.c_float] * 4 + [ctypes.POINTER(ctypes.c_float), c_f] + [c_i] * 4 +
+                           [ctypes.c_uint64, ctypes.c_uint32, c_i, c_i, ctypes.c_float, ctypes.c_float] + [c_f] * 7 +
+                           [c_s]),
+    "plnerf_coarse_samples": (c_i, [c_f] * 6 + [ctypes.c_uint64, ctypes.c_uint32] + [c_i] * 5 + [c_f] * 2 + [c_s]),
+    "plnerf_image_loss": (c_i, [c_f] * 3 + [c_i] + [c_f] * 3 + [c_s]),
     "plnerf_mlp_packed_bytes": (ctypes.c_size_t, [c_i]),
     "plnerf_mlp_pack_weights": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_i, c_i, c_i, c_f, c_s]),
     "plnerf_mlp_saved_bytes": (ctypes.c_size_t, [c_i, c_i]),

@@ -1,0 +1,251 @@
+// The coarse pass's epilogue as ONE per-ray kernel (run_plnerf.py:714-735, piecewise-linear mode):
+//
+//     raw2outputs(raw, z)                       -> rgb0, disp0, acc0, depth0        (:553-624, weights :516-550)
+//     sample_pdf_reformulation(z, w, tau, T, u) -> z_samples                        (run_nerf_helpers.py:364-445)
+//     clamp(z_samples, near, far); z_std                                            (:731, :752)
+//     sort(cat(z, z_samples))                   -> z_fine                            (:733-734)
+//     pts = o + d * z_fine                                                          (:735)
+//
+// One wavefront owns one ray.  weights, tau, T and the cdf never leave the CU: they are LDS rows of the wave (the
+// separate launches write them to HBM for the next launch to read back).  HBM sees raw, z and u in, the coarse maps,
+// z_fine, pts and z_std out: algorithmic bytes per ray 20 S + 4 N (+44) in, 16 (S + N) + 32 out.  Every device
+// function is the one the separate kernels use (ray_dev.h), so the results are bit-identical to
+// plnerf_quad_fwd -> plnerf_sample_pl -> plnerf_merge_sort -> plnerf_ray_points
+// (tests/test_gpu_parity.py::test_fused_coarse_epilogue_equals_separate_launches).
+#include "common.h"
+#include "philox.h"
+#include "ray_dev.h"
+
+using namespace plnerf;
+
+namespace {
+
+constexpr int WAVES = 4;
+
+struct EpiArgs {
+    RayIn in;
+    const float* rays_o;
+    const float* u;          // [R, N] (stride N), one shared row [N] (stride 0), or null = drawn here (rng)
+    int u_row_stride;
+    RngArgs rng;
+    int R, S, N;
+    int color_mode, white_bkgd, farcolorfix;
+    float zero_tol, eps;
+    int lds_stride;
+    float* rgb_map;
+    float* disp_map;
+    float* acc_map;
+    float* depth_map;
+    float* weights;          // optional [R, S+1]
+    float* tau;              // optional [R, S+2]
+    float* T;                // optional [R, S+2]
+    float* z_fine;           // [R, S+N]
+    float* pts;              // [R, S+N, 3]
+    float* z_std;            // [R]
+};
+
+template <int KPL>
+__global__ __launch_bounds__(256) void coarse_epilogue_kernel(const EpiArgs a) {
+    constexpr int MODE = PLNERF_MODE_LINEAR;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int ray = blockIdx.x * WAVES + wave;
+    const bool live = ray < a.R;
+    if (!live) ray = a.R - 1;
+    const int S = a.S, K = S + 2, n = S + 1, N = a.N, NF = S + N;
+    float* zk = smem + (size_t)wave * a.lds_stride;   // K knots [near, z, far]
+    float* tau = zk + K;                               // K
+    float* col = tau + K;                              // 3 S
+    float* Tr = col + 3 * S;                           // K
+    float* cdf = Tr + K;                               // K
+    float* smp = cdf + K;                              // N clamped samples; later the sorted row (NF, aliases col..)
+    float dnorm;
+    load_ray(a.in, ray, lane, zk, tau, col, dnorm);
+    __syncthreads();
+
+    // ---- quadrature (quad_fwd_kernel's loop) with the cdf's running sum riding along ----
+    double carry = 1.0, ccarry = 0.0;
+    double sr = 0, sg = 0, sb = 0, sd = 0, sa = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool valid = i < n;
+        float seg = 0.f, e = 1.f, f = 1.f;
+        if (valid) interval<MODE>(i, S, zk, tau, dnorm, seg, e, f);
+        const double incl = wave_incl_prod((double)f);
+        double excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.0;
+        const float Ti = (float)(carry * excl);
+        const float Tn = (float)(carry * incl);
+        carry = carry * __shfl(incl, 63);
+        float w = 0.0f;
+        if (valid) {
+            w = (1.0f - e) * Ti;
+            sr += (double)(w * elem_colour<MODE>(i, 0, S, col, a.color_mode, a.farcolorfix));
+            sg += (double)(w * elem_colour<MODE>(i, 1, S, col, a.color_mode, a.farcolorfix));
+            sb += (double)(w * elem_colour<MODE>(i, 2, S, col, a.color_mode, a.farcolorfix));
+            sd += (double)(w * elem_depth<MODE>(i, zk));
+            sa += (double)w;
+            Tr[i + 1] = Tn;
+            if (live) {
+                if (a.weights) a.weights[(size_t)ray * n + i] = w;
+                if (a.T) a.T[(size_t)ray * K + i + 1] = Tn;
+            }
+        }
+        // cdf = [0, cumsum(weights)] (fp64 running sum, each entry rounded to fp32), as sample_pl_kernel builds it
+        const double cincl = wave_incl_sum((double)w);
+        if (valid) cdf[i + 1] = (float)(ccarry + cincl);
+        ccarry = ccarry + __shfl(cincl, 63);
+    }
+    if (live) {
+        if (a.T && lane == 0) a.T[(size_t)ray * K] = 1.0f;
+        if (a.tau)
+            for (int s = lane; s < K; s += 64) a.tau[(size_t)ray * K + s] = tau[s];
+    }
+    sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd); sa = wave_sum(sa);
+    if (live && lane == 0) {
+        const float acc = (float)sa, depth = (float)sd;
+        float r = (float)sr, g = (float)sg, b = (float)sb;
+        if (a.white_bkgd) {
+            const float bg = 1.0f - acc;
+            r += bg; g += bg; b += bg;
+        }
+        a.rgb_map[3 * ray + 0] = r;
+        a.rgb_map[3 * ray + 1] = g;
+        a.rgb_map[3 * ray + 2] = b;
+        a.depth_map[ray] = depth;
+        a.acc_map[ray] = acc;
+        a.disp_map[ray] = 1.0f / tmax(1e-10f, depth / acc);
+    }
+    __syncthreads();
+    if (lane == 0) { Tr[0] = 1.0f; cdf[0] = 0.0f; cdf[K - 1] = 1.0f; }
+    __syncthreads();
+
+    // ---- importance samples (sample_pl_kernel's loop), clamped to [near, far] ----
+    const float lo = zk[0], hi = zk[K - 1];
+    const float zt = a.zero_tol, eps = a.eps;
+    double ssum = 0.0;
+    for (int k = lane; k < N; k += 64) {
+        const float u = a.u ? a.u[(size_t)ray * a.u_row_stride + k] : rng_uniform(a.rng, a.rng.ray_id0 + ray, k);
+        const int ind = upper_bound(cdf, K, u);
+        const int below = ind - 1 > 0 ? ind - 1 : 0;
+        const int above = ind < K - 1 ? ind : K - 1;
+        const float s0 = zk[below], s1 = zk[above];
+        const float T0 = Tr[below];
+        const float tau0 = tau[below], tau1 = tau[above];
+        const int di = below < S ? below : S;
+        const float d = tau[di + 1] - tau[di];
+        float out = (d < zt && d > -zt) ? s0 : -1.0f;
+        if (d >= zt) out = invert_segment(s0, s1, T0, tau0, tau1, u, eps, true);
+        if (d <= -zt) out = invert_segment(s0, s1, T0, tau0, tau1, u, eps, false);
+        if (out != out) out = s0;
+        out = tmin(tmax(out, lo), hi);            // torch.clamp(z_samples, near, far)
+        smp[k] = out;
+        ssum += (double)out;
+    }
+    // z_std = std(z_samples, unbiased=False) over the clamped samples
+    ssum = wave_sum(ssum);
+    const double mean = ssum / (double)N;
+    __syncthreads();
+    double sq = 0.0;
+    for (int k = lane; k < N; k += 64) {
+        const double dv = (double)smp[k] - mean;
+        sq += dv * dv;
+    }
+    sq = wave_sum(sq);
+    if (live && lane == 0) a.z_std[ray] = (float)sqrt(sq / (double)N);
+
+    // ---- sort(cat(z, samples)) in registers (merge_sort_kernel's network) ----
+    uint32_t x[KPL];
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) {
+        const int p = 64 * r + lane;
+        uint32_t key = 0xFFFFFFFFu;
+        if (p < S) key = sort_key(zk[p + 1]);
+        else if (p < NF) key = sort_key(smp[p - S]);
+        x[r] = key;
+    }
+    bitonic_sort_regs<KPL>(x, lane);
+    __syncthreads();                  // every read of col / smp is done: the sorted row may overwrite them
+    float* zs = col;                  // NF <= 3 S + K + K + N floats from col on (col, Tr, cdf, smp are contiguous)
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) {
+        const int p = 64 * r + lane;
+        if (p < NF) {
+            const float v = sort_unkey(x[r]);
+            zs[p] = v;
+            if (live) a.z_fine[(size_t)ray * NF + p] = v;
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    // ---- positions of the merged samples ----
+    const float o[3] = {a.rays_o[3 * (size_t)ray], a.rays_o[3 * (size_t)ray + 1], a.rays_o[3 * (size_t)ray + 2]};
+    const float dd[3] = {a.in.rays_d[3 * (size_t)ray], a.in.rays_d[3 * (size_t)ray + 1], a.in.rays_d[3 * (size_t)ray + 2]};
+    float* prow = a.pts + (size_t)ray * 3 * NF;
+    if ((3 * NF) % 4 == 0 && ((uintptr_t)a.pts & 15) == 0) {
+        for (int q = lane; q < 3 * NF / 4; q += 64) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = 4 * q + k, si = e / 3, c = e - 3 * si;
+                const float oc = c == 0 ? o[0] : (c == 1 ? o[1] : o[2]);
+                const float dc = c == 0 ? dd[0] : (c == 1 ? dd[1] : dd[2]);
+                v[k] = oc + dc * zs[si];
+            }
+            reinterpret_cast<float4*>(prow)[q] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    } else {
+        for (int e = lane; e < 3 * NF; e += 64) {
+            const int si = e / 3, c = e - 3 * si;
+            prow[e] = (c == 0 ? o[0] : (c == 1 ? o[1] : o[2])) + (c == 0 ? dd[0] : (c == 1 ? dd[1] : dd[2])) * zs[si];
+        }
+    }
+}
+
+template <int KPL>
+int launch(const EpiArgs& a, size_t lds, hipStream_t st) {
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)coarse_epilogue_kernel<KPL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+    hipLaunchKernelGGL(coarse_epilogue_kernel<KPL>, dim3((a.R + WAVES - 1) / WAVES), dim3(WAVES * 64), lds, st, a);
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}
+
+}  // namespace
+
+extern "C" int plnerf_coarse_epilogue(const float* raw, const float* z, const float* near, const float* far,
+                                      const float* rays_o, const float* rays_d, const float* noise, const float* u,
+                                      int u_row_stride, uint64_t seed, uint32_t step, int ray_id0, int R, int S, int N,
+                                      int color_mode, int white_bkgd, int farcolorfix, float zero_tol, float epsilon,
+                                      float* rgb_map, float* disp_map, float* acc_map, float* depth_map, float* weights,
+                                      float* tau, float* T, float* z_fine, float* pts, float* z_std,
+                                      plnerf_stream_t stream) {
+    if (R < 0 || S < 2 || N < 1) return PLNERF_EINVAL;
+    if (u && u_row_stride != 0 && u_row_stride != N) return PLNERF_EINVAL;
+    if (color_mode != PLNERF_COLOR_MIDPOINT && color_mode != PLNERF_COLOR_LEFT) return PLNERF_EINVAL;
+    if (S > PLNERF_MAX_SAMPLES || S + N > 1024) return PLNERF_ERANGE;
+    if (R == 0) return PLNERF_OK;
+    if (!raw || !z || !near || !far || !rays_o || !rays_d || !rgb_map || !disp_map || !acc_map || !depth_map ||
+        !z_fine || !pts || !z_std)
+        return PLNERF_EINVAL;
+    EpiArgs a{};
+    a.in = RayIn{raw, z, near, far, rays_d, noise, S};
+    a.rays_o = rays_o; a.u = u; a.u_row_stride = u_row_stride;
+    a.rng = RngArgs{(uint32_t)seed, (uint32_t)(seed >> 32), 1u, step, ray_id0, u ? 0 : 1};
+    a.R = R; a.S = S; a.N = N; a.color_mode = color_mode; a.white_bkgd = white_bkgd; a.farcolorfix = farcolorfix;
+    a.zero_tol = zero_tol; a.eps = epsilon;
+    a.rgb_map = rgb_map; a.disp_map = disp_map; a.acc_map = acc_map; a.depth_map = depth_map;
+    a.weights = weights; a.tau = tau; a.T = T; a.z_fine = z_fine; a.pts = pts; a.z_std = z_std;
+    // zk, tau, Tr, cdf: 4 (S+2); col 3 S; samples N   (the sorted row of S + N <= 3 S + 2 (S+2) + N reuses col onwards)
+    a.lds_stride = ((4 * (S + 2) + 3 * S + N) + 3) & ~3;
+    const size_t lds = (size_t)WAVES * a.lds_stride * sizeof(float);
+    if (lds > 160 * 1024) return PLNERF_ERANGE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nf = S + N;
+    if (nf <= 64) return launch<1>(a, lds, st);
+    if (nf <= 128) return launch<2>(a, lds, st);
+    if (nf <= 256) return launch<4>(a, lds, st);
+    if (nf <= 512) return launch<8>(a, lds, st);
+    return launch<16>(a, lds, st);
+}

@@ -7,6 +7,7 @@
 // as a wave scan (fp64 carry, like the reference's CPU cumprod) -- nothing is re-read
 // from HBM.  Algorithmic bytes per ray (linear): 32*S+64.
 #include "common.h"
+#include "ray_dev.h"
 
 using namespace plnerf;
 
@@ -42,73 +43,6 @@ struct QuadArgs {
     float* g_raw;
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-// Loads one ray into LDS: knots zk[0..S+1] = [near, z, far], tau[0..S+1] =
-// relu([1e-10, sigma+noise, 1e10]), col[3*s+c] = sigmoid(raw rgb).
-__device__ __forceinline__ void load_ray(const QuadArgs& a, int ray, int lane, float* zk, float* tau,
-                                         float* col, float& dnorm) {
-    const int S = a.S;
-    const float4* raw4 = reinterpret_cast<const float4*>(a.raw) + (size_t)ray * S;
-    const float* zrow = a.z + (size_t)ray * S;
-    const float* nrow = a.noise ? a.noise + (size_t)ray * S : nullptr;
-    for (int s = lane; s < S; s += 64) {
-        const float4 r = raw4[s];
-        float sg = r.w;
-        if (nrow) sg = sg + nrow[s];
-        col[3 * s + 0] = sigmoidf_(r.x);
-        col[3 * s + 1] = sigmoidf_(r.y);
-        col[3 * s + 2] = sigmoidf_(r.z);
-        tau[s + 1] = tmax(sg, 0.0f);
-        zk[s + 1] = zrow[s];
-    }
-    if (lane == 0) {
-        zk[0] = a.near[ray];
-        zk[S + 1] = a.far[ray];
-        tau[0] = 1e-10f;
-        tau[S + 1] = 1e10f;
-    }
-    const float dx = a.rays_d[3 * ray + 0], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
-    dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
-}
-
-// Element i of the scan: e_i (the interval's exp term) and f_i (its transmittance factor).
-template <int MODE>
-__device__ __forceinline__ void interval(int i, int S, const float* zk, const float* tau, float dnorm,
-                                         float& seg, float& e, float& f) {
-    if (MODE == PLNERF_MODE_LINEAR) {
-        seg = (zk[i + 1] - zk[i]) * dnorm;
-        const float ave = 0.5f * (tau[i + 1] + tau[i]);
-        e = expf((-ave) * seg);
-        f = e;
-    } else {
-        seg = ((i < S - 1) ? (zk[i + 2] - zk[i + 1]) : 1e10f) * dnorm;
-        e = expf((-tau[i + 1]) * seg);
-        const float alpha = 1.0f - e;
-        f = 1.0f - alpha + 1e-10f;
-    }
-}
-
-// Colour attached to element i, per channel c (the reference's padded-colour rules).
-template <int MODE>
-__device__ __forceinline__ float elem_colour(int i, int c, int S, const float* col, int color_mode,
-                                             int farcolorfix) {
-    if (MODE == PLNERF_MODE_LINEAR) {
-        const float left = col[3 * (i > 0 ? i - 1 : 0) + c];  // padded[i]
-        if (color_mode == PLNERF_COLOR_LEFT) return left;
-        float right;                                           // padded[i+1]
-        if (i < S) right = col[3 * i + c];
-        else right = farcolorfix ? 0.0f : col[3 * (S - 1) + c];
-        return 0.5f * (right + left);
-    }
-    return col[3 * i + c];
-}
-
-template <int MODE>
-__device__ __forceinline__ float elem_depth(int i, const float* zk) {
-    return (MODE == PLNERF_MODE_LINEAR) ? 0.5f * (zk[i + 1] + zk[i]) : zk[i + 1];
-}
-
 template <int MODE>
 __global__ __launch_bounds__(256) void quad_fwd_kernel(QuadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -121,7 +55,7 @@ __global__ __launch_bounds__(256) void quad_fwd_kernel(QuadArgs a) {
     float* tau = zk + (S + 2);
     float* col = tau + (S + 2);
     float dnorm;
-    load_ray(a, ray, lane, zk, tau, col, dnorm);
+    load_ray(RayIn{a.raw, a.z, a.near, a.far, a.rays_d, a.noise, a.S}, ray, lane, zk, tau, col, dnorm);
     __syncthreads();
 
     const int n = (MODE == PLNERF_MODE_LINEAR) ? S + 1 : S;
@@ -200,7 +134,7 @@ __global__ __launch_bounds__(256) void quad_bwd_kernel(QuadArgs a) {
     float* wv = av + (n + 1);    // w_i
     float* qv = wv + (n + 1);    // T_i, then Q_i = dL/de_i * seg_i * e_i
     float dnorm;
-    load_ray(a, ray, lane, zk, tau, col, dnorm);
+    load_ray(RayIn{a.raw, a.z, a.near, a.far, a.rays_d, a.noise, a.S}, ray, lane, zk, tau, col, dnorm);
     const float gr = a.g_rgb[3 * ray + 0], gg = a.g_rgb[3 * ray + 1], gb = a.g_rgb[3 * ray + 2];
     const float gdep = a.g_depth ? a.g_depth[ray] : 0.0f;
     float gacc = a.g_acc ? a.g_acc[ray] : 0.0f;

@@ -14,25 +14,13 @@
 // separately rounded fp32 op (eager PyTorch), and the bit-exact index contract of
 // plnerf_sample_const depends on that.
 #include "common.h"
+#include "ray_dev.h"
 
 using namespace plnerf;
 
 namespace {
 
 constexpr int WAVES = 4;
-
-// torch.searchsorted(cdf, u, right=True): the same upper-bound bisection as ATen's
-// (mid = start + ((end-start) >> 1); !(cdf[mid] > u) -> go right), so the result agrees
-// even on a cdf that is non-monotone by an ulp.
-__device__ __forceinline__ int upper_bound(const float* cdf, int len, float u) {
-    int start = 0, end = len;
-    while (start < end) {
-        const int mid = start + ((end - start) >> 1);
-        if (!(cdf[mid] > u)) start = mid + 1;
-        else end = mid;
-    }
-    return start;
-}
 
 // fp32 row sum with the association order of torch.sum's vectorised CPU kernel (8-lane
 // vectors, 4 interleaved accumulators, leftover vectors into accumulator 0,
@@ -229,24 +217,6 @@ struct SamplePlArgs {
     int64_t* inds;
 };
 
-// Closed-form inverse of T0 * exp(-(tau0 t + (tau1-tau0) t^2 / (2 (s1-s0)))) = 1-u on
-// one interval, with the reference's epsilon guards, op for op.
-__device__ __forceinline__ float invert_segment(float s0, float s1, float T0, float tau0, float tau1,
-                                                float u, float eps, bool rising) {
-    const float ln_term = -logf(tmax(eps, (1.0f - u) / tmax(eps, T0)));
-    const float span = tmax(eps, s1 - s0);
-    float t;
-    if (rising) {
-        const float disc = tau0 * tau0 + (2.0f * (tau1 - tau0) * ln_term) / span;
-        t = ((s1 - s0) * (-tau0 + sqrtf(tmax(eps, disc)))) / tmax(eps, tau1 - tau0);
-    } else {
-        const float disc = tau0 * tau0 - (2.0f * (tau0 - tau1) * ln_term) / span;
-        t = ((s1 - s0) * (tau0 - sqrtf(tmax(eps, disc)))) / tmax(eps, tau0 - tau1);
-    }
-    t = tmin(tmax(t, eps), s1 - s0);   // torch.clamp(t, eps, s1-s0)
-    return s0 + t;
-}
-
 __global__ __launch_bounds__(256) void sample_pl_kernel(SamplePlArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -428,18 +398,6 @@ struct MergeArgs {
     float* out;
 };
 
-// Total order on fp32 as torch.sort uses it for values: ascending, NaN last.
-__device__ __forceinline__ uint32_t sort_key(float f) {
-    if (f != f) return 0xFFFFFFFFu;
-    const uint32_t b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-
-__device__ __forceinline__ float sort_unkey(uint32_t k) {
-    if (k == 0xFFFFFFFFu) return __uint_as_float(0x7FC00000u);        // NaN (and the padding, never written)
-    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
-}
-
 // Bitonic sort of one ray's keys in REGISTERS, one wavefront per ray: position p = 64 r + lane holds key x[r],
 // the row is padded with the maximum key to 64 KPL.  A compare-exchange distance j >= 64 pairs two registers of
 // the same lane; j < 64 pairs lanes l and l ^ j (one cross-lane read per key).  log2(n)(log2(n)+1)/2 stages of
@@ -463,35 +421,7 @@ __global__ __launch_bounds__(256) void merge_sort_kernel(MergeArgs a) {
         else if (p < n) k = sort_key(tmin(tmax(a.z_new[(size_t)ray * N + (p - S)], lo), hi));
         x[r] = k;
     }
-    constexpr int NP = 64 * KPL;
-#pragma unroll
-    for (int k = 2; k <= NP; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= 64) {
-                constexpr int dummy = 0; (void)dummy;
-#pragma unroll
-                for (int r = 0; r < KPL; ++r) {
-                    const int q = r ^ (j >> 6);
-                    if (q > r) {
-                        // the pair (r, q) of this lane: ascending where bit k of the position is clear
-                        const bool up = ((64 * r) & k) == 0;
-                        const uint32_t mn = min(x[r], x[q]), mx = max(x[r], x[q]);
-                        x[r] = up ? mn : mx;
-                        x[q] = up ? mx : mn;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < KPL; ++r) {
-                    const int p = 64 * r + lane;
-                    const uint32_t other = (uint32_t)__shfl_xor((int)x[r], j);
-                    const bool up = (p & k) == 0, lower = (lane & j) == 0;
-                    x[r] = (up == lower) ? min(x[r], other) : max(x[r], other);
-                }
-            }
-        }
-    }
+    bitonic_sort_regs<KPL>(x, lane);
     if (!live) return;
 #pragma unroll
     for (int r = 0; r < KPL; ++r) {

@@ -201,7 +201,7 @@ def get_rays(H, W, intrinsic, c2w, coords=None):
 
 def batchify_rays(rays_flat, chunk=1024 * 32, use_viewdirs=False, **kwargs):
     """run_nerf_sample_based_depth.py:71-83."""
-    return RB.map_row_chunks(lambda rows: render_rays(rows, use_viewdirs, **kwargs), rays_flat, chunk)
+    return RB.map_row_chunks(lambda rows, first_row: render_rays(rows, use_viewdirs, **kwargs), rays_flat, chunk)
 
 
 def render(H, W, intrinsic, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., with_5_9=False,

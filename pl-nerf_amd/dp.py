@@ -5,9 +5,10 @@ The reference has no distributed path in run_plnerf.py (its depth variant wraps 
 in single-process nn.DataParallel, run_nerf_sample_based_depth.py:564,585); SURVEY.md
 section 8e specifies this design instead: every op on the path is per ray, the only
 cross-ray coupling is the mean in img2mse, so with equal shards the global gradient is the
-average of the per-rank gradients.  Payload: 2 networks x 595,844 fp32 = 4.77 MB, sent as a
-single bucket -- at this size a collective is latency-bound, so fewer, larger messages win
-on the point-to-point xGMI links.
+average of the per-rank gradients.  Payload: 2 networks x 595,844 fp32 = 4.77 MB, sent as ONE
+in-place all-reduce per network (2.38 MB each, latency-bound on the point-to-point xGMI links:
+few large messages, not 48 small ones), the fine network's issued while the coarse network's
+backward is still running.
 """
 import os
 
@@ -44,61 +45,101 @@ def shard_rays(n_global, rank, world_size):
 
 
 class GradientBucket:
-    """One flat fp32 buffer holding every parameter gradient of the given modules, in
-    parameter order; `allreduce_mean()` averages it across ranks in a single collective and
-    scatters the result back into the `.grad` tensors."""
+    """Gradient averaging across ranks, one collective per network, overlapped with the rest of the backward.
 
-    def __init__(self, modules):
-        self.params = [p for m in modules for p in m.parameters()]
+    functional.MlpFn.backward hands autograd a network's 24 gradients as consecutive slices of ONE buffer, and
+    autograd keeps those views as the `.grad` tensors.  So a network's whole gradient is a single flat tensor that can
+    be all-reduced IN PLACE -- no gather into a bucket, no scatter back.  A post-accumulate hook on every parameter
+    counts arrivals; when a network is complete its all-reduce is enqueued at once (async: RCCL's stream waits for
+    the gradient, the autograd stream goes on).  The fine network's backward finishes first, so its 2.4 MB travel
+    over xGMI while the coarse network's backward still computes; `allreduce_mean()` -- called where the reference
+    loop would step the optimizers -- waits for both and applies the 1/world factor.
+
+    Gradients in any other layout (another module, a CPU test) fall back to one gathered bucket per call."""
+
+    def __init__(self, modules, group=None, overlap=True):
+        self.modules = list(modules)
+        self.group = group
+        self.params = [p for m in self.modules for p in m.parameters()]
         self.numel = sum(p.numel() for p in self.params)
-        dev = self.params[0].device
-        self.flat = torch.zeros(self.numel, device=dev, dtype=torch.float32)
-        self.views = []
-        off = 0
-        for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+        self._owner = {}
+        self._arrived = [0] * len(self.modules)
+        self._works = []         # (work handle, flat tensor) of the collectives in flight
+        self._reduced = [False] * len(self.modules)
+        self._hooks = []
+        self.flat = None         # fallback bucket, allocated on first use
+        if overlap and dist.is_initialized() and dist.get_world_size(group) > 1:
+            for mi, m in enumerate(self.modules):
+                for p in m.parameters():
+                    self._owner[p] = mi
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
-    def _pieces(self):
-        """The gradients as few flat tensors as their layout allows: functional.MlpFn.backward returns a network's
-        24 gradients as slices of one buffer, so this is normally one piece per network."""
-        from .optim import contiguous_runs
-        runs = contiguous_runs([p.grad for p in self.params])
-        return None if any(g is None for _, _, g in runs) else [g for _, _, g in runs]
+    # -- overlapped path ---------------------------------------------------------------------------------------
+    def _on_grad(self, p):
+        mi = self._owner[p]
+        self._arrived[mi] += 1
+        if self._arrived[mi] == sum(1 for _ in self.modules[mi].parameters()):
+            self._arrived[mi] = 0
+            self._launch(mi)
 
-    def gather(self):
-        """All .grad tensors -> the flat bucket, in ONE kernel (torch.cat into the buffer)."""
-        if all(p.grad is not None for p in self.params):
-            self._scatter_to = self._pieces()
-            torch.cat(self._scatter_to if self._scatter_to is not None else
-                      [p.grad.reshape(-1) for p in self.params], out=self.flat)
+    def _launch(self, mi):
+        from .optim import flat_view_of
+        flat = flat_view_of([p.grad for p in self.modules[mi].parameters()])
+        if flat is None:
+            return                                        # not one buffer: the fallback handles this module
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works.append((work, flat))
+        self._reduced[mi] = True
+
+    def pending(self):
+        """Collectives enqueued by the hooks and not yet waited for (for tests / diagnostics)."""
+        return len(self._works)
+
+    # -- fallback: one gathered bucket ---------------------------------------------------------------------------
+    def _fallback(self, modules, world):
+        params = [p for m in modules for p in m.parameters()]
+        if not params:
             return
-        self._scatter_to = None
-        for p, v in zip(self.params, self.views):
+        n = sum(p.numel() for p in params)
+        if self.flat is None or self.flat.numel() < n or self.flat.device != params[0].device:
+            self.flat = torch.zeros(self.numel, device=params[0].device, dtype=torch.float32)
+        flat = self.flat[:n]
+        views, off = [], 0
+        for p in params:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        for p, v in zip(params, views):
             if p.grad is None:
                 v.zero_()
             else:
                 v.copy_(p.grad)
-
-    def scatter(self):
-        """Flat bucket -> the .grad tensors, in one multi-tensor kernel."""
-        pieces = getattr(self, "_scatter_to", None)
-        if pieces is not None:
-            torch._foreach_copy_(pieces, list(self.flat.split([t.numel() for t in pieces])))
-            return
-        missing = [p for p in self.params if p.grad is None]
-        for p in missing:
-            p.grad = torch.empty_like(p)
-        torch._foreach_copy_([p.grad for p in self.params], self.views)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.mul_(1.0 / world)
+        for p, v in zip(params, views):
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+            p.grad.copy_(v)
 
     def allreduce_mean(self, group=None, force=False):
+        """Average every gradient over the ranks (in place).  Returns the number of collectives used."""
+        group = group if group is not None else self.group
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         if world == 1 and not (force and dist.is_initialized()):
-            return
-        self.gather()
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        self.flat.mul_(1.0 / world)
-        self.scatter()
+            return 0
+        if not self._hooks:                               # single rank with force=True, or overlap disabled
+            for mi in range(len(self.modules)):
+                self._launch(mi)
+        n = len(self._works)
+        for work, flat in self._works:
+            work.wait()
+            flat.mul_(1.0 / world)
+        self._works = []
+        rest = [m for mi, m in enumerate(self.modules) if not self._reduced[mi]]
+        self._reduced = [False] * len(self.modules)
+        if rest:
+            self._fallback(rest, world)
+            n += 1
+        return n
 
 
 def broadcast_parameters(modules, src=0, group=None):

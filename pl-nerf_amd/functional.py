@@ -93,34 +93,168 @@ class QuadratureFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, g_w, g_depth, g_tau, g_T):
-        raw_c, z_c, near_c, far_c, d_c, noise_c, depth, acc = ctx.saved_tensors
-        mode, color_mode, white_bkgd, farcolorfix, has_noise = ctx.cfg
-        R, S = z_c.shape
-        dev = raw_c.device
-        g_rgb = torch.zeros(R, 3, device=dev) if g_rgb is None else _f32c(g_rgb)
-        g_depth = None if g_depth is None else _f32c(g_depth)
-        g_acc = None if g_acc is None else _f32c(g_acc)
-        if g_disp is not None:
-            # disp = 1 / max(1e-10, depth/acc)  (run_plnerf.py:617): fold into depth / acc
-            ratio = depth / acc
-            live = (ratio > 1e-10).to(torch.float32) * _f32c(g_disp)
-            gd = -live * acc / (depth * depth)
-            ga = live / depth
-            gd = torch.where(torch.isfinite(gd), gd, torch.zeros_like(gd))
-            ga = torch.where(torch.isfinite(ga), ga, torch.zeros_like(ga))
-            g_depth = gd if g_depth is None else g_depth + gd
-            g_acc = ga if g_acc is None else g_acc + ga
-        g_w = None if g_w is None else _f32c(g_w)
-        g_tau = None if (g_tau is None or mode != "linear") else _f32c(g_tau)
-        g_T = None if (g_T is None or mode != "linear") else _f32c(g_T)
-        g_raw = torch.empty(R, S, 4, device=dev)
-        if R > 0:
-            L.check(L.lib().plnerf_quad_bwd(
-              L.dptr(raw_c), L.dptr(z_c), L.dptr(near_c), L.dptr(far_c), L.dptr(d_c),
-              L.dptr(noise_c) if has_noise else None, R, S, L.MODE[mode], L.COLOR[color_mode],
-              int(white_bkgd), int(farcolorfix), L.dptr(g_rgb), L.dptr(g_depth), L.dptr(g_acc), L.dptr(g_w),
-              L.dptr(g_tau), L.dptr(g_T), L.dptr(g_raw), L.stream()), "plnerf_quad_bwd")
+        g_raw = _quad_backward(ctx.saved_tensors, ctx.cfg, g_rgb, g_disp, g_acc, g_w, g_depth, g_tau, g_T)
         return g_raw, None, None, None, None, None, None, None, None, None
+
+
+def _quad_backward(saved, cfg, g_rgb, g_disp, g_acc, g_w, g_depth, g_tau, g_T):
+    """plnerf_quad_bwd from the tensors a quadrature forward saved (shared by QuadratureFn and CoarseEpilogueFn)."""
+    raw_c, z_c, near_c, far_c, d_c, noise_c, depth, acc = saved
+    mode, color_mode, white_bkgd, farcolorfix, has_noise = cfg
+    R, S = z_c.shape
+    dev = raw_c.device
+    g_rgb = torch.zeros(R, 3, device=dev) if g_rgb is None else _f32c(g_rgb)
+    g_depth = None if g_depth is None else _f32c(g_depth)
+    g_acc = None if g_acc is None else _f32c(g_acc)
+    if g_disp is not None:
+        # disp = 1 / max(1e-10, depth/acc)  (run_plnerf.py:617): fold into depth / acc
+        ratio = depth / acc
+        live = (ratio > 1e-10).to(torch.float32) * _f32c(g_disp)
+        gd = -live * acc / (depth * depth)
+        ga = live / depth
+        gd = torch.where(torch.isfinite(gd), gd, torch.zeros_like(gd))
+        ga = torch.where(torch.isfinite(ga), ga, torch.zeros_like(ga))
+        g_depth = gd if g_depth is None else g_depth + gd
+        g_acc = ga if g_acc is None else g_acc + ga
+    g_w = None if g_w is None else _f32c(g_w)
+    g_tau = None if (g_tau is None or mode != "linear") else _f32c(g_tau)
+    g_T = None if (g_T is None or mode != "linear") else _f32c(g_T)
+    g_raw = torch.empty(R, S, 4, device=dev)
+    if R > 0:
+        L.check(L.lib().plnerf_quad_bwd(
+          L.dptr(raw_c), L.dptr(z_c), L.dptr(near_c), L.dptr(far_c), L.dptr(d_c),
+          L.dptr(noise_c) if has_noise else None, R, S, L.MODE[mode], L.COLOR[color_mode],
+          int(white_bkgd), int(farcolorfix), L.dptr(g_rgb), L.dptr(g_depth), L.dptr(g_acc), L.dptr(g_w),
+          L.dptr(g_tau), L.dptr(g_T), L.dptr(g_raw), L.stream()), "plnerf_quad_bwd")
+    return g_raw
+
+
+class DrawSource:
+    """Counter-based uniform draws (csrc/philox.h): a draw is a function of (seed, step, which draw of the step, the
+    ray's GLOBAL id, column) only, so a batch sharded over N ranks (ray_id0 = the rank's first global ray) sees the
+    numbers one rank would see.  Install with `set_draw_source`; render_rays then takes its stratified jitter and
+    its sampler draws from here (in the consuming kernels themselves on the fused path) instead of torch.rand."""
+    T_RAND, U = 0, 1          # stream ids
+
+    def __init__(self, seed=0, ray_id0=0, step=0):
+        self.seed, self.ray_id0, self.step = int(seed), int(ray_id0), int(step)
+        self.chunk_offset = 0
+
+    def first_ray(self):
+        return self.ray_id0 + self.chunk_offset
+
+    def uniform(self, R, n, stream_id, device):
+        out = torch.empty(R, n, device=device)
+        if R > 0:
+            L.check(L.lib().plnerf_uniform(self.seed, stream_id, self.step, self.first_ray(), R, n, L.dptr(out),
+                                           L.stream()), "plnerf_uniform")
+        return out
+
+
+DRAWS = None
+
+
+def set_draw_source(src):
+    """Install (or with None remove) the process-wide DrawSource; returns the previous one."""
+    global DRAWS
+    prev, DRAWS = DRAWS, src
+    return prev
+
+
+class CoarseEpilogueFn(torch.autograd.Function):
+    """run_plnerf.py:714-735 in piecewise-linear mode as one launch (plnerf_coarse_epilogue): raw2outputs of the
+    coarse pass, sample_pdf_reformulation, clamp, sort(cat), the fine pass's sample positions and z_std.
+    Differentiable with respect to `raw` through the coarse maps (backward = plnerf_quad_bwd); the samples are
+    detached on the reference path (:728).  `u` None = drawn inside the kernel from `draws`."""
+
+    @staticmethod
+    def forward(ctx, raw, z, near, far, rays_o, rays_d, noise, u, N, color_mode, white_bkgd, farcolorfix, zero_tol,
+                eps, draws):
+        R, S = z.shape
+        dev = raw.device
+        _expect(tuple(raw.shape) == (R, S, 4), f"raw must be [{R}, {S}, 4], got {tuple(raw.shape)}")
+        raw_c, z_c = _f32c(raw), _f32c(z)
+        near_c, far_c = _f32c(near).reshape(-1), _f32c(far).reshape(-1)
+        o_c, d_c = _f32c(rays_o), _f32c(rays_d)
+        noise_c = None if noise is None else _f32c(noise)
+        u_c = None if u is None else _f32c(u)
+        _expect(u_c is None or tuple(u_c.shape) in ((N,), (R, N)), "u must be [N] or [R, N]")
+        _expect(u_c is not None or draws is not None, "no draws: pass u or a DrawSource")
+        stride = 0 if (u_c is None or u_c.dim() == 1) else N
+        rgb = torch.empty(R, 3, device=dev)
+        disp, acc, depth, z_std = (torch.empty(R, device=dev) for _ in range(4))
+        z_fine = torch.empty(R, S + N, device=dev)
+        pts = torch.empty(R, S + N, 3, device=dev)
+        seed, step, ray0 = (draws.seed, draws.step, draws.first_ray()) if draws is not None else (0, 0, 0)
+        L.check(L.lib().plnerf_coarse_epilogue(
+            L.dptr(raw_c, "raw"), L.dptr(z_c, "z_vals"), L.dptr(near_c, "near"), L.dptr(far_c, "far"),
+            L.dptr(o_c, "rays_o"), L.dptr(d_c, "rays_d"), L.dptr(noise_c, "noise"), L.dptr(u_c, "u"), stride, seed, step,
+            ray0, R, S, int(N), L.COLOR[color_mode], int(bool(white_bkgd)), int(bool(farcolorfix)), float(zero_tol),
+            float(eps), L.dptr(rgb), L.dptr(disp), L.dptr(acc), L.dptr(depth), None, None, None, L.dptr(z_fine),
+            L.dptr(pts), L.dptr(z_std), L.stream()), "plnerf_coarse_epilogue")
+        ctx.save_for_backward(raw_c, z_c, near_c, far_c, d_c, noise_c if noise_c is not None else torch.empty(0),
+                              depth, acc)
+        ctx.cfg = ("linear", color_mode, bool(white_bkgd), bool(farcolorfix), noise_c is not None)
+        ctx.mark_non_differentiable(z_fine, pts, z_std)
+        ctx.set_materialize_grads(False)
+        return rgb, disp, acc, depth, z_fine, pts, z_std
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_depth, g_z, g_pts, g_std):
+        g_raw = _quad_backward(ctx.saved_tensors, ctx.cfg, g_rgb, g_disp, g_acc, None, g_depth, None, None)
+        return (g_raw,) + (None,) * 14
+
+
+class ImageLossFn(torch.autograd.Function):
+    """img2mse(rgb, target) + img2mse(rgb0, target) (run_plnerf.py:1287-1296) -> (total, fine, coarse), one launch
+    that also leaves d total / d rgb and d total / d rgb0; the backward scales them by the upstream gradients."""
+
+    @staticmethod
+    def forward(ctx, rgb, rgb0, target):
+        rgb_c, t_c = _f32c(rgb), _f32c(target)
+        rgb0_c = None if rgb0 is None else _f32c(rgb0)
+        _expect(rgb_c.shape == t_c.shape and rgb_c.dim() == 2 and rgb_c.shape[1] == 3, "rgb / target must be [R, 3]")
+        R = rgb_c.shape[0]
+        loss3 = torch.empty(3, device=rgb_c.device)
+        g1 = torch.empty_like(rgb_c)
+        g0 = None if rgb0_c is None else torch.empty_like(rgb_c)
+        L.check(L.lib().plnerf_image_loss(L.dptr(rgb_c, "rgb"), L.dptr(rgb0_c, "rgb0"), L.dptr(t_c, "target"), R,
+                                          L.dptr(loss3), L.dptr(g1), L.dptr(g0), L.stream()), "plnerf_image_loss")
+        ctx.grads = (g1, g0)
+        ctx.set_materialize_grads(False)
+        total, fine, coarse = loss3.unbind(0)
+        return total, fine, coarse
+
+    @staticmethod
+    def backward(ctx, g_total, g_fine, g_coarse):
+        g1, g0 = ctx.grads
+
+        def scaled(g, *ups):
+            ups = [x for x in ups if x is not None]
+            if g is None or not ups:
+                return None
+            w = ups[0] if len(ups) == 1 else ups[0] + ups[1]
+            return g * w
+        return scaled(g1, g_total, g_fine), scaled(g0, g_total, g_coarse), None
+
+
+def coarse_samples(rays_o, rays_d, near, far, t_vals, t_rand, lindisp, perturb, draws):
+    """plnerf_coarse_samples: (z_vals [R,S], pts [R,S,3]) of run_plnerf.py:683-708.  With perturb and t_rand None
+    the jitter is drawn in the kernel from `draws`."""
+    o_c, d_c = _f32c(rays_o), _f32c(rays_d)
+    near_c, far_c = _f32c(near).reshape(-1), _f32c(far).reshape(-1)
+    t_c = _f32c(t_vals)
+    r_c = _f32c(t_rand) if t_rand is not None else None
+    R, S = near_c.shape[0], t_c.shape[0]
+    _expect(not perturb or r_c is not None or draws is not None, "perturb needs t_rand or a DrawSource")
+    z = torch.empty(R, S, device=near_c.device)
+    pts = torch.empty(R, S, 3, device=near_c.device)
+    seed, step, ray0 = (draws.seed, draws.step, draws.first_ray()) if draws is not None else (0, 0, 0)
+    L.check(L.lib().plnerf_coarse_samples(
+        L.dptr(o_c, "rays_o"), L.dptr(d_c, "rays_d"), L.dptr(near_c, "near"), L.dptr(far_c, "far"), L.dptr(t_c, "t_vals"),
+        L.dptr(r_c, "t_rand"), seed, step, ray0, R, S, int(bool(lindisp)), int(bool(perturb)), L.dptr(z), L.dptr(pts),
+        L.stream()), "plnerf_coarse_samples")
+    return z, pts
 
 
 class MlpFn(torch.autograd.Function):

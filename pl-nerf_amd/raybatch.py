@@ -30,12 +30,27 @@ def pack_rays(rays_o, rays_d, near, far, extra_columns=()):
     return torch.cat([o, d, bounds] + [c.reshape(n, -1).float() for c in extra_columns], -1), lead
 
 
+class RayColumns:
+    """A ray batch held as separate contiguous columns (what plnerf_select_rays writes) instead of the packed
+    [R, 11] rows: render_rays takes either; this form saves the five slice-copies per call."""
+
+    def __init__(self, rays_o, rays_d, near, far, viewdirs=None):
+        self.rays_o, self.rays_d, self.near, self.far, self.viewdirs = rays_o, rays_d, near, far, viewdirs
+        self.shape = (rays_o.shape[0], 11 if viewdirs is not None else 8)
+        self.device, self.is_cuda, self.requires_grad = rays_o.device, rays_o.is_cuda, False
+
+    def packed(self):
+        cols = [self.rays_o, self.rays_d, self.near.reshape(-1, 1), self.far.reshape(-1, 1)]
+        return torch.cat(cols + ([self.viewdirs] if self.viewdirs is not None else []), -1)
+
+
 def map_row_chunks(fn, rows, chunk):
-    """fn(rows[i:i+chunk]) -> dict of tensors, over consecutive chunks; values concatenated along dim 0 (what the
-    reference's batchify_rays does to bound memory, run_plnerf.py:95-107)."""
+    """fn(rows[i:i+chunk], i) -> dict of tensors, over consecutive chunks; values concatenated along dim 0 (what
+    the reference's batchify_rays does to bound memory, run_plnerf.py:95-107).  The second argument is the chunk's
+    first row, for draws keyed on the ray's position in the batch."""
     if rows.shape[0] <= chunk:
-        return dict(fn(rows))
-    parts = [fn(piece) for piece in torch.split(rows, chunk, dim=0)]
+        return dict(fn(rows, 0))
+    parts = [fn(rows[i:i + chunk], i) for i in range(0, rows.shape[0], chunk)]
     return {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]}
 
 

@@ -79,6 +79,16 @@ def _rgb_sigma(raw):
     return raw if raw.shape[-1] == 4 else raw[..., :4]
 
 
+def _draw_noise(raw, raw_noise_std, pytest):
+    """The density noise of raw2outputs (run_plnerf.py:568-576), or None."""
+    if not raw_noise_std > 0.:
+        return None
+    shape = list(raw.shape[:-1])
+    if pytest:   # the reference's deterministic draw is UNIFORM (run_plnerf.py:573-576)
+        return Fn.numpy_uniform(shape, raw.device) * raw_noise_std
+    return torch.randn(shape, device=raw.device) * raw_noise_std
+
+
 def _noise_tensor(noise, raw):
     if isinstance(noise, torch.Tensor):
         return noise.to(raw.device)
@@ -95,13 +105,7 @@ def raw2outputs(raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std=
         raise ValueError(f"mode must be 'linear' or 'constant', got {mode!r}")
     if mode == "linear" and color_mode not in ("midpoint", "left"):
         raise ValueError("Color mode unimplemented, please select left or midpoint.")
-    noise = None
-    if raw_noise_std > 0.:
-        shape = list(raw[..., 3].shape)
-        if pytest:   # the reference's deterministic draw is UNIFORM (run_plnerf.py:573-576)
-            noise = Fn.numpy_uniform(shape, raw.device) * raw_noise_std
-        else:
-            noise = torch.randn(shape, device=raw.device) * raw_noise_std
+    noise = _draw_noise(raw, raw_noise_std, pytest)
     cm = color_mode if mode == "linear" else "midpoint"
     rgb, disp, acc, w, depth, tau, T = Fn.QuadratureFn.apply(_rgb_sigma(raw), z_vals, near, far, rays_d, noise, mode,
                                                              cm, white_bkgd, farcolorfix)
@@ -145,25 +149,32 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_
     + rgb0, disp0, depth0, acc0, z_std if N_importance > 0)."""
     dev = ray_batch.device
     N_rays = ray_batch.shape[0]
-    # one contiguous copy of each column group: every kernel below takes them as they are (the slices of the
-    # packed batch would otherwise be re-copied by each of the ~12 launches that consume them)
-    rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
-    viewdirs = ray_batch[:, -3:].contiguous() if ray_batch.shape[-1] > 8 else None
-    near, far = ray_batch[:, 6:7].contiguous(), ray_batch[:, 7:8].contiguous()
+    if isinstance(ray_batch, RB.RayColumns):
+        rays_o, rays_d, near, far, viewdirs = (ray_batch.rays_o, ray_batch.rays_d, ray_batch.near.reshape(-1, 1),
+                                               ray_batch.far.reshape(-1, 1), ray_batch.viewdirs)
+    else:
+        # one contiguous copy of each column group: every kernel below takes them as they are (the slices of the
+        # packed batch would otherwise be re-copied by each launch that consumes them)
+        rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
+        viewdirs = ray_batch[:, -3:].contiguous() if ray_batch.shape[-1] > 8 else None
+        near, far = ray_batch[:, 6:7].contiguous(), ray_batch[:, 7:8].contiguous()
 
     t_vals = Fn.cpu_linspace(N_samples, dev)
     # The ray batch carries no gradient on this path (the reference never differentiates through the rays and
-    # the kernels downstream give none to positions), so the prologue's element-wise chain runs as two kernels,
-    # bit-identical to the torch expressions below -- which stay for a batch that does require grad, so that z_vals
-    # remains on the caller's tape.
+    # the kernels downstream give none to positions), so the prologue's element-wise chain runs as ONE kernel
+    # (depths + positions, bit-identical to the torch expressions below) -- which stay for a batch that does require
+    # grad, so that z_vals remains on the caller's tape.
     fused_glue = ray_batch.is_cuda and N_rays > 0 and not (torch.is_grad_enabled() and ray_batch.requires_grad)
+    # Random draws: pytest=True replays the reference's numpy draws; otherwise an installed functional.DrawSource
+    # supplies counter-based draws (inside the consuming kernels on the fused path), else torch.rand as the
+    # reference does.
+    draws = None if pytest else Fn.DRAWS
     if fused_glue:
         t_rand = None
-        if perturb > 0.:
+        if perturb > 0. and (pytest or draws is None):
             shape = [N_rays, N_samples]
             t_rand = Fn.numpy_uniform(shape, dev) if pytest else torch.rand(shape, device=dev)
-        z_vals = Fn.stratified_z(near, far, t_vals, t_rand, lindisp)
-        pts = Fn.ray_points(rays_o, rays_d, z_vals)
+        z_vals, pts = Fn.coarse_samples(rays_o, rays_d, near, far, t_vals, t_rand, lindisp, perturb > 0., draws)
     else:
         if not lindisp:
             z_vals = near * (1. - t_vals) + far * t_vals
@@ -177,6 +188,8 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_
             lower = torch.cat([z_vals[..., :1], mids], -1)
             if pytest:
                 t_rand = Fn.numpy_uniform(list(z_vals.shape), dev)
+            elif draws is not None:
+                t_rand = draws.uniform(N_rays, N_samples, Fn.DrawSource.T_RAND, dev)
             else:
                 t_rand = torch.rand(z_vals.shape, device=dev)
             z_vals = lower + (upper - lower) * t_rand
@@ -187,28 +200,39 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_
         mode = "constant"
 
     raw = network_query_fn(pts, viewdirs, network_fn)
-    rgb_map, disp_map, acc_map, weights, depth_map, tau, T = raw2outputs(
-        raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std, pytest=pytest, white_bkgd=white_bkgd,
-        farcolorfix=farcolorfix)
+    fused_epilogue = fused_glue and N_importance > 0 and mode == "linear" and color_mode in ("midpoint", "left")
+    if fused_epilogue:
+        # coarse raw2outputs + sampler + clamp + sort + fine positions + z_std: one launch (weights, tau, T and the
+        # cdf never reach HBM); identical values to the separate calls below
+        det = perturb == 0.
+        u = _draw_u([N_rays], N_importance, det, pytest, dev) if (pytest or det or draws is None) else None
+        rgb_map_0, disp_map_0, acc_map_0, depth_map_0, z_vals, pts, z_std = Fn.CoarseEpilogueFn.apply(
+            _rgb_sigma(raw), z_vals, near, far, rays_o, rays_d, _draw_noise(raw, raw_noise_std, pytest), u,
+            N_importance, color_mode, white_bkgd, farcolorfix, zero_tol, epsilon, draws)
+    else:
+        rgb_map, disp_map, acc_map, weights, depth_map, tau, T = raw2outputs(
+            raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std, pytest=pytest, white_bkgd=white_bkgd,
+            farcolorfix=farcolorfix)
 
     if N_importance > 0:
-        rgb_map_0, disp_map_0, acc_map_0, depth_map_0 = rgb_map, disp_map, acc_map, depth_map
-        if mode == "linear":
-            z_samples, _, _, _ = sample_pdf_reformulation(
-                z_vals, weights, tau, T, near, far, N_importance, det=(perturb == 0.), pytest=pytest,
-                quad_solution_v2=quad_solution_v2, zero_threshold=zero_tol, epsilon_=epsilon)
-        elif mode == "constant":
-            z_vals_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
-            z_samples = sample_pdf(z_vals_mid, weights[..., 1:-1], N_importance, det=(perturb == 0.),
-                                   pytest=pytest)
-        z_samples = z_samples.detach()
-        # clamp + cat + sort (run_plnerf.py:731-734) in one kernel; z_samples clamped for z_std
-        z_vals = Fn.merge_sort(z_vals, z_samples, near, far)
-        z_samples = torch.clamp(z_samples, near, far)
-        if fused_glue:
-            pts = Fn.ray_points(rays_o, rays_d, z_vals)
-        else:
-            pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+        if not fused_epilogue:
+            rgb_map_0, disp_map_0, acc_map_0, depth_map_0 = rgb_map, disp_map, acc_map, depth_map
+            if mode == "linear":
+                z_samples, _, _, _ = sample_pdf_reformulation(
+                    z_vals, weights, tau, T, near, far, N_importance, det=(perturb == 0.), pytest=pytest,
+                    quad_solution_v2=quad_solution_v2, zero_threshold=zero_tol, epsilon_=epsilon)
+            elif mode == "constant":
+                z_vals_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+                z_samples = sample_pdf(z_vals_mid, weights[..., 1:-1], N_importance, det=(perturb == 0.),
+                                       pytest=pytest)
+            z_samples = z_samples.detach()
+            # clamp + cat + sort (run_plnerf.py:731-734) in one kernel; z_samples clamped for z_std
+            z_vals = Fn.merge_sort(z_vals, z_samples, near, far)
+            z_std = torch.std(torch.clamp(z_samples, near, far), dim=-1, unbiased=False)
+            if fused_glue:
+                pts = Fn.ray_points(rays_o, rays_d, z_vals)
+            else:
+                pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
 
         run_fn = network_fn if network_fine is None else network_fine
         raw = network_query_fn(pts, viewdirs, run_fn)
@@ -224,7 +248,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_
         ret['disp0'] = disp_map_0
         ret['depth0'] = depth_map_0
         ret['acc0'] = acc_map_0
-        ret['z_std'] = torch.std(z_samples, dim=-1, unbiased=False)
+        ret['z_std'] = z_std
 
     if DEBUG:
         for k in ret:
@@ -235,7 +259,15 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_
 
 def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
     """run_plnerf.py:95-107: render_rays over chunks of the flat ray rows."""
-    return RB.map_row_chunks(lambda rows: render_rays(rows, **kwargs), rays_flat, chunk)
+    def one_chunk(rows, first_row):
+        if Fn.DRAWS is not None:
+            Fn.DRAWS.chunk_offset = first_row       # draws are keyed on the ray's position in the whole batch
+        return render_rays(rows, **kwargs)
+    try:
+        return RB.map_row_chunks(one_chunk, rays_flat, chunk)
+    finally:
+        if Fn.DRAWS is not None:
+            Fn.DRAWS.chunk_offset = 0
 
 
 def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,

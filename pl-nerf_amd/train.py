@@ -9,13 +9,17 @@ ray shards per rank with one bucketed gradient all-reduce (dp.py).  Ray selectio
 device (only the N_rand selected pixels are turned into rays) instead of rebuilding the full
 H x W ray grid and choosing on the host every step (lines 1259, 1275).
 """
+import ctypes
 import os
 
 import numpy as np
 import torch
 
+from . import _lib as L
 from . import dp
-from .render import render
+from . import functional as Fn
+from . import raybatch as RB
+from .render import render, render_rays
 
 
 class _MseFn(torch.autograd.Function):
@@ -42,7 +46,8 @@ def img2mse(x, y):
 
 
 def mse2psnr(x):
-    return -10. * torch.log(x) / torch.log(torch.tensor(10., device=x.device))
+    """run_nerf_helpers.py:18: -10 log10(x)."""
+    return -10. * torch.log10(x)
 
 
 def select_rays(H, W, K, c2w, n_rand, generator=None, precrop=None):
@@ -66,13 +71,47 @@ def select_rays(H, W, K, c2w, n_rand, generator=None, precrop=None):
     return torch.stack([rays_o, rays_d], 0), rows, cols
 
 
+def select_view_rays(H, W, K, c2w, image, n_rand, near, far, seed=0, step=0, ray_id0=0, precrop=None,
+                     want_viewdirs=True, want_pixels=False):
+    """Device-side version of the reference's per-step ray selection (run_plnerf.py:1259-1281) in ONE launch
+    (plnerf_select_rays): `n_rand` distinct random pixels of the view `c2w` (inside the central precrop window, if
+    given as (dH, dW)), their rays, unit view directions, near / far columns and target colours image[row, col].
+    The choice is a keyed bijection of the pixel window evaluated at the global ray ids ray_id0 .. ray_id0 + n_rand
+    - 1, so ranks with disjoint id ranges draw disjoint pixels of one global sample.
+    Returns (RayColumns, target [n_rand, 3] or None, pixels [n_rand, 2] int32 or None)."""
+    dev = image.device if image is not None else torch.device("cuda", torch.cuda.current_device())
+    if precrop is not None:
+        dH, dW = precrop
+        r0, c0, nr, nc = H // 2 - dH, W // 2 - dW, 2 * dH, 2 * dW
+    else:
+        r0, c0, nr, nc = 0, 0, H, W
+    c2w_host = (ctypes.c_float * 12)(*[float(v) for v in torch.as_tensor(c2w, device="cpu")[:3, :4].reshape(-1)])
+    o, d = torch.empty(n_rand, 3, device=dev), torch.empty(n_rand, 3, device=dev)
+    vd = torch.empty(n_rand, 3, device=dev) if want_viewdirs else None
+    nr_col, fr_col = torch.empty(n_rand, device=dev), torch.empty(n_rand, device=dev)
+    target = torch.empty(n_rand, 3, device=dev) if image is not None else None
+    pix = torch.empty(n_rand, 2, device=dev, dtype=torch.int32) if want_pixels else None
+    img_c = None if image is None else image.detach().to(torch.float32).contiguous()
+    L.check(L.lib().plnerf_select_rays(
+        int(H), int(W), float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]), c2w_host,
+        L.dptr(img_c, "image"), r0, c0, nr, nc, int(seed), int(step), int(ray_id0), int(n_rand), float(near),
+        float(far), L.dptr(o), L.dptr(d), L.dptr(vd), L.dptr(nr_col), L.dptr(fr_col), L.dptr(target),
+        L.dptr(pix, "pixels", torch.int32), L.stream()), "plnerf_select_rays")
+    return RB.RayColumns(o, d, nr_col, fr_col, vd), target, pix
+
+
 class TrainStep:
     """One training iteration of the reference loop on the HIP path.
 
     render_kwargs / optimizer / optimizer_coarse come from create_nerf(args).  `args` supplies
-    lrate, lrate_decay, constant_init (iterations of forced constant-mode warm-up), chunk."""
+    lrate, lrate_decay, constant_init (iterations of forced constant-mode warm-up), chunk.
 
-    def __init__(self, args, render_kwargs_train, optimizer, optimizer_coarse, start=0, distributed=None):
+    Random draws (stratified jitter, sampler u, pixel choice) come from a counter-based generator keyed on
+    (`seed`, step, global ray id) (functional.DrawSource): a global batch gives the same step whether one rank
+    renders it or N ranks render a shard each.  `counter_rng=False` restores torch.rand."""
+
+    def __init__(self, args, render_kwargs_train, optimizer, optimizer_coarse, start=0, distributed=None, seed=0,
+                 counter_rng=True):
         self.args = args
         self.kw = render_kwargs_train
         self.optimizer = optimizer
@@ -80,8 +119,12 @@ class TrainStep:
         self.global_step = start
         self.nets = [n for n in (self.kw["network_fn"], self.kw.get("network_fine")) if n is not None]
         distributed = torch.distributed.is_initialized() if distributed is None else distributed
+        self.rank, self.world = (torch.distributed.get_rank(), torch.distributed.get_world_size()) if distributed \
+            else (0, 1)
+        self.draws = Fn.DrawSource(seed=seed) if counter_rng else None
+        self.seed = seed
         self.bucket = None
-        if distributed and torch.distributed.get_world_size() > 1:
+        if distributed and self.world > 1:
             # replicas must start from the same weights (create_nerf initialises from each process's own RNG, and a
             # checkpoint may have been loaded on one rank only): averaged gradients applied to different weights
             # diverge silently
@@ -92,18 +135,53 @@ class TrainStep:
         decay_rate, decay_steps = 0.1, self.args.lrate_decay * 1000
         return self.args.lrate * (decay_rate ** (self.global_step / decay_steps))
 
+    def step_view(self, H, W, K, c2w, image, near=0., far=1., n_rand=None, precrop=None):
+        """The loop body from the view on (run_plnerf.py:1259-1316): choose this rank's n_rand pixels of the view on
+        the device, then the optimisation step.  `image` [H, W, 3] lives on the device."""
+        n_rand = int(n_rand if n_rand is not None else self.args.N_rand)
+        cols, target, _ = select_view_rays(H, W, K, c2w, image, n_rand, near, far, seed=self.seed,
+                                           step=self.global_step, ray_id0=self.rank * n_rand, precrop=precrop,
+                                           want_viewdirs=bool(self.kw.get("use_viewdirs", True)))
+        return self._step(H, W, K, cols, target, near, far)
+
     def __call__(self, H, W, K, batch_rays, target_s, near=0., far=1.):
-        i = self.global_step + 1                      # the reference iterates i = start+1 .. N_iters
+        return self._step(H, W, K, batch_rays, target_s, near, far)
+
+    def _render(self, H, W, K, rays, near, far, constant_init):
         chunk = getattr(self.args, "chunk", 1024 * 32)
-        rgb, disp, acc, extras = render(H, W, K, chunk=chunk, rays=batch_rays, near=near, far=far, retraw=True,
-                                        constant_init=i < getattr(self.args, "constant_init", 0), **self.kw)
+        direct = isinstance(rays, RB.RayColumns) and rays.shape[0] <= chunk and not self.kw.get("ndc", True) \
+            and (rays.viewdirs is not None) == bool(self.kw.get("use_viewdirs", False))
+        if direct:     # the columns go straight into render_rays: no packing, no slicing
+            kw = {k: v for k, v in self.kw.items() if k not in ("ndc", "use_viewdirs")}
+            ret = render_rays(rays, retraw=True, constant_init=constant_init, **kw)
+            return ret['rgb_map'], ret
+        if isinstance(rays, RB.RayColumns):
+            rays = (rays.rays_o, rays.rays_d)
+        rgb, disp, acc, extras = render(H, W, K, chunk=chunk, rays=rays, near=near, far=far, retraw=True,
+                                        constant_init=constant_init, **self.kw)
+        return rgb, extras
+
+    def _step(self, H, W, K, rays, target_s, near, far):
+        i = self.global_step + 1                      # the reference iterates i = start+1 .. N_iters
+        n_local = rays.shape[0] if isinstance(rays, RB.RayColumns) else rays[0].reshape(-1, 3).shape[0]
+        prev = Fn.DRAWS
+        if self.draws is not None:
+            self.draws.step, self.draws.ray_id0 = self.global_step, self.rank * n_local
+            Fn.set_draw_source(self.draws)
+        try:
+            rgb, extras = self._render(H, W, K, rays, near, far, i < getattr(self.args, "constant_init", 0))
+        finally:
+            Fn.set_draw_source(prev)
         self.optimizer.zero_grad()
         self.optimizer_coarse.zero_grad()
-        img_loss = img2mse(rgb, target_s)
-        loss = img_loss
+        rgb0 = extras.get('rgb0')
+        if rgb.is_cuda and rgb.dim() == 2 and rgb.shape == target_s.shape:
+            # img2mse(rgb) + img2mse(rgb0) and both gradients in one launch (:1287-1296)
+            loss, img_loss, _ = Fn.ImageLossFn.apply(rgb, rgb0, target_s)
+        else:
+            img_loss = img2mse(rgb, target_s)
+            loss = img_loss if rgb0 is None else img_loss + img2mse(rgb0, target_s)
         psnr = mse2psnr(img_loss.detach())
-        if 'rgb0' in extras:
-            loss = loss + img2mse(extras['rgb0'], target_s)
         loss.backward()
         if self.bucket is not None:
             self.bucket.allreduce_mean()

@@ -1,0 +1,246 @@
+"""The step-level kernels (csrc/epilogue.hip, csrc/step.hip) on a real MI355X: the fused coarse epilogue against the
+separate launches it replaces (bit for bit), the counter-based draws (known-answer + invariance to how a batch is
+split), device-side ray selection against the get_rays formula, the fused image loss against torch, and the training
+step built from them.
+"""
+import os
+import tempfile
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import plnerf_oracle as orc
+from test_gpu_parity import assert_close, dev, g, make_net, maxdiff, quad_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    import plnerf_amd
+    return plnerf_amd
+
+
+# ----------------------------------------------------------------------------- Philox (host restatement for the KAT)
+def _philox4x32_10(ctr, key):
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    c, k = list(ctr), list(key)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xFFFFFFFF, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xFFFFFFFF]
+        k = [(k[0] + W0) & 0xFFFFFFFF, (k[1] + W1) & 0xFFFFFFFF]
+    return c
+
+
+def test_philox_known_answers_and_device_draws(P):
+    from plnerf_amd import functional as Fn
+    # Random123's known-answer vectors for philox4x32-10
+    assert _philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert _philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert _philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    seed, step, stream_id, id0 = 0x1234567890abcdef, 7, 1, 1000
+    src = Fn.DrawSource(seed=seed, ray_id0=id0, step=step)
+    out = src.uniform(5, 10, stream_id, dev()).cpu().numpy()
+    for r in range(5):
+        for col in range(10):
+            w = _philox4x32_10([id0 + r, col >> 2, stream_id, step], [seed & 0xFFFFFFFF, seed >> 32])[col & 3]
+            assert out[r, col] == np.float32((w >> 8) * 2.0 ** -24), (r, col)
+    big = src.uniform(4096, 128, 0, dev())
+    assert float(big.min()) >= 0.0 and float(big.max()) < 1.0
+    assert abs(float(big.mean()) - 0.5) < 2e-3 and abs(float(big.var()) - 1.0 / 12.0) < 1e-3
+    # a batch drawn in one piece == the same global rows drawn as two shards
+    a = Fn.DrawSource(seed=3, ray_id0=0, step=2).uniform(8, 64, 0, dev())
+    b = torch.cat([Fn.DrawSource(seed=3, ray_id0=0, step=2).uniform(5, 64, 0, dev()),
+                   Fn.DrawSource(seed=3, ray_id0=5, step=2).uniform(3, 64, 0, dev())], 0)
+    assert torch.equal(a, b)
+    assert not torch.equal(a, Fn.DrawSource(seed=3, ray_id0=0, step=3).uniform(8, 64, 0, dev()))
+
+
+# ----------------------------------------------------------------------------- fused coarse epilogue
+@pytest.mark.parametrize("S,N,color,white", [(64, 128, "midpoint", True), (128, 64, "midpoint", False),
+                                             (37, 23, "left", True), (300, 200, "midpoint", True), (2, 1, "midpoint", False)])
+def test_fused_coarse_epilogue_equals_separate_launches(P, S, N, color, white):
+    """plnerf_coarse_epilogue == plnerf_quad_fwd -> plnerf_sample_pl -> clamp -> plnerf_merge_sort ->
+    plnerf_ray_points, bit for bit (same device functions, same LDS values), forward and backward; z_std against
+    torch.std."""
+    from plnerf_amd import functional as Fn
+    R = 133
+    raw, z, near, far, d, _ = quad_case(R, S, 1000 + S)
+    gen = torch.Generator().manual_seed(S * 7 + N)
+    o = torch.randn(R, 3, generator=gen)
+    u = torch.rand(R, N, generator=gen)
+    noise = torch.rand(R, S, generator=gen) if S == 37 else None
+    raw_a = g(raw).requires_grad_(True)
+    rgb, disp, acc, w, depth, tau, Tr = Fn.QuadratureFn.apply(raw_a, g(z), g(near), g(far), g(d), None if noise is None else g(noise),
+                                                              "linear", color, white, False)
+    zs = Fn.sample_pl(g(z), w, tau, Tr, g(near), g(far), g(u), 1e-4, 1e-3).detach()
+    z_fine = Fn.merge_sort(g(z), zs, g(near), g(far))
+    pts = Fn.ray_points(g(o), g(d), z_fine)
+    z_std = torch.std(torch.clamp(zs, g(near), g(far)), dim=-1, unbiased=False)
+    raw_b = g(raw).requires_grad_(True)
+    out = Fn.CoarseEpilogueFn.apply(raw_b, g(z), g(near), g(far), g(o), g(d), None if noise is None else g(noise), g(u),
+                                    N, color, white, False, 1e-4, 1e-3, None)
+    for name, a, b in (("rgb0", rgb, out[0]), ("disp0", disp, out[1]), ("acc0", acc, out[2]), ("depth0", depth, out[3]),
+                       ("z_fine", z_fine, out[4]), ("pts", pts, out[5])):
+        assert torch.equal(a, b), (name, maxdiff(a, b))
+    assert_close(out[6], z_std.cpu(), atol=2e-6, rtol=2e-6, what="z_std")
+    cot = torch.randn(R, 3, generator=gen)
+    (rgb * g(cot)).sum().backward()
+    (out[0] * g(cot)).sum().backward()
+    assert torch.equal(raw_a.grad, raw_b.grad)
+    # draws made inside the kernel == the same draws handed in as a tensor
+    src = Fn.DrawSource(seed=11, ray_id0=40, step=5)
+    u_dev = src.uniform(R, N, Fn.DrawSource.U, dev())
+    a = Fn.CoarseEpilogueFn.apply(g(raw), g(z), g(near), g(far), g(o), g(d), None, u_dev, N, color, white, False, 1e-4,
+                                  1e-3, None)
+    b = Fn.CoarseEpilogueFn.apply(g(raw), g(z), g(near), g(far), g(o), g(d), None, None, N, color, white, False, 1e-4,
+                                  1e-3, src)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("S,lindisp", [(64, False), (128, False), (37, True), (1, False)])
+def test_coarse_samples_equals_separate_launches(P, S, lindisp):
+    from plnerf_amd import functional as Fn
+    R = 77
+    gen = torch.Generator().manual_seed(S)
+    o, d = g(torch.randn(R, 3, generator=gen)), g(torch.randn(R, 3, generator=gen))
+    near = g(1.0 + torch.rand(R, 1, generator=gen))
+    far = near + 3.0
+    t_vals = Fn.cpu_linspace(S, dev())
+    src = Fn.DrawSource(seed=5, ray_id0=9, step=1)
+    t_rand = src.uniform(R, S, Fn.DrawSource.T_RAND, dev())
+    for tr, draws, perturb in ((None, None, False), (t_rand, None, True), (None, src, True)):
+        z_ref = Fn.stratified_z(near, far, t_vals, t_rand if perturb else None, lindisp)
+        p_ref = Fn.ray_points(o, d, z_ref)
+        z, p = Fn.coarse_samples(o, d, near, far, t_vals, tr, lindisp, perturb, draws)
+        assert torch.equal(z, z_ref) and torch.equal(p, p_ref), (S, lindisp, perturb)
+
+
+# ----------------------------------------------------------------------------- ray selection, loss
+def test_select_view_rays(P):
+    H, W, f = 40, 60, 50.0
+    K = [[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]]
+    c2w = P.rays.pose_spherical(40.0, -30.0, 4.0)[:3, :4]
+    image = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(0))
+    o_all, d_all = P.get_rays(H, W, K, c2w)
+    for precrop, n in ((None, 500), ((7, 9), 2 * 7 * 2 * 9)):      # the second draw takes EVERY pixel of the window
+        cols, target, pix = P.select_view_rays(H, W, K, c2w, g(image), n, 2.0, 6.0, seed=4, step=3, precrop=precrop,
+                                               want_pixels=True)
+        rows, cs = pix[:, 0].long().cpu(), pix[:, 1].long().cpu()
+        assert len(set((rows * W + cs).tolist())) == n                                   # distinct pixels
+        if precrop is not None:
+            assert rows.min() == H // 2 - 7 and rows.max() == H // 2 + 6 and cs.min() == W // 2 - 9 and cs.max() == W // 2 + 8
+        assert_close(cols.rays_d, d_all[rows, cs], atol=1e-6, rtol=1e-6, what="rays_d")
+        assert torch.equal(cols.rays_o.cpu(), o_all[rows, cs])
+        assert_close(cols.viewdirs, torch.nn.functional.normalize(d_all[rows, cs], dim=-1), atol=1e-6, rtol=1e-6, what="viewdirs")
+        assert torch.equal(target.cpu(), image[rows, cs])
+        assert (cols.near == 2.0).all() and (cols.far == 6.0).all()
+    # two ranks of a global batch of 300 draw the same pixels one rank would, and disjoint ones
+    whole = P.select_view_rays(H, W, K, c2w, g(image), 300, 2.0, 6.0, seed=4, step=9, want_pixels=True)
+    h0 = P.select_view_rays(H, W, K, c2w, g(image), 150, 2.0, 6.0, seed=4, step=9, ray_id0=0, want_pixels=True)
+    h1 = P.select_view_rays(H, W, K, c2w, g(image), 150, 2.0, 6.0, seed=4, step=9, ray_id0=150, want_pixels=True)
+    assert torch.equal(whole[2], torch.cat([h0[2], h1[2]], 0)) and torch.equal(whole[1], torch.cat([h0[1], h1[1]], 0))
+    other = P.select_view_rays(H, W, K, c2w, g(image), 300, 2.0, 6.0, seed=4, step=10, want_pixels=True)
+    assert not torch.equal(whole[2], other[2])
+    # the choice is roughly uniform over the image: mean pixel coordinates near the centre
+    many = P.select_view_rays(800, 800, [[1111.0, 0, 400], [0, 1111.0, 400], [0, 0, 1]], c2w, None, 65536, 2.0, 6.0,
+                              seed=1, step=0, want_pixels=True)[2].float()
+    assert abs(float(many[:, 0].mean()) - 399.5) < 4.0 and abs(float(many[:, 1].mean()) - 399.5) < 4.0
+
+
+def test_image_loss_matches_torch(P):
+    from plnerf_amd import functional as Fn
+    gen = torch.Generator().manual_seed(2)
+    R = 4096
+    rgb, rgb0, target = (torch.rand(R, 3, generator=gen) for _ in range(3))
+    a, b = rgb.clone().requires_grad_(True), rgb0.clone().requires_grad_(True)
+    ref = torch.mean((a - target) ** 2) + torch.mean((b - target) ** 2)
+    ref.backward()
+    x, y = g(rgb).requires_grad_(True), g(rgb0).requires_grad_(True)
+    total, fine, coarse = Fn.ImageLossFn.apply(x, y, g(target))
+    assert abs(float(total) - float(ref)) <= 1e-7 and abs(float(fine) - float(torch.mean((rgb - target) ** 2))) <= 1e-7
+    (3.0 * total + 0.5 * fine).backward()
+    assert_close(x.grad, 3.5 * a.grad, atol=1e-9, rtol=1e-6, what="g_rgb")
+    assert_close(y.grad, 3.0 * b.grad, atol=1e-9, rtol=1e-6, what="g_rgb0")
+    x2 = g(rgb).requires_grad_(True)
+    t2, f2, c2 = Fn.ImageLossFn.apply(x2, None, g(target))      # single-pass configuration
+    t2.backward()
+    assert abs(float(t2) - float(f2)) == 0.0 and float(c2) == 0.0
+    assert_close(x2.grad, a.grad, atol=1e-9, rtol=1e-6, what="g_rgb single")
+
+
+# ----------------------------------------------------------------------------- the step built from them
+def _args(ckpt_dir, precision="f16x3", **over):
+    a = dict(multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=128, N_samples=64, netdepth=8,
+             netwidth=256, netdepth_fine=8, netwidth_fine=256, netchunk=65536, lrate=5e-4, coarse_lrate=5e-4,
+             ft_path=None, ckpt_dir=ckpt_dir, expname="exp", no_reload=True, perturb=1.0, white_bkgd=True,
+             raw_noise_std=0.0, mode="linear", color_mode="midpoint", dataset="blender", no_ndc=False, lindisp=False,
+             lrate_decay=250, constant_init=0, chunk=32768, precision=precision, N_rand=256)
+    a.update(over)
+    return Namespace(**a)
+
+
+def _nets(P, precision="f16x3", **over):
+    d = tempfile.mkdtemp()
+    os.makedirs(os.path.join(d, "exp"))
+    args = _args(d, precision, **over)
+    kw, _, start, _, opt, opt_c = P.create_nerf(args, device=dev())
+    kw["network_fn"].load_state_dict(orc.closed_form_state_dict(0, False))
+    kw["network_fine"].load_state_dict(orc.closed_form_state_dict(1, False))
+    return args, kw, opt, opt_c
+
+
+def test_render_is_invariant_to_sharding_of_the_batch(P):
+    """Counter-based draws: rendering a global batch in one piece, as two "ranks" (ray_id0 offsets), or in chunks gives
+    the same per-ray results, bit for bit -- what makes a data-parallel step independent of the world size."""
+    from plnerf_amd import functional as Fn
+    args, kw, _, _ = _nets(P)
+    batch, _ = orc.synthetic_blender_rays(96, seed=21)
+    rays = g(batch)
+    rkw = {k: v for k, v in kw.items() if k not in ("ndc", "use_viewdirs")}
+
+    def run(rows, id0, chunk=None):
+        prev = Fn.set_draw_source(Fn.DrawSource(seed=8, ray_id0=id0, step=4))
+        try:
+            with torch.no_grad():
+                if chunk is None:
+                    return P.render_rays(rows, retraw=True, **rkw)
+                return P.batchify_rays(rows, chunk, retraw=True, **rkw)
+        finally:
+            Fn.set_draw_source(prev)
+    whole = run(rays, 0)
+    a, b = run(rays[:40], 0), run(rays[40:], 40)
+    chunked = run(rays, 0, chunk=36)
+    for k in ("rgb_map", "depth_map", "rgb0", "z_std", "raw"):
+        assert torch.equal(whole[k], torch.cat([a[k], b[k]], 0)), k
+        assert torch.equal(whole[k], chunked[k]), k
+    other = run(rays, 1)
+    assert not torch.equal(whole["rgb_map"], other["rgb_map"])
+
+
+def test_train_step_from_a_view(P):
+    """TrainStep.step_view (device-side pixel choice -> columns -> render_rays -> fused loss -> backward -> Adam) equals
+    TrainStep.__call__ on the same rays and targets, and optimises."""
+    H = W = 100
+    K = [[140.0, 0, W / 2], [0, 140.0, H / 2], [0, 0, 1]]
+    c2w = P.rays.pose_spherical(30.0, -30.0, 4.0)[:3, :4]
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+    image = g(torch.stack([xx, yy, 0.5 * (xx + yy)], -1))
+    args, kw, opt, opt_c = _nets(P)
+    ts = P.TrainStep(args, kw, opt, opt_c, distributed=False, seed=5)
+    args2, kw2, opt2, opt_c2 = _nets(P)
+    ts2 = P.TrainStep(args2, kw2, opt2, opt_c2, distributed=False, seed=5)
+    losses = []
+    for step in range(6):
+        cols, target, _ = P.select_view_rays(H, W, K, c2w, image, 256, 2.0, 6.0, seed=5, step=step)
+        loss2, psnr2 = ts2(H, W, K, (cols.rays_o, cols.rays_d), target, near=2.0, far=6.0)
+        loss, psnr = ts.step_view(H, W, K, c2w, image, near=2.0, far=6.0, n_rand=256)
+        losses.append(float(loss))
+        assert abs(float(loss) - float(loss2)) <= 2e-6 * max(1.0, float(loss2)), (step, float(loss), float(loss2))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    for p, q in zip(kw["network_fine"].parameters(), kw2["network_fine"].parameters()):
+        assert maxdiff(p, q) <= 1e-4
