@@ -216,7 +216,8 @@ int plnerf_coarse_samples(const float* rays_o, const float* rays_d, const float*
                           plnerf_stream_t stream);
 
 /* img2mse(rgb, target) + img2mse(rgb0, target) (run_plnerf.py:1287-1296; run_nerf_helpers.py:17):
- * loss3 = {total, fine, coarse}; g_rgb, g_rgb0 [R,3] = d total / d rgb, d total / d rgb0.
+ * loss3 [4] = {total, fine, coarse, psnr = -10 log10(fine)}; g_rgb, g_rgb0 [R,3] = d total / d rgb,
+ * d total / d rgb0.
  * rgb0 may be NULL (single-pass configuration).  Deterministic (one workgroup, fp64 partial sums). */
 int plnerf_image_loss(const float* rgb, const float* rgb0, const float* target, int R, float* loss3,
                       float* g_rgb, float* g_rgb0, plnerf_stream_t stream);

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void coarse_samples_kernel(const CoarseArgs a)
 // order -> deterministic.
 __global__ __launch_bounds__(1024) void image_loss_kernel(const float* __restrict__ rgb, const float* __restrict__ rgb0,
                                                            const float* __restrict__ target, const int n,
-                                                           float* __restrict__ loss3, float* __restrict__ g_rgb,
+                                                           float* __restrict__ loss3 /* [4] */, float* __restrict__ g_rgb,
                                                            float* __restrict__ g_rgb0) {
     __shared__ double part[2][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -210,6 +210,7 @@ __global__ __launch_bounds__(1024) void image_loss_kernel(const float* __restric
         loss3[0] = fine + coarse;
         loss3[1] = fine;
         loss3[2] = coarse;
+        loss3[3] = -10.0f * log10f(fine);      // mse2psnr(img_loss) (run_nerf_helpers.py:18, run_plnerf.py:1290)
     }
 }
 

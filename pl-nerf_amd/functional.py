@@ -215,14 +215,14 @@ class ImageLossFn(torch.autograd.Function):
         rgb0_c = None if rgb0 is None else _f32c(rgb0)
         _expect(rgb_c.shape == t_c.shape and rgb_c.dim() == 2 and rgb_c.shape[1] == 3, "rgb / target must be [R, 3]")
         R = rgb_c.shape[0]
-        loss3 = torch.empty(3, device=rgb_c.device)
+        loss3 = torch.empty(4, device=rgb_c.device)
         g1 = torch.empty_like(rgb_c)
         g0 = None if rgb0_c is None else torch.empty_like(rgb_c)
         L.check(L.lib().plnerf_image_loss(L.dptr(rgb_c, "rgb"), L.dptr(rgb0_c, "rgb0"), L.dptr(t_c, "target"), R,
                                           L.dptr(loss3), L.dptr(g1), L.dptr(g0), L.stream()), "plnerf_image_loss")
         ctx.grads = (g1, g0)
         ctx.set_materialize_grads(False)
-        total, fine, coarse = loss3.unbind(0)
+        total, fine, coarse, _ = loss3.unbind(0)
         return total, fine, coarse
 
     @staticmethod
@@ -236,6 +236,22 @@ class ImageLossFn(torch.autograd.Function):
             w = ups[0] if len(ups) == 1 else ups[0] + ups[1]
             return g * w
         return scaled(g1, g_total, g_fine), scaled(g0, g_total, g_coarse), None
+
+
+def image_loss_and_grads(rgb, rgb0, target):
+    """plnerf_image_loss without the autograd wrapper, for a caller that back-propagates the two gradients itself
+    (train.TrainStep: torch.autograd.backward((rgb, rgb0), (g_rgb, g_rgb0)) is loss.backward() minus three tiny
+    launches).  Returns (loss4 = [total, fine, coarse, psnr], g_rgb, g_rgb0)."""
+    rgb_c, t_c = _f32c(rgb), _f32c(target)
+    rgb0_c = None if rgb0 is None else _f32c(rgb0)
+    _expect(rgb_c.shape == t_c.shape and rgb_c.dim() == 2 and rgb_c.shape[1] == 3, "rgb / target must be [R, 3]")
+    loss4 = torch.empty(4, device=rgb_c.device)
+    g1 = torch.empty_like(rgb_c)
+    g0 = None if rgb0_c is None else torch.empty_like(rgb_c)
+    L.check(L.lib().plnerf_image_loss(L.dptr(rgb_c, "rgb"), L.dptr(rgb0_c, "rgb0"), L.dptr(t_c, "target"),
+                                      rgb_c.shape[0], L.dptr(loss4), L.dptr(g1), L.dptr(g0), L.stream()),
+            "plnerf_image_loss")
+    return loss4, g1, g0
 
 
 def coarse_samples(rays_o, rays_d, near, far, t_vals, t_rand, lindisp, perturb, draws):

