@@ -32,5 +32,12 @@ int bf16_fwd(const void* packed, int ns, int f16, const float* pts, const float*
 int bf16_dgrad(const void* packed, int ns, const float* g_raw, int n_rows, const void* saved, void* dz,
                const unsigned* gmax, hipStream_t st);
 
+// Register-resident forward kernel (mlp_rr.hip; IEEE-half elements): its own weight section (k order permuted to the
+// accumulator layout) appended to the packed buffer of the half modes.
+size_t rr_packed_bytes(int ns);
+int rr_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, void* section, hipStream_t st);
+int rr_fwd(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs, int n_rows,
+           int samples_per_ray, float* raw_out, void* saved, hipStream_t st);
+
 }  // namespace impl
 }  // namespace plnerf

@@ -316,3 +316,66 @@ def test_reference_written_checkpoint_loads_and_continues(P, golden, precision, 
     # coarse Adam restarts: a first step (every weight moves ~lr, sign flips cost 2 lr).  The fine Adam's second step
     # divides by sqrt(v) built from two gradients: same bound.
     assert worst["coarse"] <= 1.25e-3 and worst["fine"] <= 1.25e-3
+
+
+# ----------------------------------------------------------------------------- the two forward kernels of the half modes
+_KERNEL_PROBE = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+import plnerf_amd as P
+from oracle import plnerf_oracle as orc
+dev = torch.device("cuda:0")
+out = {}
+for prec in ("f16x3", "f16"):
+    net = P.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True, precision=prec)
+    net.load_state_dict(orc.closed_form_state_dict(3, True))
+    net = net.to(dev)
+    gen = torch.Generator().manual_seed(5)
+    pts = ((torch.rand(37, 101, 3, generator=gen) * 2 - 1) * 2.5).to(dev)          # 3737 rows: ragged last tile
+    vd = torch.nn.functional.normalize(torch.randn(37, 3, generator=gen), dim=-1).to(dev)
+    cot = torch.randn(37, 101, 4, generator=gen).to(dev)
+    with torch.no_grad():
+        out[prec + "_infer"] = net.query(pts, vd).cpu()
+    raw = net.query(pts, vd)
+    (raw * cot).sum().backward()
+    out[prec + "_train"] = raw.detach().cpu()
+    out[prec + "_grads"] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
+torch.save(out, sys.argv[2])
+'''
+
+
+def test_register_resident_and_ping_pong_forward_kernels_agree(P, tmp_path):
+    """The half-element modes have two forward kernels (mlp_rr.hip: inference by default; mlp_h16_fwd_pp.inc: training
+    by default).  Forced to one or the other for BOTH roles (PLNERF_FWD_KERNEL, read once per process), they must
+    produce the same outputs to rounding (they sum in different orders) and -- through the saved half planes and relu
+    bits each writes -- the same parameter gradients; both against the fp32 oracle within the modes' bounds."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "probe.py"
+    script.write_text(_KERNEL_PROBE)
+    res = {}
+    for k in ("rr", "pp"):
+        path = str(tmp_path / f"{k}.pt")
+        env = dict(os.environ, PLNERF_FWD_KERNEL=k)
+        r = subprocess.run([sys.executable, str(script), root, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        res[k] = torch.load(path)
+    sd = orc.closed_form_state_dict(3, True)
+    gen = torch.Generator().manual_seed(5)
+    pts = (torch.rand(37, 101, 3, generator=gen) * 2 - 1) * 2.5
+    vd = torch.nn.functional.normalize(torch.randn(37, 3, generator=gen), dim=-1)
+    ref = orc.query_network(sd, pts, vd)
+    for prec, tol in (("f16x3", 1e-5), ("f16", 2e-3)):
+        for role in ("infer", "train"):
+            a, b = res["rr"][f"{prec}_{role}"], res["pp"][f"{prec}_{role}"]
+            print(f"{prec} {role}: rr vs pp {maxdiff(a, b):.2e}; rr vs oracle {maxdiff(a, ref):.2e}; pp vs oracle {maxdiff(b, ref):.2e}")
+            assert maxdiff(a, ref) <= tol and maxdiff(b, ref) <= tol
+        ga, gb = res["rr"][f"{prec}_grads"], res["pp"][f"{prec}_grads"]
+        cos = float(torch.nn.functional.cosine_similarity(ga.double().reshape(1, -1), gb.double().reshape(1, -1)))
+        rel = float((ga - gb).abs().max() / gb.abs().max())
+        print(f"{prec} gradients: rr vs pp max diff / max|g| {rel:.2e}, cosine {cos:.8f}")
+        if prec == "f16x3":       # same relu branches on both sides (the forward errors are ~1e-6): sharp agreement
+            assert rel <= 2e-3 and cos >= 0.999999
+        else:
+            assert cos >= 0.99

@@ -1,0 +1,14 @@
+#!/bin/bash
+# (Re)compile csrc/mlp_rr.hip with extra flags and link a library variant.
+#   bash tools/build_rr.sh                      -> csrc/mlp_rr.o (the product object), resource report
+#   bash tools/build_rr.sh <name> -DRR_...      -> tools/_head/librr_<name>.so (git-ignored A/B variant)
+R=/root/repo; C=$R/pl-nerf_amd/csrc
+name=$1; shift
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
+if [ -z "$name" ]; then
+  cd $C && /opt/rocm/bin/hipcc $FLAGS -c mlp_rr.hip -o mlp_rr.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "error|warning|ScratchSize|VGPRs Spill|AGPRs:|VGPRs:" | grep -v "Spill: 0\|Size \[bytes/lane\]: 0" | sort | uniq -c
+else
+  mkdir -p /tmp/rr/v $R/tools/_head
+  cd $C && /opt/rocm/bin/hipcc $FLAGS "$@" -c mlp_rr.hip -o /tmp/rr/v/mlp_rr_$name.o 2>&1 | grep -E "error" 
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/_head/librr_$name.so capi.o quad.o sampler.o epilogue.o step.o mlp_api.o mlp_f32.o mlp_bf16.o /tmp/rr/v/mlp_rr_$name.o
+fi
