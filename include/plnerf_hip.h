@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PLNERF_VERSION 220 /* major*10000 + minor*100 + patch */
+#define PLNERF_VERSION 230 /* major*10000 + minor*100 + patch */
 
 /* error codes */
 #define PLNERF_OK 0
@@ -45,9 +45,14 @@ extern "C" {
 #define PLNERF_PREC_BF16 2   /* plain bf16 operands, fp32 accumulate                              */
 #define PLNERF_PREC_F16X3 3  /* 3-term IEEE-half split on v_mfma_f32_32x32x16_f16 (22 bits)        */
 #define PLNERF_PREC_F16 4    /* plain half operands, fp32 accumulate                              */
-/* Range of the half-element modes (3, 4): conversions saturate; activations and weights are represented up to
- * |x| = 131,008 in mode 3 (hi + lo) and 65,504 in mode 4, and clamp silently beyond.  Modes 0-2 carry fp32's
- * exponent range. */
+/* Range of the half-element modes (3, 4): conversions saturate at the IEEE-half maximum, 65,504.  A forward that
+ * meets an activation, or a pack that meets a weight, beyond it sets a bit of the STATUS WORD -- the uint32 at
+ * plnerf_mlp_status_offset(precision) bytes into the packed-weight buffer (sticky: the library only ever ORs into it;
+ * the caller zeroes it when it allocates the buffer and after reading it).  Results computed with a bit set are
+ * clamped, i.e. wrong: re-run in mode 1 (bf16x3) or 0.  plnerf_adam_step can be handed the word and then leaves the
+ * weights untouched while it is non-zero.  Modes 0-2 carry fp32's exponent range and never set it. */
+#define PLNERF_RANGE_ACTIVATION 1u /* an activation beyond +-65,504 was split into halves (forward)  */
+#define PLNERF_RANGE_WEIGHT 2u     /* a weight beyond +-65,504, or not finite, was packed             */
 /* Backward of modes 1-4: the saved activations and the pre-activation gradients are IEEE-half
  * planes, the latter under one power-of-two scale per launch (max |g_raw| -> [8,16), saturating
  * conversion); dgrad chain and weight gradients are single half MFMAs with fp32 accumulation.
@@ -69,6 +74,9 @@ extern "C" {
 typedef void* plnerf_stream_t;
 
 int plnerf_version(void);
+/* 0 for a product build.  Non-zero when the library was compiled with tools-only switches: bit 0 timing ablations
+ * whose results are WRONG by construction, bit 1 timing switches that keep results right, bit 2 trace hooks. */
+int plnerf_build_flags(void);
 const char* plnerf_error_string(int code);
 
 /* ------------------------------------------------------------------------------------
@@ -233,8 +241,10 @@ int plnerf_image_loss(const float* rgb, const float* rgb0, const float* target, 
  * (the host array itself lives in host memory and is read during the call).
  */
 
-/* Size in bytes of the packed-weight buffer for a precision mode. */
+/* Size in bytes of the packed-weight buffer for a precision mode (weight sections + a 16-byte status block). */
 size_t plnerf_mlp_packed_bytes(int precision);
+/* Byte offset of the uint32 range status word inside the packed buffer (see PLNERF_RANGE_*). */
+size_t plnerf_mlp_status_offset(int precision);
 /* Re-layout the 24 parameter tensors into MFMA fragment order (call after every
  * optimizer step; cheap: one pass over 2.4 MB). */
 int plnerf_mlp_pack_weights(const float* const* params, int precision, int input_ch,
@@ -268,10 +278,12 @@ int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, int in
  * Fused Adam step over a flat parameter buffer (torch.optim.Adam semantics as used at
  * run_plnerf.py:446-447, 1302-1303: betas (0.9,0.999), eps 1e-8, no weight decay, no
  * amsgrad).  step >= 1 is the step count AFTER this update. grad_scale multiplies the
- * gradient first (1/world_size after an all-reduce sum). */
+ * gradient first (1/world_size after an all-reduce sum).  skip_if_set (nullable): a device uint32 -- the
+ * status word of the network's packed buffer -- read by the kernel; while it is non-zero the launch changes
+ * nothing (a step whose forward left the half range must not reach the weights). */
 int plnerf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                      int64_t n, float lr, float beta1, float beta2, float eps, int step,
-                     float grad_scale, plnerf_stream_t stream);
+                     float grad_scale, const uint32_t* skip_if_set, plnerf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,7 @@ MODE = {"constant": 0, "linear": 1}
 COLOR = {"midpoint": 0, "left": 1}
 PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3, "f16": 4}
 N_PARAM_TENSORS = 24
+RANGE_ACTIVATION, RANGE_WEIGHT = 1, 2      # bits of the packed buffer's status word (plnerf_hip.h)
 
 c_f = ctypes.c_void_p      # device pointer
 c_i = ctypes.c_int
@@ -25,6 +26,7 @@ c_s = ctypes.c_void_p      # hipStream_t
 # name -> (restype, argtypes); mirrors include/plnerf_hip.h one to one
 SIGNATURES = {
     "plnerf_version": (c_i, []),
+    "plnerf_build_flags": (c_i, []),
     "plnerf_error_string": (ctypes.c_char_p, [c_i]),
     "plnerf_quad_fwd": (c_i, [c_f] * 6 + [c_i] * 6 + [c_f] * 7 + [c_s]),
     "plnerf_quad_bwd": (c_i, [c_f] * 6 + [c_i] * 6 + [c_f] * 7 + [c_s]),
@@ -49,7 +51,8 @@ SIGNATURES = {
     "plnerf_mlp_bwd_workspace_bytes": (ctypes.c_size_t, [c_i, c_i]),
     "plnerf_mlp_fwd": (c_i, [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_s]),
     "plnerf_mlp_bwd": (c_i, [c_f, c_i, c_f, c_i, c_i, c_i, c_f, c_f, ctypes.POINTER(ctypes.c_void_p), c_s]),
-    "plnerf_adam_step": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_int64] + [ctypes.c_float] * 4 + [c_i, ctypes.c_float, c_s]),
+    "plnerf_adam_step": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_int64] + [ctypes.c_float] * 4 + [c_i, ctypes.c_float, c_f, c_s]),
+    "plnerf_mlp_status_offset": (ctypes.c_size_t, [c_i]),
 }
 
 _lib = None
@@ -69,6 +72,13 @@ def lib():
             fn = getattr(handle, name)   # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
+        flags = handle.plnerf_build_flags()
+        if flags and os.environ.get("PLNERF_ALLOW_TOOLS_BUILD") != "1":
+            raise ImportError(
+                f"{LIB_PATH} was built with tools-only switches (plnerf_build_flags() = {flags}: bit 0 = timing "
+                "ablations that make results WRONG, bit 1 = timing switches, bit 2 = trace hooks).  It is not the "
+                "product library: rebuild with `make -C pl-nerf_amd/csrc` (no -D switches), or set "
+                "PLNERF_ALLOW_TOOLS_BUILD=1 for a measurement script under tools/.")
         _lib = handle
     return _lib
 

@@ -13,3 +13,10 @@ extern "C" const char* plnerf_error_string(int code) {
         default: return "unknown plnerf error";
     }
 }
+
+// Build hygiene: the MLP translation units carry timing-experiment switches (PLNERF_ABLATE, RR_ABLATE: results wrong
+// by construction) and trace hooks (PLNERF_TRACE, RR_TRACE) for tools/ builds.  A library built with any of them says
+// so here, and the Python binding refuses to load it as the product (pl-nerf_amd/_lib.py).
+extern "C" int plnerf_build_flags_h16(void);
+extern "C" int plnerf_build_flags_rr(void);
+extern "C" int plnerf_build_flags(void) { return plnerf_build_flags_h16() | plnerf_build_flags_rr(); }

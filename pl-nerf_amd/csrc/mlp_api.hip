@@ -38,12 +38,23 @@ inline int forced_kernel() {      // 0 = default split, 1 = rr, 2 = pp
 inline bool use_rr(const void* saved) { return forced_kernel() == 1 || (forced_kernel() == 0 && !saved); }
 }  // namespace
 
-extern "C" size_t plnerf_mlp_packed_bytes(int precision) {
+// bytes of the weight sections; the 16-byte status block follows them
+inline size_t sections_bytes(int precision) {
     if (precision == PLNERF_PREC_FP32) return impl::f32_packed_bytes();
     if (ns_of(precision))
         return impl::bf16_packed_bytes(ns_of(precision)) + (f16_of(precision) ? impl::rr_packed_bytes(ns_of(precision)) : 0);
     return 0;
 }
+inline unsigned* status_word(void* packed, int precision) {
+    return f16_of(precision) ? (unsigned*)((unsigned char*)packed + sections_bytes(precision)) : nullptr;
+}
+
+extern "C" size_t plnerf_mlp_packed_bytes(int precision) {
+    const size_t n = known(precision) ? sections_bytes(precision) : 0;
+    return n ? n + 16 : 0;
+}
+
+extern "C" size_t plnerf_mlp_status_offset(int precision) { return known(precision) ? sections_bytes(precision) : 0; }
 
 extern "C" int plnerf_mlp_pack_weights(const float* const* params, int precision, int input_ch,
                                        int input_ch_views, void* packed, plnerf_stream_t stream) {
@@ -53,7 +64,7 @@ extern "C" int plnerf_mlp_pack_weights(const float* const* params, int precision
         if (!params[i]) return PLNERF_EINVAL;
     if (precision == PLNERF_PREC_FP32) return impl::f32_pack(params, input_ch, input_ch_views, packed, (hipStream_t)stream);
     const int rc = impl::bf16_pack(params, input_ch, input_ch_views, ns_of(precision), f16_of(precision), packed,
-                                   (hipStream_t)stream);
+                                   status_word(packed, precision), (hipStream_t)stream);
     if (rc || !f16_of(precision)) return rc;
     return impl::rr_pack(params, input_ch, input_ch_views, ns_of(precision),
                          (unsigned char*)packed + impl::bf16_packed_bytes(ns_of(precision)), (hipStream_t)stream);
@@ -90,9 +101,10 @@ extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pt
     if (f16_of(precision) && !embedded && use_rr(saved))
         return impl::rr_fwd(packed, (const unsigned char*)packed + impl::bf16_packed_bytes(ns_of(precision)),
                             ns_of(precision), pts, viewdirs, n_rows, samples_per_ray, raw_out, saved,
-                            (hipStream_t)stream);
+                            status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);
     return impl::bf16_fwd(packed, ns_of(precision), f16_of(precision), pts, viewdirs, embedded, input_ch,
-                          input_ch_views, n_rows, samples_per_ray, raw_out, saved, (hipStream_t)stream);
+                          input_ch_views, n_rows, samples_per_ray, raw_out, saved,
+                          status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);
 }
 
 extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, int input_ch,

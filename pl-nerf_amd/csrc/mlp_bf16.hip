@@ -57,20 +57,22 @@ namespace impl {
 
 size_t bf16_packed_bytes(int ns) { return plnerf_h16_bf16::h16_packed_bytes(ns); }
 
-int bf16_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, int f16, void* packed, hipStream_t st) {
+int bf16_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, int f16, void* packed, unsigned* status,
+              hipStream_t st) {
     // forward section in the mode's element type (ns planes), dgrad section always one half plane: one launch
     // when the forward section is half too, two otherwise
-    if (f16) return plnerf_h16_f16::h16_pack(params, xyz_ch, dir_ch, ns, 3, ns, packed, st);
-    const int rc = plnerf_h16_bf16::h16_pack(params, xyz_ch, dir_ch, ns, 1, ns, packed, st);
-    return rc ? rc : plnerf_h16_f16::h16_pack(params, xyz_ch, dir_ch, 1, 2, ns, packed, st);
+    if (f16) return plnerf_h16_f16::h16_pack(params, xyz_ch, dir_ch, ns, 3, ns, packed, status, st);
+    const int rc = plnerf_h16_bf16::h16_pack(params, xyz_ch, dir_ch, ns, 1, ns, packed, nullptr, st);
+    return rc ? rc : plnerf_h16_f16::h16_pack(params, xyz_ch, dir_ch, 1, 2, ns, packed, status, st);
 }
 
 int bf16_fwd(const void* packed, int ns, int f16, const float* pts, const float* viewdirs, const float* embedded,
-             int xyz_ch, int dir_ch, int n_rows, int samples_per_ray, float* raw_out, void* saved, hipStream_t st) {
+             int xyz_ch, int dir_ch, int n_rows, int samples_per_ray, float* raw_out, void* saved, unsigned* status,
+             hipStream_t st) {
     return f16 ? plnerf_h16_f16::h16_fwd(packed, ns, pts, viewdirs, embedded, xyz_ch, dir_ch, n_rows, samples_per_ray,
-                                         raw_out, saved, st)
+                                         raw_out, saved, status, st)
                : plnerf_h16_bf16::h16_fwd(packed, ns, pts, viewdirs, embedded, xyz_ch, dir_ch, n_rows, samples_per_ray,
-                                          raw_out, saved, st);
+                                          raw_out, saved, nullptr, st);
 }
 
 int bf16_dgrad(const void* packed, int ns, const float* g_raw, int n_rows, const void* saved, void* dz,
@@ -80,6 +82,17 @@ int bf16_dgrad(const void* packed, int ns, const float* g_raw, int n_rows, const
 
 }  // namespace impl
 }  // namespace plnerf
+
+// bit 0: results-wrong ablation switches compiled in; bit 1: results-right timing switches; bit 2: trace hooks
+extern "C" int plnerf_build_flags_h16(void) {
+    int f = 0;
+    if (PLNERF_ABLATE & ~(64 | 128 | 256)) f |= 1;
+    if (PLNERF_ABLATE & (64 | 128 | 256)) f |= 2;
+#ifdef PLNERF_TRACE
+    f |= 4;
+#endif
+    return f;
+}
 
 #ifdef PLNERF_TRACE
 // profiling builds only (tools/trace_fwd.py): phase stamps of workgroup PLNERF_TRACE, bf16 element type

@@ -26,9 +26,11 @@ inline size_t h16_dz_bytes(int n_rows) { return ((size_t)4864 * (size_t)n_rows +
 // 16-bit-operand MFMA modes.  ns = 1: plain operands; ns = 2: 3-term split (hi/lo planes).
 // f16 = 0: bf16 elements; f16 = 1: IEEE half elements.
 size_t bf16_packed_bytes(int ns);
-int bf16_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, int f16, void* packed, hipStream_t st);
+int bf16_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, int f16, void* packed, unsigned* status,
+              hipStream_t st);
 int bf16_fwd(const void* packed, int ns, int f16, const float* pts, const float* viewdirs, const float* embedded,
-             int xyz_ch, int dir_ch, int n_rows, int samples_per_ray, float* raw_out, void* saved, hipStream_t st);
+             int xyz_ch, int dir_ch, int n_rows, int samples_per_ray, float* raw_out, void* saved, unsigned* status,
+             hipStream_t st);
 int bf16_dgrad(const void* packed, int ns, const float* g_raw, int n_rows, const void* saved, void* dz,
                const unsigned* gmax, hipStream_t st);
 
@@ -37,7 +39,7 @@ int bf16_dgrad(const void* packed, int ns, const float* g_raw, int n_rows, const
 size_t rr_packed_bytes(int ns);
 int rr_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, void* section, hipStream_t st);
 int rr_fwd(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs, int n_rows,
-           int samples_per_ray, float* raw_out, void* saved, hipStream_t st);
+           int samples_per_ray, float* raw_out, void* saved, unsigned* status, hipStream_t st);
 
 }  // namespace impl
 }  // namespace plnerf

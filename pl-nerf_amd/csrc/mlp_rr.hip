@@ -200,6 +200,7 @@ struct FwdArgs {
     int n_rows, spr;
     float* raw_out;
     void* saved;
+    unsigned* status;       // range status word of the packed buffer
 };
 
 // ---- LDS-DMA: 64 lanes x 16 B from global memory to LDS at a wave-uniform address, not visible to hipcc's wait
@@ -255,6 +256,7 @@ struct Wave {
     float px, py, pz, dx, dy, dz;   // the row's position and view direction
     f32x16 acc[8];
     float sig, o0, o1, o2;          // head partials
+    float amax;                     // largest activation magnitude split into halves so far (range check)
     unsigned mw[8];                 // relu bit words of the layer in flight (training)
     h16x8 hvf[1];                   // the view layer's half fragment being assembled (training)
     u32x4 stg[4];                   // a staged slab pair on its way from LDS to HBM (training)
@@ -410,6 +412,9 @@ __device__ __forceinline__ void epi_chunk(Wave<NS>& w, const int j, const int c,
     for (int r = 0; r < 2; ++r)      // ReLU and the half range in one v_med3_f32 (a value beyond it would become inf)
         v[r] = (L == 8) ? __builtin_amdgcn_fmed3f(acc[4 * i + r0 + r], -H16_MAX_SPLIT, H16_MAX_SPLIT)
                         : __builtin_amdgcn_fmed3f(acc[4 * i + r0 + r], 0.0f, H16_MAX_SPLIT);
+    // (the clamp above keeps the halves finite; how far the activations really went is remembered for the status word)
+    w.amax = fmaxf(w.amax, fmaxf(fabsf(acc[4 * i + r0]), fabsf(acc[4 * i + r0 + 1])));
+    asm volatile("" : "+v"(w.amax));
     const int f0 = 32 * j + 8 * i + 4 * ln.g + r0;
     if constexpr (L == 7) {          // sigma = w_alpha . relu(h7)
         const f32x2 wa = *reinterpret_cast<const f32x2*>(ln.hd + H_WA + f0);
@@ -653,7 +658,7 @@ __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
             reinterpret_cast<float4*>(hd)[i] = reinterpret_cast<const float4*>(hg)[i];
     }
     Wave<NS> w;
-    w.sig = w.o0 = w.o1 = w.o2 = 0.0f;
+    w.sig = w.o0 = w.o1 = w.o2 = w.amax = 0.0f;
     // ---- this lane's row: position and view direction stay in six registers; the encodings (32 of the 64 xyz
     // channels, 16 of the 32 direction channels per lane) are evaluated where they are consumed -- before L0 and again
     // before the skip layer, before the view layer -- rather than held in 48 registers across the network ----
@@ -726,6 +731,7 @@ __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
     const u32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w.o0), __float_as_uint(w.o0), false, false);
     const u32x2 s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w.o1), __float_as_uint(w.o1), false, false);
     const u32x2 s3 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w.o2), __float_as_uint(w.o2), false, false);
+    if (a.status && !(w.amax <= H16_MAX)) atomicOr(a.status, PLNERF_RANGE_ACTIVATION);   // (rare; sticky until cleared)
     if (ln.g == 0 && ln.rowv) {
         const float sg = (__uint_as_float(s0[0]) + __uint_as_float(s0[1])) + hd[H_BA];
         const float r = (__uint_as_float(s1[0]) + __uint_as_float(s1[1])) + hd[H_BR + 0];
@@ -754,6 +760,14 @@ extern "C" int plnerf_debug_rr_trace(unsigned long long* out8) {
 }
 #endif
 
+extern "C" int plnerf_build_flags_rr(void) {
+    int f = RR_ABLATE ? 1 : 0;
+#ifdef RR_TRACE
+    f |= 4;
+#endif
+    return f;
+}
+
 namespace plnerf {
 namespace impl {
 
@@ -771,8 +785,9 @@ int rr_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, void* se
 }
 
 int rr_fwd(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs, int n_rows,
-           int samples_per_ray, float* raw_out, void* saved, hipStream_t st) {
-    plnerf_rr::FwdArgs a{packed, section, pts, viewdirs, n_rows, samples_per_ray < 1 ? 1 : samples_per_ray, raw_out, saved};
+           int samples_per_ray, float* raw_out, void* saved, unsigned* status, hipStream_t st) {
+    plnerf_rr::FwdArgs a{packed, section, pts, viewdirs, n_rows, samples_per_ray < 1 ? 1 : samples_per_ray, raw_out, saved,
+                         status};
     if (ns == 1) return saved ? plnerf_rr::launch<1, true>(a, st) : plnerf_rr::launch<1, false>(a, st);
     return saved ? plnerf_rr::launch<2, true>(a, st) : plnerf_rr::launch<2, false>(a, st);
 }

@@ -294,8 +294,10 @@ def create_nerf(args, scene_render_params=None, device=None):
         return run_network(inputs, viewdirs, embedded_cam, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
                            bb_center=box[0], bb_scale=box[1], netchunk=getattr(args, "netchunk", 1024 * 64))
     # (optim.FlatAdam on the GPU: one launch per network's gradient buffer)
+    half_range = device.type == "cuda" and getattr(args, "precision", "fp32") in ("f16x3", "f16")
+    extra = {"guards": [n.status_word() for n in (model, model_fine) if n is not None]} if half_range else {}
     optimizer = (FlatAdam if device.type == "cuda" else torch.optim.Adam)(params=grad_vars, lr=args.lrate,
-                                                                           betas=(0.9, 0.999))
+                                                                           betas=(0.9, 0.999), **extra)
     start = 0
     if not getattr(args, "no_reload", True) and os.path.isdir(os.path.join(getattr(args, "ckpt_dir", ""),
                                                                            getattr(args, "expname", ""))):

@@ -155,11 +155,47 @@ class NeRF(nn.Module):
             raise NotImplementedError(f"precision mode {self.precision!r} is not built")
         dev = params[0].device
         flat = [p.detach() for p in params]
-        if self._packed is None or self._packed.device != dev or self._packed.numel() * 4 != nbytes:
-            self._packed = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+        self._ensure_packed(dev, nbytes)
         L.check(L.lib().plnerf_mlp_pack_weights(L.ptr_table(flat), prec, int(self.input_ch), int(self.view_ch),
                                                 L.dptr(self._packed), L.stream()), "plnerf_mlp_pack_weights")
         return self._packed
+
+    def _ensure_packed(self, dev, nbytes):
+        if self._packed is None or self._packed.device != dev or self._packed.numel() * 4 != nbytes:
+            self._packed = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+            self.status_word().zero_()         # the library only ever ORs into it
+
+    def status_word(self):
+        """The packed buffer's range status word as a 1-element int32 tensor (a view: the kernels OR into it).  Half-
+        element modes only set it (include/plnerf_hip.h: PLNERF_RANGE_*); optim.FlatAdam takes it as its guard."""
+        self._require_supported()
+        prec = L.PRECISION[self.precision]
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("plnerf_amd: the range status word lives on the GPU (there is no CPU fallback)")
+        self._ensure_packed(dev, L.lib().plnerf_mlp_packed_bytes(prec))
+        off = L.lib().plnerf_mlp_status_offset(prec) // 4
+        return self._packed.view(torch.int32)[off:off + 1]
+
+    def range_status(self, reset=False):
+        """Bits set since the word was last cleared (synchronises): _lib.RANGE_ACTIVATION -- a forward met an activation
+        beyond the IEEE-half range (the `f16x3` / `f16` modes clamp there: their result is wrong; `bf16x3` carries
+        fp32's exponent range); _lib.RANGE_WEIGHT -- a weight beyond it (or not finite) was packed."""
+        w = self.status_word()
+        bits = int(w.item())
+        if reset and bits:
+            w.zero_()
+        return bits
+
+    def check_range(self):
+        """Raise if a forward of this network left the half range since the last check (and clear the word)."""
+        bits = self.range_status(reset=True)
+        if bits:
+            what = [n for b, n in ((L.RANGE_ACTIVATION, "an activation"), (L.RANGE_WEIGHT, "a weight")) if bits & b]
+            raise FloatingPointError(
+                f"plnerf_amd: {' and '.join(what)} exceeded the IEEE-half range (65,504) in precision={self.precision!r}: "
+                "results since the last check were clamped and the optimizer steps were withheld.  Use "
+                "precision='bf16x3' (fp32 exponent range, same speed) or 'fp32' for this network.")
 
     # -- reference interface --------------------------------------------------------
     def forward(self, x):

@@ -54,8 +54,12 @@ def flat_view_of(tensors):
 
 
 class FlatAdam(torch.optim.Adam):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, guards=None):
+        """guards: optional list of 1-element int32 device tensors (NeRF.status_word()); while any of them is non-zero
+        the step kernels leave parameters and moments untouched (a step whose forward left the half range must not
+        reach the weights; the host finds out at its next NeRF.check_range())."""
         super().__init__(params, lr=lr, betas=betas, eps=eps)
+        self.guards = list(guards or [])
         self._flat = []          # per group: dict(param, m, v, grad, step) or None (torch's own step)
         for group in self.param_groups:
             ps = group['params']
@@ -91,6 +95,18 @@ class FlatAdam(torch.optim.Adam):
                 fv.view(p.shape).copy_(st['exp_avg_sq'])
                 st['exp_avg'], st['exp_avg_sq'] = fm.view(p.shape), fv.view(p.shape)
                 st['step'] = torch.as_tensor(float(st['step']), dtype=torch.float32)
+
+    def _guard_ptr(self, first, last):
+        """One status word can guard a launch.  With several guards (one Adam over both networks, the depth variant)
+        they are OR-ed into a scratch word first."""
+        if not self.guards:
+            return None
+        if len(self.guards) == 1:
+            return L.dptr(self.guards[0], "guard", torch.int32)
+        if getattr(self, "_guard_any", None) is None:
+            self._guard_any = torch.zeros(1, device=self.guards[0].device, dtype=torch.int32)
+        self._guard_any.copy_(torch.stack([g.reshape(()) for g in self.guards]).amax().reshape(1))
+        return L.dptr(self._guard_any, "guard", torch.int32)
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
@@ -141,6 +157,7 @@ class FlatAdam(torch.optim.Adam):
                     L.check(L.lib().plnerf_adam_step(
                         L.dptr(fl['param'][lo:hi]), L.dptr(gview), L.dptr(fl['m'][lo:hi]), L.dptr(fl['v'][lo:hi]),
                         hi - lo, float(group['lr']), float(b1), float(b2), float(group['eps']),
-                        int(steps[0].item()), float(grad_scale), L.stream()), "plnerf_adam_step")
+                        int(steps[0].item()), float(grad_scale), self._guard_ptr(first, last), L.stream()),
+                        "plnerf_adam_step")
                 k = e
         return loss

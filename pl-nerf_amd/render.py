@@ -303,6 +303,9 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
             rgb, disp, acc, _ = render(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
             rgbs.append(rgb.cpu().numpy())
             disps.append(disp.cpu().numpy())
+            for net in (render_kwargs.get('network_fn'), render_kwargs.get('network_fine')):
+                if isinstance(net, NeRF) and net.precision in ("f16x3", "f16") and net.is_supported():
+                    net.check_range()       # (the frame was just synchronised) a clamped frame must not pass silently
     return np.stack(rgbs, 0), np.stack(disps, 0)
 
 
@@ -333,13 +336,19 @@ def create_nerf(args, device=None):
                            netchunk=args.netchunk)
 
     on_gpu = device.type == "cuda"
-    optimizer = (FlatAdam if on_gpu else torch.optim.Adam)(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    half_range = on_gpu and precision in ("f16x3", "f16")      # modes that clamp at the half maximum: guard the steps
+
+    def guard(net):
+        return {"guards": [net.status_word()]} if (half_range and net.is_supported()) else {}
+    optimizer = (FlatAdam if on_gpu else torch.optim.Adam)(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999),
+                                                         **guard(model_fine if model_fine is not None else model))
     # Single-pass configuration (N_importance == 0): the reference builds BOTH Adams over the same (coarse)
     # parameters and steps them one after the other.  A second FlatAdam would re-home the weights into its own flat
     # buffer and orphan the first one's; torch's Adam steps the same views in place, which is the reference's
     # behaviour.
     coarse_adam = FlatAdam if (on_gpu and model_fine is not None) else torch.optim.Adam
-    optimizer_coarse = coarse_adam(params=coarse_vars, lr=args.coarse_lrate, betas=(0.9, 0.999))
+    optimizer_coarse = coarse_adam(params=coarse_vars, lr=args.coarse_lrate, betas=(0.9, 0.999),
+                                   **(guard(model) if coarse_adam is FlatAdam else {}))
 
     start = 0
     candidates = RB.checkpoint_candidates(args)

@@ -111,7 +111,7 @@ class TrainStep:
     renders it or N ranks render a shard each.  `counter_rng=False` restores torch.rand."""
 
     def __init__(self, args, render_kwargs_train, optimizer, optimizer_coarse, start=0, distributed=None, seed=0,
-                 counter_rng=True):
+                 counter_rng=True, range_check_every=100):
         self.args = args
         self.kw = render_kwargs_train
         self.optimizer = optimizer
@@ -122,6 +122,10 @@ class TrainStep:
         self.rank, self.world = (torch.distributed.get_rank(), torch.distributed.get_world_size()) if distributed \
             else (0, 1)
         self.draws = Fn.DrawSource(seed=seed) if counter_rng else None
+        # f16x3 / f16 clamp at the IEEE-half maximum.  The kernels record that in a status word and the guarded Adam
+        # withholds the affected steps; the host looks every `range_check_every` steps (one 4-byte read per network)
+        # and raises.  0 = never look (the caller does).
+        self.range_check_every = int(range_check_every)
         self.seed = seed
         self.bucket = None
         if distributed and self.world > 1:
@@ -196,7 +200,15 @@ class TrainStep:
         for group in self.optimizer_coarse.param_groups:
             group['lr'] = new_lrate                   # sic: the reference uses the fine rate here (line 1315)
         self.global_step += 1
+        if self.range_check_every and self.global_step % self.range_check_every == 0:
+            self.check_range()
         return loss.detach(), psnr
+
+    def check_range(self):
+        for net in self.nets:
+            if getattr(net, "precision", None) in ("f16x3", "f16") and net.is_supported() and \
+                    next(net.parameters()).is_cuda:
+                net.check_range()
 
 
 def save_checkpoint(path, global_step, network_fn, network_fine, optimizer):

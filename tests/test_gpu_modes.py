@@ -379,3 +379,59 @@ def test_register_resident_and_ping_pong_forward_kernels_agree(P, tmp_path):
             assert rel <= 2e-3 and cos >= 0.999999
         else:
             assert cos >= 0.99
+
+
+# ----------------------------------------------------------------------------- range of the half modes
+def test_half_modes_flag_range_overflow_and_withhold_the_step(P):
+    """`f16x3` / `f16` clamp at the IEEE-half maximum (65,504).  A forward that gets there must not pass silently: the
+    kernels set the packed buffer's status word, NeRF.check_range() raises, and the guarded Adam leaves the weights
+    alone for as long as the word is set.  The same network in `bf16x3` / `fp32` (fp32 exponent range) is exact and
+    sets nothing."""
+    from plnerf_amd import _lib
+    sd = orc.closed_form_state_dict(2, False)
+    sd["pts_linears.0.weight"] = sd["pts_linears.0.weight"] * 6.0e4        # weights within the half range, h0 ~ 1e5..1e6 beyond it
+    sd["pts_linears.1.weight"] = sd["pts_linears.1.weight"] * 1.0e-5       # (back to O(1) for the rest of the trunk)
+    assert float(sd["pts_linears.0.weight"].abs().max()) < 65504.0
+    gen = torch.Generator().manual_seed(3)
+    pts = (torch.rand(6, 40, 3, generator=gen) * 2 - 1) * 2.0
+    vd = torch.nn.functional.normalize(torch.randn(6, 3, generator=gen), dim=-1)
+    ref = orc.query_network(sd, pts, vd)
+    for prec, flagged in (("fp32", False), ("bf16x3", False), ("f16x3", True), ("f16", True)):
+        net = make_net(P, sd, prec)
+        for grad in (False, True):          # inference kernel, then the training forward
+            with torch.set_grad_enabled(grad):
+                raw = net.query(g(pts), g(vd))
+            err = maxdiff(raw, ref)
+            bits = net.range_status()
+            print(f"{prec} grad={grad}: err {err:.2e}, status {bits}")
+            assert bool(bits & _lib.RANGE_ACTIVATION) == flagged, (prec, grad, bits)
+            if not flagged:
+                assert err <= 2e-5 * (1.0 + float(ref.abs().max())), (prec, err)
+        if flagged:
+            with pytest.raises(FloatingPointError, match="exceeded the IEEE-half range"):
+                net.check_range()
+            assert net.range_status() == 0                                   # cleared by the check
+        else:
+            net.check_range()
+    # weights beyond the range are caught at packing time
+    sd_w = orc.closed_form_state_dict(2, False)
+    sd_w["feature_linear.weight"][3, 5] = 1.0e5
+    net = make_net(P, sd_w, "f16x3")
+    with torch.no_grad():
+        net.query(g(pts), g(vd))
+    assert net.range_status() & _lib.RANGE_WEIGHT
+    # the guarded optimizer: a step computed from a clamped forward does not reach the weights
+    net = make_net(P, sd, "f16x3")
+    opt = P.FlatAdam(net.parameters(), lr=1e-3, guards=[net.status_word()])
+    before = [p.detach().clone() for p in net.parameters()]
+    (net.query(g(pts), g(vd)) ** 2).sum().backward()
+    opt.step()
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, net.parameters()))
+    assert net.range_status(reset=True) & _lib.RANGE_ACTIVATION
+    net.load_state_dict(orc.closed_form_state_dict(2, False))                # a sane network again: steps apply
+    opt.zero_grad()
+    (net.query(g(pts), g(vd)) ** 2).sum().backward()
+    opt.step()
+    assert net.range_status() == 0
+    sane = list(orc.closed_form_state_dict(2, False).values())
+    assert any(not torch.equal(q, p.detach().cpu()) for q, p in zip(sane, net.parameters()))

@@ -1034,7 +1034,7 @@ def test_fused_adam_matches_torch(P):
         ref.grad = gr * step
         opt.step()
         L.check(L.lib().plnerf_adam_step(L.dptr(p), L.dptr(g(gr * step)), L.dptr(m), L.dptr(v), n, 5e-4, 0.9, 0.999,
-                                         1e-8, step, 1.0, L.stream()), "adam")
+                                         1e-8, step, 1.0, None, L.stream()), "adam")
     assert_close(p, ref.detach(), atol=1e-6, rtol=1e-6, what="adam params")
 
 

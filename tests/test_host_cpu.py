@@ -33,7 +33,9 @@ def test_library_exports_every_declared_symbol(built):
         assert hasattr(handle, name), f"{name} declared in plnerf_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     declared = int(re.search(r"#define\s+PLNERF_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "plnerf_hip.h")).read()).group(1))
-    assert built.library_version() == declared >= 220
+    assert built.library_version() == declared >= 230
+    from plnerf_amd import _lib as _L
+    assert _L.lib().plnerf_build_flags() == 0      # no ablation / trace switches in the product library
     assert _lib.lib().plnerf_error_string(-3).decode().startswith("size outside")
 
 

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLNERF_ALLOW_TOOLS_BUILD=1      # variant libraries carry ablation / trace switches (pl-nerf_amd/_lib.py refuses them otherwise)
 # Same-box A/B of the working tree against a reference copy of the sources: GPU boxes differ by +-3 % in step
 # time, so two variants are only comparable inside one gpurun call, alternating.
 #   (in the build container)  rm -rf tools/_head && mkdir tools/_head && git archive HEAD pl-nerf_amd/csrc include | tar -x -C tools/_head

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLNERF_ALLOW_TOOLS_BUILD=1      # variant libraries carry ablation / trace switches (pl-nerf_amd/_lib.py refuses them otherwise)
 # Same-box A/B of a compile-time definition with a value: DEF="PLNERF_WG_SPLITS=28" bash tools/ab_define.sh
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}

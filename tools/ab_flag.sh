@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLNERF_ALLOW_TOOLS_BUILD=1      # variant libraries carry ablation / trace switches (pl-nerf_amd/_lib.py refuses them otherwise)
 # Same-box A/B of a compile-time flag: builds the working tree twice (with / without -D$FLAG) and alternates.
 #   gpurun -- 'FLAG=PLNERF_NT_WEIGHTS bash tools/ab_flag.sh'
 set -e

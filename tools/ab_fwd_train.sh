@@ -1,6 +1,7 @@
 #!/bin/bash
 # Training-forward launch time (the fine network's SAVE forward inside bench.py's step) per library variant.
 R=${GRAFT_REPO_ROOT:-/root/repo}
+export PLNERF_ALLOW_TOOLS_BUILD=1      # variant libraries carry ablation / trace switches
 for r in 1 2; do
 for lib in pp default $R/tools/_head/lib*.so; do
   unset PLNERF_HIP_LIB PLNERF_FWD_KERNEL

@@ -2,6 +2,7 @@
 # A/B of kernel variants built as separate libraries (tools/_head/lib*.so, git-ignored): the MLP-only benchmark per
 # library, interleaved rounds in one gpurun call.  usage: bash tools/ab_libs.sh "<precisions>" <rounds> [bench_mlp args]
 R=${GRAFT_REPO_ROOT:-/root/repo}
+export PLNERF_ALLOW_TOOLS_BUILD=1      # variant libraries carry ablation / trace switches
 prec=${1:-f16x3}; rounds=${2:-2}; shift 2
 for r in $(seq $rounds); do
   for lib in default $R/tools/_head/lib*.so; do

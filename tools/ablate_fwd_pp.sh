@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLNERF_ALLOW_TOOLS_BUILD=1      # variant libraries carry ablation / trace switches (pl-nerf_amd/_lib.py refuses them otherwise)
 # Timing experiments on the ping-pong forward (results wrong): PLNERF_ABLATE 16 = no LDS operand reads in the
 # ring K loop, 32 = no weight refills from L2, 4 = no epilogue (conversion + LDS stores), 1 = n/a.
 # Prints MLP-only inference throughput at 65536 x 192 per variant.

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PLNERF_ALLOW_TOOLS_BUILD=1      # variant libraries carry ablation / trace switches (pl-nerf_amd/_lib.py refuses them otherwise)
 # Build a trace variant of the library on the GPU box and print the forward kernel's phase breakdown.
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
