@@ -21,11 +21,13 @@ inline bool known(int precision) { return precision >= PLNERF_PREC_FP32 && preci
 inline bool geometry_ok(int input_ch, int input_ch_views) {
     return input_ch >= 1 && input_ch <= lay::PE_K && input_ch_views >= 1 && input_ch_views <= lay::DPE_K;
 }
-// Forward kernels of the half-element modes with the in-kernel encoding.  Inference (no saved state) runs on the
-// register-resident kernel (mlp_rr.hip: +8 % at 65,536 x 192 rows); the training forward on the ping-pong kernel,
-// whose activation tile already sits in LDS in the saved planes' row order (the register-resident kernel has to stage
-// its planes through LDS first and measures 5 % slower there).  PLNERF_FWD_KERNEL=rr | pp forces one kernel for both
-// (A/B measurements, and the test suite's second pass).  Read once.
+// Forward kernels of the half-element modes with the in-kernel encoding.  Split-mode inference (f16x3, no saved
+// state) runs on the register-resident kernel (mlp_rr.hip: +8...10 % at 65,536 x 192 rows).  The training forward
+// stays on the ping-pong kernel, whose activation tile already sits in LDS in the saved planes' row order (the
+// register-resident kernel has to stage its planes through LDS first and measures 5 % slower there), and so does the
+// plain mode (f16: one MFMA per product leaves too few MFMAs to hide the register-resident kernel's side work behind:
+// 1.01 vs 1.08 PFLOP/s).  PLNERF_FWD_KERNEL=rr | pp forces one kernel for everything (A/B measurements, and the
+// test suite's second pass).  Read once.
 inline int forced_kernel() {      // 0 = default split, 1 = rr, 2 = pp
     static const int v = [] {
         const char* e = std::getenv("PLNERF_FWD_KERNEL");
@@ -35,7 +37,9 @@ inline int forced_kernel() {      // 0 = default split, 1 = rr, 2 = pp
     }();
     return v;
 }
-inline bool use_rr(const void* saved) { return forced_kernel() == 1 || (forced_kernel() == 0 && !saved); }
+inline bool use_rr(const void* saved, int ns) {
+    return forced_kernel() == 1 || (forced_kernel() == 0 && !saved && ns == 2);
+}
 }  // namespace
 
 // bytes of the weight sections; the 16-byte status block follows them
@@ -98,7 +102,7 @@ extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pt
     if (precision == PLNERF_PREC_FP32)
         return impl::f32_fwd(packed, pts, viewdirs, embedded, input_ch, input_ch_views, n_rows, samples_per_ray,
                              raw_out, saved, (hipStream_t)stream);
-    if (f16_of(precision) && !embedded && use_rr(saved))
+    if (f16_of(precision) && !embedded && use_rr(saved, ns_of(precision)))
         return impl::rr_fwd(packed, (const unsigned char*)packed + impl::bf16_packed_bytes(ns_of(precision)),
                             ns_of(precision), pts, viewdirs, n_rows, samples_per_ray, raw_out, saved,
                             status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);

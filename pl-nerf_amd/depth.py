@@ -22,7 +22,7 @@ from . import functional as Fn
 from . import raybatch as RB
 from .nerf import Embedder, NeRF
 from .optim import FlatAdam
-from .render import batchify, raw2outputs as _raw2outputs, sample_pdf, sample_pdf_reformulation
+from .render import MAX_ROWS_PER_LAUNCH, batchify, raw2outputs as _raw2outputs, sample_pdf, sample_pdf_reformulation
 
 
 def get_embedder(multires, i=0):
@@ -43,6 +43,11 @@ def run_network(inputs, viewdirs, embedded_cam, fn, embed_fn, embeddirs_fn, bb_c
         per_ray = embeddirs_fn(viewdirs)                              # row-wise encoder: encode once per ray ...
         columns.append(per_ray[:, None, :].expand(R, S, per_ray.shape[-1]).reshape(R * S, -1))   # ... then repeat
         columns.append(embedded_cam.reshape(1, -1).expand(R * S, embedded_cam.shape[0]))
+    # `netchunk` "does not affect final results" (rows are independent): on the HIP MLP the rows go in launches as large
+    # as the saved-activation buffer allows instead of the reference's 65,536-row chunks (a training step would
+    # otherwise pay one forward, one backward and one weight-gradient reduction PER CHUNK)
+    if isinstance(fn, NeRF) and fn.is_supported() and inputs.is_cuda:
+        netchunk = max(int(netchunk), MAX_ROWS_PER_LAUNCH)
     raw = batchify(fn, netchunk)(torch.cat(columns, -1))
     return raw.reshape(*inputs.shape[:-1], raw.shape[-1])
 

@@ -52,6 +52,8 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
     if viewdirs is not None:
         input_dirs = viewdirs[:, None].expand(inputs.shape)
         embedded = torch.cat([embedded, embeddirs_fn(torch.reshape(input_dirs, [-1, input_dirs.shape[-1]]))], -1)
+    if isinstance(fn, NeRF) and fn.is_supported() and embedded.is_cuda:
+        netchunk = max(int(netchunk), MAX_ROWS_PER_LAUNCH)      # rows are independent: fewer, larger launches
     outputs_flat = batchify(fn, netchunk)(embedded)
     return torch.reshape(outputs_flat, list(inputs.shape[:-1]) + [outputs_flat.shape[-1]])
 

@@ -48,6 +48,24 @@ with torch.no_grad():
     zmid = .5 * (z64[..., 1:] + z64[..., :-1])
     wc = rnd(R, 62)
     report("sample_const (B=63, N=128)", timeit(lambda: P.sample_pdf(zmid, wc, N, det=False)), 4 * (2 * 63 + N) + 12 * N)
+    # round 2: the fused step-level kernels (csrc/epilogue.hip, csrc/step.hip)
+    u = rnd(R, N)
+    rays_o3 = rays_o
+    fused = lambda: Fn.CoarseEpilogueFn.apply(raw64, z64, near, far, rays_o3, rays_d, None, u, N, "midpoint", True, False,
+                                              1e-4, 1e-3, None)
+    # in: raw 16 S, z 4 S, u 4 N, near/far/o/d 32; out: maps 28, z_std 4, z_fine 4 (S+N), pts 12 (S+N)
+    report("coarse_epilogue fused (S=64, N=128): quad + sample_pl + clamp + sort + points + z_std",
+           timeit(fused), 20 * 64 + 4 * N + 32 + 32 + 16 * (64 + N))
+    src = Fn.DrawSource(seed=1)
+    fused_rng = lambda: Fn.CoarseEpilogueFn.apply(raw64, z64, near, far, rays_o3, rays_d, None, None, N, "midpoint", True,
+                                                  False, 1e-4, 1e-3, src)
+    report("coarse_epilogue fused, draws in the kernel (S=64, N=128)", timeit(fused_rng), 20 * 64 + 32 + 32 + 16 * (64 + N))
+    report("coarse_samples fused (S=64): stratified z + points, draws in the kernel",
+           timeit(lambda: Fn.coarse_samples(rays_o3, rays_d, near, far, t_vals, None, False, True, src)), 32 + 16 * 64)
+    sep = lambda: (P.raw2outputs(raw64, z64, near, far, rays_d, "linear", "midpoint", white_bkgd=True),
+                   Fn.ray_points(rays_o3, rays_d, Fn.merge_sort(z64, P.sample_pdf_reformulation(z64, w, tau, T, near, far, N, det=False)[0], near, far)))
+    report("the same as separate launches (quad_fwd, rand, sample_pl, merge_sort, ray_points)", timeit(sep),
+           20 * 64 + 4 * N + 32 + 32 + 16 * (64 + N))
 raw.requires_grad_(True)
 res = P.raw2outputs(raw, z, near, far, rays_d, "linear", "midpoint", white_bkgd=True)
 gr = torch.randn_like(res[0])
