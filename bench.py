@@ -43,8 +43,13 @@ PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "f16x3": 2500.0,
 MFMA_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "bf16": 1, "f16x3": 3, "f16": 1}
 DTYPE = {"fp32": "f32", "bf16x3": "bf16x3 (3-term bf16 split, f32 accumulate)", "bf16": "bf16 (f32 accumulate)",
          "f16x3": "f16x3 (3-term f16 split, f32 accumulate)", "f16": "f16 (f32 accumulate)"}
-FWD_KERNEL = {"fp32": "mlp_fwd_f32_kernel<2,true>", "f16x3": "mlp_fwd_pp_kernel<2,true>", "f16": "mlp_fwd_pp_kernel<1,true>",
+FWD_KERNEL = {"fp32": "mlp_fwd_f32_kernel<2,true>", "f16x3": "mlp_fwd_rr_kernel<2,true>", "f16": "mlp_fwd_pp_kernel<1,true>",
               "bf16x3": "mlp_fwd_pp_kernel<2,true>", "bf16": "mlp_fwd_pp_kernel<1,true>"}
+# (PLNERF_FWD_KERNEL=pp in the environment puts f16x3 back on mlp_fwd_pp_kernel<2,true>; the line then names that one)
+if os.environ.get("PLNERF_FWD_KERNEL") == "pp":
+    FWD_KERNEL["f16x3"] = "mlp_fwd_pp_kernel<2,true>"
+elif os.environ.get("PLNERF_FWD_KERNEL") == "rr":
+    FWD_KERNEL["f16"] = "mlp_fwd_rr_kernel<1,true>"
 
 # (N_samples, N_importance, description); every workload is 4096 rays per GPU, mode = linear / midpoint
 WORKLOADS = {

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PLNERF_VERSION 230 /* major*10000 + minor*100 + patch */
+#define PLNERF_VERSION 240 /* major*10000 + minor*100 + patch */
 
 /* error codes */
 #define PLNERF_OK 0
@@ -254,6 +254,11 @@ int plnerf_mlp_pack_weights(const float* const* params, int precision, int input
  * backward scratch (per-layer pre-activation gradients, split-K partial sums). */
 size_t plnerf_mlp_saved_bytes(int n_rows, int precision);
 size_t plnerf_mlp_bwd_workspace_bytes(int n_rows, int precision);
+/* Layout tag of the saved state the forward of this configuration writes (has_embedded: the call passes `embedded`
+ * instead of pts / viewdirs).  Opaque to the caller: hand it to plnerf_mlp_bwd with the saved buffer.  (The half
+ * modes have two forward kernels; one stores its 256-wide planes row-major, the other in 32-row tiles of the MFMA
+ * accumulator layout, which the weight-gradient stage reads directly.) */
+int plnerf_mlp_saved_layout(int precision, int has_embedded);
 
 /* Forward.  Either (pts [n_rows,3] AND viewdirs [n_rows/samples_per_ray, 3]) with
  * embedded == NULL -- the encoding is computed in the kernel prologue, once per sample
@@ -271,7 +276,7 @@ int plnerf_mlp_fwd(const void* packed, int precision, const float* pts, const fl
  * the reference path (they do not depend on parameters; z_samples is detached,
  * run_plnerf.py:728). */
 int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, int input_ch,
-                   int input_ch_views, int n_rows, const void* saved, void* workspace,
+                   int input_ch_views, int n_rows, const void* saved, int saved_layout, void* workspace,
                    float* const* grads, plnerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------

@@ -21,13 +21,12 @@ inline bool known(int precision) { return precision >= PLNERF_PREC_FP32 && preci
 inline bool geometry_ok(int input_ch, int input_ch_views) {
     return input_ch >= 1 && input_ch <= lay::PE_K && input_ch_views >= 1 && input_ch_views <= lay::DPE_K;
 }
-// Forward kernels of the half-element modes with the in-kernel encoding.  Split-mode inference (f16x3, no saved
-// state) runs on the register-resident kernel (mlp_rr.hip: +8...10 % at 65,536 x 192 rows).  The training forward
-// stays on the ping-pong kernel, whose activation tile already sits in LDS in the saved planes' row order (the
-// register-resident kernel has to stage its planes through LDS first and measures 5 % slower there), and so does the
-// plain mode (f16: one MFMA per product leaves too few MFMAs to hide the register-resident kernel's side work behind:
-// 1.01 vs 1.08 PFLOP/s).  PLNERF_FWD_KERNEL=rr | pp forces one kernel for everything (A/B measurements, and the
-// test suite's second pass).  Read once.
+// Forward kernels of the half-element modes with the in-kernel encoding.  The split mode (f16x3) runs on the
+// register-resident kernel (mlp_rr.hip), inference and training; its saved planes leave in the tiled layout of
+// mlp_layout.h, which the weight-gradient stage reads as it is.  The plain mode (f16) stays on the ping-pong kernel:
+// one MFMA per product leaves too few MFMAs to hide the register-resident kernel's side work behind (1.01 vs
+// 1.08 PFLOP/s).  PLNERF_FWD_KERNEL=rr | pp forces one kernel for everything (A/B measurements, and the test
+// suite's second pass).  Read once.
 inline int forced_kernel() {      // 0 = default split, 1 = rr, 2 = pp
     static const int v = [] {
         const char* e = std::getenv("PLNERF_FWD_KERNEL");
@@ -38,7 +37,8 @@ inline int forced_kernel() {      // 0 = default split, 1 = rr, 2 = pp
     return v;
 }
 inline bool use_rr(const void* saved, int ns) {
-    return forced_kernel() == 1 || (forced_kernel() == 0 && !saved && ns == 2);
+    (void)saved;
+    return forced_kernel() == 1 || (forced_kernel() == 0 && ns == 2);
 }
 }  // namespace
 
@@ -78,7 +78,14 @@ extern "C" int plnerf_mlp_pack_weights(const float* const* params, int precision
 extern "C" size_t plnerf_mlp_saved_bytes(int n_rows, int precision) {
     if (!known(precision) || n_rows < 0) return 0;
     if (precision == PLNERF_PREC_FP32) return (size_t)lay::SAVED_PER_ROW * (size_t)n_rows * sizeof(float);
-    return ((size_t)lay::SVH_BYTES_PER_ROW * (size_t)n_rows + 15) & ~(size_t)15;
+    return (size_t)lay::SVH_BYTES_PER_ROW * lay::sv_rows((size_t)n_rows);      // rows padded to whole 32-row tiles
+}
+
+// layout of the 256-wide saved planes the forward of this configuration writes (lay::SV_LAYOUT_*): the backward is
+// told, so that whichever forward kernel ran, the weight-gradient stage reads its planes as they are
+extern "C" int plnerf_mlp_saved_layout(int precision, int has_embedded) {
+    return (f16_of(precision) && !has_embedded && use_rr((const void*)1, ns_of(precision))) ? lay::SV_LAYOUT_TILED
+                                                                                             : lay::SV_LAYOUT_ROWS;
 }
 
 extern "C" size_t plnerf_mlp_bwd_workspace_bytes(int n_rows, int precision) {
@@ -112,8 +119,10 @@ extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pt
 }
 
 extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, int input_ch,
-                              int input_ch_views, int n_rows, const void* saved, void* workspace,
+                              int input_ch_views, int n_rows, const void* saved, int saved_layout, void* workspace,
                               float* const* grads, plnerf_stream_t stream) {
+    if (saved_layout != lay::SV_LAYOUT_ROWS && saved_layout != lay::SV_LAYOUT_TILED) return PLNERF_EINVAL;
+    if (saved_layout == lay::SV_LAYOUT_TILED && !ns_of(precision)) return PLNERF_EINVAL;
     if (!known(precision)) return PLNERF_ENOSYS;
     if (!packed || !g_raw || !saved || !workspace || !grads || n_rows < 1) return PLNERF_EINVAL;
     if (!geometry_ok(input_ch, input_ch_views)) return PLNERF_EINVAL;
@@ -125,7 +134,7 @@ extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_
         const int rc = impl::f32_dgrad(packed, g_raw, n_rows, (const float*)saved, dz, st);
         if (rc) return rc;
         return impl::wgrad(g_raw, n_rows, saved, dz, nullptr, dz + (size_t)lay::DZ_PER_ROW * (size_t)n_rows, grads,
-                           input_ch, input_ch_views, false, st);
+                           input_ch, input_ch_views, false, lay::SV_LAYOUT_ROWS, st);
     }
     // 16-bit modes: [dz half planes][max |g_raw|][partials]
     unsigned char* ws = (unsigned char*)workspace;
@@ -135,5 +144,5 @@ extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_
     if (rc) return rc;
     rc = impl::bf16_dgrad(packed, ns_of(precision), g_raw, n_rows, saved, ws, gmax, st);
     if (rc) return rc;
-    return impl::wgrad(g_raw, n_rows, saved, ws, gmax, partials, grads, input_ch, input_ch_views, true, st);
+    return impl::wgrad(g_raw, n_rows, saved, ws, gmax, partials, grads, input_ch, input_ch_views, true, saved_layout, st);
 }

@@ -492,6 +492,7 @@ struct WJob {
     int lda, ldb, O, I;
     int part_off;     // offset (floats) of this job's [O][I] partial inside a split block
     int bias_off;     // offset of the [O] bias partial, or -1
+    int b_tiled;      // half planes: B is in SV_LAYOUT_TILED (mlp_layout.h) instead of row-major
 };
 constexpr int MAX_WTILES = 20;
 struct WgradArgs {
@@ -612,6 +613,25 @@ __device__ __forceinline__ wh8 tr_frag(const _Float16* plane, int lane, int col0
     return u.v;
 }
 
+// The same fragment from a B stage held in the TILED order (mlp_layout.h: SV_LAYOUT_TILED): the stage's LDS image is
+// [piece block pb = (slab, fragment, lane half)][row of the stage][8 halves] with TRB_PAD halves between blocks (the
+// two lane halves a 16-lane read group touches then sit on different banks); 4 consecutive features of a row are
+// contiguous there too, which is all ds_read_b64_tr_b16 asks for.
+constexpr int TRB_PAD = 32;
+__device__ __forceinline__ wh8 tr_frag_tiled(const _Float16* stage, int srows, int k, int lane, int col0) {
+    const int lam = lane & 15, gam = lane >> 4;
+    const int row = TR_ROWS * k + 8 * (gam >> 1) + (lam >> 2);
+    const int pb = ((col0 >> 5) * 2 + (gam & 1)) * 2 + (lam & 1);          // col = col0 + 16 (gam & 1) + 4 (lam & 3)
+    const _Float16* p = stage + (size_t)pb * (srows * 8 + TRB_PAD) + row * 8 + 4 * ((lam >> 1) & 1);
+    typedef __attribute__((address_space(3))) v4s16* lds_v4;
+    const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)p);
+    const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p + 4 * 8));
+    union { v4s16 h[2]; wh8 v; } u;
+    u.h[0] = lo;
+    u.h[1] = hi;
+    return u.v;
+}
+
 // One body for every job shape.  The thin jobs (256 x 64 encoding columns of L0 / L5, 128 x 32 direction columns
 // of the view layer) run it DEEP: a stage costs its HBM latency whatever its width, and a thin job's stage is only 20-40 KB per CU, so
 // ONE stage ahead left the launch at 3.9 TB/s.  Here two stages are in flight, in two register sets -- which
@@ -620,8 +640,9 @@ __device__ __forceinline__ wh8 tr_frag(const _Float16* plane, int lane, int col0
 // vmcnt(0) and the younger stage's latency is back on the critical path (a first attempt inside the generic
 // kernel measured +-0 for exactly that reason).  O and I are therefore template parameters (slot counts static),
 // rows past the range are loaded from the clamped last row and zeroed by a select.
-template <int O, int I, int NI, bool DEEP>
+template <int O, int I, int NI, bool DEEP, bool TILED = false>
 __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& job, unsigned char* smem_raw) {
+    static_assert(!TILED || I == W, "the tiled layout exists for the 256-wide planes");
     constexpr int NO = 2, WI = 2, KST = TR_STEPS, SROWS = TR_ROWS * KST, SPLANE = SROWS * TR_RS;
     constexpr int A_C8 = O / 8, B_C8 = I / 8;
     constexpr int SA = SROWS * A_C8 / 512;                  // A chunks per thread and stage: 4 (O = 256) or 2
@@ -647,12 +668,17 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
         const int q = tid + 512 * j;
         a_row[j] = q / A_C8; a_col[j] = (q % A_C8) * 8;
     }
-    int b_row[SB], b_col[SB];
+    int b_row[SB], b_col[SB];        // TILED: row of the stage | piece block of the chunk
 #pragma unroll
     for (int j = 0; j < SB; ++j) {
         const int q = tid % B_THREADS + 512 * j;           // (threads past B_THREADS reload a neighbour's chunk, unused)
-        b_row[j] = q / B_C8; b_col[j] = (q % B_C8) * 8;
+        if (TILED) {                                       // chunk q of the stage = tile q / 1024, piece q % 1024
+            b_row[j] = (q >> 10) * 32 + (q & 31); b_col[j] = (q & 1023) >> 5;
+        } else {
+            b_row[j] = q / B_C8; b_col[j] = (q % B_C8) * 8;
+        }
     }
+    const int last_tile = (int)(sv_rows((size_t)a.n_rows) / 32) - 1;
     const bool b_owner = tid < B_THREADS;
     struct Set { wh8 a[SA]; wh8 b[SB]; };
     Set s0, s1;      // (s1 only in the DEEP variant)
@@ -668,8 +694,13 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
         for (int j = 0; j < SA; ++j)
             s.a[j] = *reinterpret_cast<const wh8*>(Ag + (size_t)min(m + a_row[j], last) * O + a_col[j]);
 #pragma unroll
-        for (int j = 0; j < SB; ++j)
-            s.b[j] = *reinterpret_cast<const wh8*>(Bg + (size_t)min(m + b_row[j], last) * I + b_col[j]);
+        for (int j = 0; j < SB; ++j) {
+            if (TILED)      // (m is a multiple of 64: a stage is two whole tiles; a tile past the plane re-reads the last one)
+                s.b[j] = *reinterpret_cast<const wh8*>(
+                    Bg + ((size_t)min((m >> 5) + (b_row[j] >> 5), last_tile) * 1024 + b_col[j] * 32 + (b_row[j] & 31)) * 8);
+            else
+                s.b[j] = *reinterpret_cast<const wh8*>(Bg + (size_t)min(m + b_row[j], last) * I + b_col[j]);
+        }
     };
     auto stash = [&](const Set& s, const int buf, const int m) {
         _Float16* A0 = lds + (size_t)buf * 2 * SPLANE;
@@ -683,8 +714,11 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
         }
         if (b_owner) {
 #pragma unroll
-            for (int j = 0; j < SB; ++j)
-                *reinterpret_cast<wh8*>(B0 + b_row[j] * TR_RS + b_col[j]) = m + b_row[j] < m_end ? s.b[j] : zero8;
+            for (int j = 0; j < SB; ++j) {
+                _Float16* dst = TILED ? B0 + (size_t)b_col[j] * (SROWS * 8 + TRB_PAD) + b_row[j] * 8
+                                      : B0 + b_row[j] * TR_RS + b_col[j];
+                *reinterpret_cast<wh8*>(dst) = m + b_row[j] < m_end ? s.b[j] : zero8;
+            }
         }
     };
     f32x16 acc[NO][NI];
@@ -700,7 +734,8 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
             for (int o = 0; o < NO; ++o) af[o] = tr_frag(A0 + k * TR_PLANE, lane, o_base + 32 * o);
 #pragma unroll
             for (int i = 0; i < NI; ++i) {      // one B fragment live at a time (register budget of the two sets)
-                const wh8 bf = tr_frag(B0 + k * TR_PLANE, lane, i_base + 32 * i);
+                const wh8 bf = TILED ? tr_frag_tiled(B0, SROWS, k, lane, i_base + 32 * i)
+                                     : tr_frag(B0 + k * TR_PLANE, lane, i_base + 32 * i);
 #pragma unroll
                 for (int o = 0; o < NO; ++o)
                     acc[o][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[o], bf, acc[o][i], 0, 0, 0);
@@ -781,8 +816,13 @@ __global__ __launch_bounds__(512) void wgrad_thin_kernel(WgradArgs a) {
 __global__ __launch_bounds__(512) void wgrad_main_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const WJob job = a.jobs[a.tile_job[blockIdx.x]];
-    if (job.O == W) wgrad_half_body<W, W, 4, false>(a, job, smem_raw);
-    else wgrad_half_body<HV, W, 4, false>(a, job, smem_raw);
+    if (job.b_tiled) {      // (uniform per workgroup)
+        if (job.O == W) wgrad_half_body<W, W, 4, false, true>(a, job, smem_raw);
+        else wgrad_half_body<HV, W, 4, false, true>(a, job, smem_raw);
+    } else {
+        if (job.O == W) wgrad_half_body<W, W, 4, false>(a, job, smem_raw);
+        else wgrad_half_body<HV, W, 4, false>(a, job, smem_raw);
+    }
 }
 
 // sigma / rgb heads: dW_alpha = sum_m g_sigma h7, dW_rgb[c] = sum_m g_c hv, and their biases
@@ -793,6 +833,7 @@ struct HeadArgs {
     const PT* hv;
     int n_rows, rows_per_wg;
     float* part;  // [n_wg][HEAD_PART]
+    int tiled;    // half planes in SV_LAYOUT_TILED (rows_per_wg is then a multiple of 32)
 };
 
 template <typename PT>
@@ -810,30 +851,41 @@ __global__ __launch_bounds__(256) void wgrad_head_kernel(HeadArgs<PT> a) {
     const int m_begin = blockIdx.x * a.rows_per_wg;
     const int m_end = min(a.n_rows, m_begin + a.rows_per_wg);
     const float4* g4 = reinterpret_cast<const float4*>(a.g_raw);
+    // Tiled half planes (mlp_layout.h): a 16-byte piece = 8 features {4 g + 0..3, 8 + 4 g + 0..3} + 32 j + 16 f of one row,
+    // 32 rows of a piece block contiguous.  Thread = (piece block, row class): eight lanes read one 128-byte line.
+    const bool tiled = sizeof(PT) == 2 && a.tiled;
     {   // dW_alpha[c] = sum_m g_sigma[m] h7[m][c]
-        const int c = tid % T7, r = tid / T7;
+        const int c = tiled ? tid / R7 : tid % T7, r = tiled ? tid % R7 : tid / T7;
         float w[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) w[e] = 0.0f;
 #pragma unroll 4
         for (int m = m_begin + r; m < m_end; m += R7) {
             const float gs = a.g_raw[4 * (size_t)m + 3];
-            const vec_t h = *reinterpret_cast<const vec_t*>(a.h7 + (size_t)m * W + c * VEC);
+            const PT* src = tiled ? a.h7 + (size_t)(m >> 5) * (32 * W) + ((size_t)c * 32 + (m & 31)) * 8
+                                  : a.h7 + (size_t)m * W + c * VEC;
+            const vec_t h = *reinterpret_cast<const vec_t*>(src);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) w[e] = fmaf(gs, (float)h[e], w[e]);
         }
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) acc7[r][c * VEC + e] = w[e];
+        for (int e = 0; e < VEC; ++e) {
+            // piece block c = (slab, fragment, lane half): features 32 j + 16 f + 4 g + (e & 3) + 8 (e >> 2)
+            const int col = tiled ? 16 * (c >> 1) + 4 * (c & 1) + (e & 3) + 8 * (e >> 2) : c * VEC + e;
+            acc7[r][col] = w[e];
+        }
     }
     {   // dW_rgb[k][c] = sum_m g_k[m] hv[m][c]
-        const int c = tid % TV, r = tid / TV;
+        const int c = tiled ? tid / RV : tid % TV, r = tiled ? tid % RV : tid / TV;
         float w0[VEC], w1[VEC], w2[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { w0[e] = 0.0f; w1[e] = 0.0f; w2[e] = 0.0f; }
 #pragma unroll 4
         for (int m = m_begin + r; m < m_end; m += RV) {
             const float4 g = g4[m];
-            const vec_t h = *reinterpret_cast<const vec_t*>(a.hv + (size_t)m * HV + c * VEC);
+            const PT* src = tiled ? a.hv + (size_t)(m >> 5) * (32 * HV) + ((size_t)c * 32 + (m & 31)) * 8
+                                  : a.hv + (size_t)m * HV + c * VEC;
+            const vec_t h = *reinterpret_cast<const vec_t*>(src);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const float hf = (float)h[e];
@@ -844,9 +896,10 @@ __global__ __launch_bounds__(256) void wgrad_head_kernel(HeadArgs<PT> a) {
         }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            accv[r][0][c * VEC + e] = w0[e];
-            accv[r][1][c * VEC + e] = w1[e];
-            accv[r][2][c * VEC + e] = w2[e];
+            const int col = tiled ? 16 * (c >> 1) + 4 * (c & 1) + (e & 3) + 8 * (e >> 2) : c * VEC + e;
+            accv[r][0][col] = w0[e];
+            accv[r][1][col] = w1[e];
+            accv[r][2][col] = w2[e];
         }
     }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -1072,24 +1125,26 @@ int absmax(const float* x, size_t n, unsigned* out, hipStream_t st) {
 }
 
 int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, const unsigned* gmax, float* part,
-          float* const* grads, int xyz_ch, int dir_ch, bool h16, hipStream_t st) {
+          float* const* grads, int xyz_ch, int dir_ch, bool h16, int saved_layout, hipStream_t st) {
     const size_t N = (size_t)n_rows;
+    const size_t NS_ = h16 ? sv_rows(N) : N;       // row stride of the saved half state (padded, mlp_layout.h)
+    const int tiled = h16 && saved_layout == SV_LAYOUT_TILED;
     const size_t es = h16 ? sizeof(_Float16) : sizeof(float);        // plane element size
     float* head_part = part + (size_t)MAX_SPLITS * PART_PER_SPLIT;
     const int splits = splits_for(n_rows, h16);
     int rps = (n_rows + splits - 1) / splits;
-    rps = (rps + 15) & ~15;
+    rps = h16 ? (rps + 63) & ~63 : (rps + 15) & ~15;      // half kernels: whole 64-row stages (two tiles of the tiled layout)
     int splits_thin = splits;
     if (h16) { splits_thin = (n_rows + 1023) / 1024; splits_thin = splits_thin < 1 ? 1 : (splits_thin > 85 ? 85 : splits_thin); }
     int rps_thin = (n_rows + splits_thin - 1) / splits_thin;
     rps_thin = (rps_thin + 15) & ~15;
     const unsigned char* sv = (const unsigned char*)saved;
     const unsigned char* dz = (const unsigned char*)dzv;
-    auto splane = [&](int p) { return (const void*)(sv + (size_t)p * W * N * es); };
+    auto splane = [&](int p) { return (const void*)(sv + (size_t)p * W * NS_ * es); };
     auto dplane = [&](int p) { return (const void*)(dz + (size_t)p * W * N * es); };
-    const void* hv_plane = sv + (size_t)SV_HV_OFF * N * es;
-    const void* pe_plane = sv + (size_t)SV_PE_OFF * N * es;
-    const void* dpe_plane = sv + (size_t)SV_DPE_OFF * N * es;
+    const void* hv_plane = sv + (size_t)SV_HV_OFF * NS_ * es;
+    const void* pe_plane = sv + (size_t)SV_PE_OFF * NS_ * es;
+    const void* dpe_plane = sv + (size_t)SV_DPE_OFF * NS_ * es;
     const void* dzv_plane = dz + (size_t)DZ_V_OFF * N * es;
     {
         // main: 256 x 256 layer jobs + the view layer's feature columns
@@ -1109,13 +1164,14 @@ int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, co
                 jb.bias_off = PART_BIAS + 8 * W;
             }
             jb.lda = W; jb.ldb = W; jb.O = W; jb.I = W;
+            jb.b_tiled = tiled;
             jb.part_off = PART_MAIN + j * W * W;
             a.tile_job[nt] = j; a.tile_o0[nt++] = 0;
             if (!h16) { a.tile_job[nt] = j; a.tile_o0[nt++] = 128; }   // f32 kernel: 128-row o tiles
         }
         WJob& jv = a.jobs[8];
         jv.A = dzv_plane; jv.lda = HV; jv.B = splane(SV_FEAT); jv.ldb = W; jv.O = HV; jv.I = W;
-        jv.part_off = PART_VMAIN; jv.bias_off = PART_BIAS + 9 * W;
+        jv.part_off = PART_VMAIN; jv.bias_off = PART_BIAS + 9 * W; jv.b_tiled = tiled;
         a.tile_job[nt] = 8; a.tile_o0[nt++] = 0;
         a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
         if (!h16) hipLaunchKernelGGL((wgrad_f32_kernel<2, 2, 2, 4, 4>), dim3(nt, splits), dim3(256), 0, st, a);
@@ -1130,9 +1186,9 @@ int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, co
         // the three thin jobs: encoding columns of L0 / L5 (256 x 64), direction columns of the view layer (128 x 32)
         // (folding them into the main launch as extra tiles measured 1-2 % slower than this second launch)
         WgradArgs a{};
-        a.jobs[0] = WJob{dplane(0), pe_plane, W, PE_K, W, PE_K, PART_PE0, PART_BIAS + 0 * W};
-        a.jobs[1] = WJob{dplane(5), pe_plane, W, PE_K, W, PE_K, PART_PE5, -1};
-        a.jobs[2] = WJob{dzv_plane, dpe_plane, HV, DPE_K, HV, DPE_K, PART_VDIR, -1};
+        a.jobs[0] = WJob{dplane(0), pe_plane, W, PE_K, W, PE_K, PART_PE0, PART_BIAS + 0 * W, 0};
+        a.jobs[1] = WJob{dplane(5), pe_plane, W, PE_K, W, PE_K, PART_PE5, -1, 0};
+        a.jobs[2] = WJob{dzv_plane, dpe_plane, HV, DPE_K, HV, DPE_K, PART_VDIR, -1, 0};
         for (int t = 0; t < 3; ++t) { a.tile_job[t] = t; a.tile_o0[t] = 0; }
         a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
         if (h16) {
@@ -1157,11 +1213,11 @@ int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, co
     const int n_head = head_wgs_for(n_rows);
     if (h16) {
         HeadArgs<_Float16> a{g_raw, (const _Float16*)splane(7), (const _Float16*)hv_plane, n_rows,
-                             (n_rows + n_head - 1) / n_head, head_part};
+                             (((n_rows + n_head - 1) / n_head) + 31) & ~31, head_part, tiled};
         hipLaunchKernelGGL(wgrad_head_kernel<_Float16>, dim3(n_head), dim3(256), 0, st, a);
     } else {
         HeadArgs<float> a{g_raw, (const float*)splane(7), (const float*)hv_plane, n_rows,
-                          (n_rows + n_head - 1) / n_head, head_part};
+                          (n_rows + n_head - 1) / n_head, head_part, 0};
         hipLaunchKernelGGL(wgrad_head_kernel<float>, dim3(n_head), dim3(256), 0, st, a);
     }
     PLNERF_CHECK_LAUNCH();

@@ -7,6 +7,7 @@
 //   view layer (256 feature + 27 direction encoding)->128, relu | rgb 128->3
 // K is padded to a multiple of 8 (one MFMA chunk): encodings 63->64 and 27->32.
 #pragma once
+#include <stddef.h>
 
 namespace plnerf {
 namespace lay {
@@ -96,6 +97,27 @@ constexpr int DZ_PER_ROW = DZ_V_OFF + HV;    // 2432
 // power-of-two scale per launch (max |g_raw| -> [8, 16), 4096x of headroom below the half maximum,
 // conversion saturating); the reduction kernel divides it back out.  Both halve the bytes the
 // backward pass moves through HBM.
+// Rows are padded to a multiple of SV_ROW_PAD in every offset of the half state (plane p starts at
+// plane_off(p) * sv_rows(n_rows)), so that the TILED layout below never runs from one plane into the next.
+//
+// Layouts of the 256-wide planes h0..h7, feature and of hv (128 wide) -- the encoding planes and the relu bits are
+// always row-major:
+//   SV_LAYOUT_ROWS   [row][width]: written by the ping-pong forward (its LDS tile is in this order)
+//   SV_LAYOUT_TILED  32-row tiles in the register-resident forward's own order: tile t = row / 32 holds
+//                    [slab j = col / 32][fragment f][lane half g][row r = row % 32][8 halves], the 8 halves being
+//                    features 32 j + 16 f + 4 g + {0..3} and 32 j + 16 f + 8 + 4 g + {0..3} -- what a lane of the MFMA
+//                    accumulator layout holds, so a wave stores a fragment as ONE contiguous KiB straight from its
+//                    registers.  4 consecutive features of a row stay contiguous, which is all the weight-gradient
+//                    kernel's transposing LDS reads need.
+constexpr int SV_ROW_PAD = 32;
+constexpr int SV_LAYOUT_ROWS = 0, SV_LAYOUT_TILED = 1;
+__host__ __device__ constexpr size_t sv_rows(size_t n_rows) { return (n_rows + SV_ROW_PAD - 1) / SV_ROW_PAD * SV_ROW_PAD; }
+// position (in halves) of element (row, col) of a `width`-wide plane in the tiled layout
+__host__ __device__ constexpr size_t sv_tiled_index(size_t row, int col, int width) {
+    return (row >> 5) * (size_t)(32 * width) +
+           ((size_t)((((col >> 5) * 2 + ((col >> 4) & 1)) * 2 + ((col >> 2) & 1)) * 32) + (row & 31)) * 8 +
+           (size_t)(((col >> 3) & 1) * 4 + (col & 3));
+}
 constexpr int SVH_BYTES_PER_ROW = SV_FLOATS * 2 + SV_MASK_BYTES;   // 5328
 constexpr int DZH_BYTES_PER_ROW = DZ_PER_ROW * 2;                  // 4864
 constexpr int WSH_SCALARS_BYTES = 16;                              // max |g_raw| (fp32 bits) + pad

@@ -18,8 +18,9 @@
 //     that an LDS-DMA ring (global_load_lds_dwordx4, 4 slots x 32 KB) pulls from L2: 128 rows per fetch instead of
 //     64, one barrier per 48 MFMAs whose only job is to hand a landed slot over.
 //   * the sigma and rgb heads are folded into the epilogues that hold their inputs in fp32 registers; the saved
-//     half planes of the training forward leave straight from the registers (v_permlane32_swap pairs the two
-//     lanes of a row so that every store instruction writes 32 contiguous bytes per row).
+//     half planes of the training forward leave straight from the registers, in 32-row tiles of the accumulator
+//     layout (SV_LAYOUT_TILED, mlp_layout.h: one contiguous KiB per store instruction); the weight-gradient
+//     kernels read that layout as it is.
 //
 // Per unit (one 32-feature slab x 16 k-steps in split mode) a wave issues 48 MFMAs, 32 ds_read_b128 of weight
 // fragments shared by all four waves, and the previous slab's ~70 VALU epilogue; HBM sees pts in, raw (and the saved
@@ -259,7 +260,6 @@ struct Wave {
     float amax;                     // largest activation magnitude split into halves so far (range check)
     unsigned mw[8];                 // relu bit words of the layer in flight (training)
     h16x8 hvf[1];                   // the view layer's half fragment being assembled (training)
-    u32x4 stg[4];                   // a staged slab pair on its way from LDS to HBM (training)
 };
 
 // two fp32 values -> one dword (two halves) of the hi plane (+ one of the lo plane) of an operand fragment
@@ -332,7 +332,6 @@ struct Lane {
     int lane, g, wave, trow, grow;      // trow: row within the tile; grow: global row (clamped)
     bool rowv;                          // the row exists
     int wrow0, n_rows;                  // first global row of the wave; rows in the launch
-    unsigned char* stg;                 // the wave's staging tile (training)
     const unsigned char* lds;           // the workgroup's LDS
     const float* hd;                    // head block in LDS
     size_t N;
@@ -361,36 +360,15 @@ __device__ __forceinline__ unsigned char* mask_ptr(const FwdArgs& a, const int p
     return reinterpret_cast<unsigned char*>(a.saved) + (size_t)SV_FLOATS * 2 * N + (size_t)p * (W / 8) * N;
 }
 
-// ---- saved half planes (training): registers -> this wave's LDS staging tile -> HBM in whole 128-byte lines ----
-// A lane holds 8-byte pieces of its row (features {0..3, 8..11} + 4 g of a 16-feature fragment); stored from the
-// registers, one instruction would touch 32 different cache lines with 32 bytes each.  Instead two slabs (64 features
-// = one 128-byte line per row) are collected in a [32 rows][128 B] tile of LDS (rows padded to 144 B), read back as
-// 16-byte pieces in row order, and leave as full lines: 8 lanes per row, 8 rows per store instruction.
-constexpr int STG_ROW = 144;                       // bytes per staged row (128 + 16: 8-byte writes 2-way, reads conflict-free)
-constexpr int STG_BYTES = 32 * STG_ROW;            // per wave
-__device__ __forceinline__ void stage_frag(const h16x8 f, unsigned char* stg, const int slab_parity, const int frag,
-                                           const Lane& ln) {
-    const u32x4 a = __builtin_bit_cast(u32x4, f);
-    unsigned char* p = stg + (ln.lane & 31) * STG_ROW + (32 * slab_parity + 16 * frag + 4 * ln.g) * 2;
-    *reinterpret_cast<u32x2*>(p) = u32x2{a[0], a[1]};
-    *reinterpret_cast<u32x2*>(p + 16) = u32x2{a[2], a[3]};
-}
-__device__ __forceinline__ void stage_read(u32x4 (&r)[4], const unsigned char* stg, const Lane& ln) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int idx = q * 64 + ln.lane;
-        r[q] = *reinterpret_cast<const u32x4*>(stg + (idx >> 3) * STG_ROW + (idx & 7) * 16);
-    }
-}
-// rows wrow0 .. wrow0 + 31 of a plane with `width` halves per row, features feat0 .. feat0 + 63
-__device__ __forceinline__ void stage_flush(const u32x4 (&r)[4], _Float16* plane, const int width, const int feat0,
-                                            const int wrow0, const int n_rows, const Lane& ln) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int idx = q * 64 + ln.lane, row = wrow0 + (idx >> 3);
-        if (row < n_rows && !(RR_ABLATE & 16))
-            *reinterpret_cast<u32x4*>(plane + (size_t)row * width + feat0 + (idx & 7) * 8) = r[q];
-    }
+// ---- saved half planes (training): SV_LAYOUT_TILED (mlp_layout.h) -- a fragment leaves as the wave's registers hold
+// it, one contiguous KiB per store instruction: no transposition, no LDS, two stores per 32-feature slab ----
+__device__ __forceinline__ void store_frag_tiled(const h16x8 f, _Float16* tile, const int width, const int j, const int frag,
+                                                 const Lane& ln) {
+    // (rows past n_rows inside the last tile land in the planes' row padding; a wave whose 32 rows all lie past
+    // n_rows has no tile)
+    if (ln.wrow0 < ln.n_rows && !(RR_ABLATE & 16))
+        *reinterpret_cast<h16x8*>(tile + ((size_t)((j * 2 + frag) * 64 + ln.lane)) * 8) = f;
+    (void)width;
 }
 
 __device__ __forceinline__ unsigned or_halves(const unsigned w) {      // w | (the other lane half's w)
@@ -438,23 +416,14 @@ __device__ __forceinline__ void epi_chunk(Wave<NS>& w, const int j, const int c,
             // relu bits at the lane-half-0 positions; the whole word moves by 4 g once, in the last chunk
             unsigned bits = c == 0 ? 0u : w.mw[j];
             bits |= (v[0] > 0.0f ? 1u << (8 * i + r0) : 0u) | (v[1] > 0.0f ? 1u << (8 * i + r0 + 1) : 0u);
-            if (c == 0 && !(j & 1))      // the slab pair staged before this one leaves: the feature plane's last, or hv's first
-                stage_flush(w.stg, j == 0 ? plane_ptr(a, 8, ln.N) : plane_ptr(a, 0, ln.N) + (size_t)SV_HV_OFF * ln.N,
-                            j == 0 ? W : HV, j == 0 ? W - 64 : 0, ln.wrow0, ln.n_rows, ln);
             put_split<1>(w.hvf, 4 * (i & 1) + r0, v[0], v[1]);
-            if (c % 4 == 3) stage_frag(w.hvf[0], ln.stg, j & 1, i >> 1, ln);
-            if (c == 7 && (j & 1)) stage_read(w.stg, ln.stg, ln);
+            if (c % 4 == 3)
+                store_frag_tiled(w.hvf[0], plane_ptr(a, 0, ln.N) + (size_t)SV_HV_OFF * ln.N + (size_t)ln.wrow0 * HV, HV, j,
+                                 i >> 1, ln);
             w.mw[j] = c == 7 ? or_halves(bits << (4 * ln.g)) : bits;
         }
     }
     if constexpr (L <= 8) {
-        if constexpr (SAVE) {
-            // the slab pair staged before this one leaves for HBM: this layer's slabs j - 2, j - 1, or the previous
-            // layer's last pair (its reads were requested eight chunks ago)
-            if (c == 0 && !(j & 1) && (j > 0 || L > 0))
-                stage_flush(w.stg, plane_ptr(a, j > 0 ? L : L - 1, ln.N), W, j > 0 ? 32 * (j - 2) : W - 64, ln.wrow0,
-                            ln.n_rows, ln);
-        }
         h16x8 (&dst)[NS] = ((L % 2 == 0) ? w.X : w.Y)[2 * j + (i >> 1)];
         put_split<NS>(dst, 4 * (i & 1) + r0, v[0], v[1]);
         if constexpr (SAVE) {
@@ -465,8 +434,7 @@ __device__ __forceinline__ void epi_chunk(Wave<NS>& w, const int j, const int c,
                 bits |= (v[0] > 0.0f ? 1u << (8 * i + r0) : 0u) | (v[1] > 0.0f ? 1u << (8 * i + r0 + 1) : 0u);
                 w.mw[j] = c == 7 ? or_halves(bits << (4 * ln.g)) : bits;
             }
-            if (c % 4 == 3) stage_frag(dst[0], ln.stg, j & 1, i >> 1, ln);
-            if (c == 7 && (j & 1)) stage_read(w.stg, ln.stg, ln);
+            if (c % 4 == 3) store_frag_tiled(dst[0], plane_ptr(a, L, ln.N) + (size_t)ln.wrow0 * W, W, j, i >> 1, ln);
         }
     }
 }
@@ -625,7 +593,7 @@ __device__ __forceinline__ void run_units(Wave<NS>& w, h16x8 (&carry)[PFD][NS], 
     }
 }
 
-constexpr size_t rr_lds_bytes(bool save) { return (size_t)NSLOTS * SLOT_BYTES + HEAD_BYTES + (save ? 4 * STG_BYTES : 0); }
+constexpr size_t rr_lds_bytes(bool) { return (size_t)NSLOTS * SLOT_BYTES + HEAD_BYTES; }
 
 template <int NS, bool SAVE>
 __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
@@ -641,9 +609,8 @@ __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
     ln.trow = wave * 32 + (lane & 31);
     ln.rowv = row0 + ln.trow < a.n_rows;
     ln.grow = min(row0 + ln.trow, a.n_rows - 1);
-    ln.lds = smem; ln.hd = hd; ln.N = (size_t)a.n_rows;
+    ln.lds = smem; ln.hd = hd; ln.N = sv_rows((size_t)a.n_rows);
     ln.wrow0 = row0 + wave * 32; ln.n_rows = a.n_rows;
-    ln.stg = smem + (size_t)NSLOTS * SLOT_BYTES + HEAD_BYTES + (size_t)wave * STG_BYTES;
 
 #ifdef RR_TRACE
     if (blockIdx.x == (RR_TRACE) && tid == 0) { g_rr_trace[0] = clock64(); g_rr_trace[1] = wall_clock64(); }
@@ -719,10 +686,7 @@ __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
         constexpr Unit ld = unit_desc(NS, n_units(NS) - 1);
 #pragma unroll
         for (int c = 0; c < 8 * ld.nj; ++c) epi_chunk<NS, SAVE, ld.layer>(w, ld.j0 + (c >> 3), c & 7, a, ln);
-        if constexpr (SAVE) {
-            store_mask_row<NS, 9>(w, a, ln);
-            stage_flush(w.stg, plane_ptr(a, 0, ln.N) + (size_t)SV_HV_OFF * ln.N, HV, 64, ln.wrow0, ln.n_rows, ln);
-        }
+        if constexpr (SAVE) store_mask_row<NS, 9>(w, a, ln);
     }
 #ifdef RR_TRACE
     if (blockIdx.x == (RR_TRACE) && tid == 0) { g_rr_trace[2] = clock64(); g_rr_trace[3] = wall_clock64(); }

@@ -316,6 +316,7 @@ class MlpFn(torch.autograd.Function):
         if timer is not None:
             ev[1].record()
         ctx.net, ctx.prec, ctx.n_rows = net, prec, n_rows
+        ctx.saved_layout = L.lib().plnerf_mlp_saved_layout(prec, int(emb_c is not None))
         ctx.saved_acts = saved
         ctx.packed = packed
         ctx.param_shapes = [p.shape for p in params]
@@ -344,7 +345,8 @@ class MlpFn(torch.autograd.Function):
             ev[0].record()
         L.check(L.lib().plnerf_mlp_bwd(
             L.dptr(ctx.packed), prec, L.dptr(g, "g_raw"), int(ctx.net.input_ch), int(ctx.net.view_ch), n_rows,
-            L.dptr(ctx.saved_acts), L.dptr(ws), L.ptr_table(grads, "grads"), L.stream()), "plnerf_mlp_bwd")
+            L.dptr(ctx.saved_acts), ctx.saved_layout, L.dptr(ws), L.ptr_table(grads, "grads"), L.stream()),
+            "plnerf_mlp_bwd")
         if timer is not None:
             ev[1].record()
         ctx.saved_acts = None
