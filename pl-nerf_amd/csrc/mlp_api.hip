@@ -22,11 +22,12 @@ inline bool geometry_ok(int input_ch, int input_ch_views) {
     return input_ch >= 1 && input_ch <= lay::PE_K && input_ch_views >= 1 && input_ch_views <= lay::DPE_K;
 }
 // Forward kernels of the half-element modes with the in-kernel encoding.  The split mode (f16x3) runs on the
-// register-resident kernel (mlp_rr.hip), inference and training; its saved planes leave in the tiled layout of
-// mlp_layout.h, which the weight-gradient stage reads as it is.  The plain mode (f16) stays on the ping-pong kernel:
-// one MFMA per product leaves too few MFMAs to hide the register-resident kernel's side work behind (1.01 vs
-// 1.08 PFLOP/s).  PLNERF_FWD_KERNEL=rr | pp forces one kernel for everything (A/B measurements, and the test
-// suite's second pass).  Read once.
+// register-resident kernel (mlp_rr.hip), inference (+8...10 %) and training (-4 % per launch); its saved planes leave
+// in the tiled layout of mlp_layout.h, which the weight-gradient stage reads as it is.  The plain mode (f16) uses it
+// for inference (two row tiles per wave: +12 %) and keeps the ping-pong kernel for the training forward (with one
+// MFMA per product and 512 registers in use, the register-resident kernel's plane stores and relu bits are not
+// hidden: 9.0 vs 8.6 ms forward + backward at 8192 x 192 rows).  PLNERF_FWD_KERNEL=rr | pp forces one kernel for
+// everything (A/B measurements, and the test suite's other passes).  Read once.
 inline int forced_kernel() {      // 0 = default split, 1 = rr, 2 = pp
     static const int v = [] {
         const char* e = std::getenv("PLNERF_FWD_KERNEL");
@@ -37,8 +38,7 @@ inline int forced_kernel() {      // 0 = default split, 1 = rr, 2 = pp
     return v;
 }
 inline bool use_rr(const void* saved, int ns) {
-    (void)saved;
-    return forced_kernel() == 1 || (forced_kernel() == 0 && ns == 2);
+    return forced_kernel() == 1 || (forced_kernel() == 0 && (ns == 2 || !saved));
 }
 }  // namespace
 

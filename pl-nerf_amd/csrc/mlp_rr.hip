@@ -76,7 +76,7 @@ constexpr int H_BIAS = HB_BIAS - HB, H_BF = HB_BF - HB, H_BV = HB_BV - HB, H_WA 
 // largest magnitude the hi + lo pair of halves represents (65504 + 65504 2^-11 ...): activations are clamped to it
 constexpr float H16_MAX_SPLIT = 65504.0f;
 constexpr int RR_THREADS = 256;     // four waves, one per SIMD
-constexpr int RR_ROWS = 128;        // rows per workgroup (32 per wave)
+constexpr int RR_ROWS = 128;        // rows per workgroup and row tile (32 per wave)
 constexpr int SLOT_BYTES = 32768;   // one ring slot = one unit's weight fragments
 constexpr int NSLOTS = 4;
 constexpr int N_LAYERS = 10;        // L0..L7, feature, view layer (= FwdGemm order)
@@ -166,28 +166,32 @@ constexpr int unit_elem_off(int ns, const Unit& d) {                            
 // the first `window` products of unit u after product 0: chunk c right BEFORE the MFMAs of product
 // 1 + c * window / nch.  A chunk writes into k-step 2 j + (i >> 1) of the NEXT layer's operand (behind the 4 encoding
 // k-steps in the skip layer); unit u must not read that k-step earlier.  The window is the widest that respects this.
-constexpr bool epi_window_ok(int ns, int u, int window) {
+// (rt row tiles per wave: the chunks of a slab's rt tiles follow each other, c = (slab q * rt + tile) * 8 + chunk)
+constexpr bool epi_window_ok(int ns, int rt, int u, int window) {
     const Unit d = unit_desc(ns, u), p = unit_desc(ns, u - 1);
-    const int nch = 8 * p.nj;
+    const int nch = 8 * p.nj * rt;
     if (d.layer != p.layer + 1) return true;
     for (int c = 0; c < nch; ++c) {
-        const int tc = 1 + c * window / nch, q = c >> 3, i = (c & 7) >> 1;
+        const int tc = 1 + c * window / nch, q = c / (8 * rt), i = (c & 7) >> 1;
         const int kr = 2 * (p.j0 + q) + (i >> 1) + (d.layer == 5 ? 4 : 0);
         if (kr >= d.k0 && kr < d.k0 + d.nk && (kr - d.k0) * d.nj < tc) return false;
     }
     return true;
 }
-constexpr int epi_window(int ns, int u) {
+constexpr int epi_window(int ns, int rt, int u) {
     const Unit d = unit_desc(ns, u);
     for (int wdw = d.nj * d.nk - 1; wdw >= 1; --wdw)
-        if (epi_window_ok(ns, u, wdw)) return wdw;
+        if (epi_window_ok(ns, rt, u, wdw)) return wdw;
     return 0;
 }
+// row tiles (32 rows each) a wave carries through the network: the split mode's two operand planes leave room for one;
+// the plain mode takes two, so that every weight fragment fetched from LDS feeds two MFMAs
+constexpr int row_tiles(int ns) { return ns == 2 ? 1 : 2; }
 constexpr bool schedule_ok(int ns) {
     for (int u = 0; u < n_units(ns); ++u) {
         const Unit d = unit_desc(ns, u);
         if (unit_pieces(ns, d) * 1024 > SLOT_BYTES || d.nj * d.nk < 8) return false;
-        if (u > 0 && unit_desc(ns, u - 1).last && epi_window(ns, u) < 1) return false;
+        if (u > 0 && unit_desc(ns, u - 1).last && epi_window(ns, row_tiles(ns), u) < 1) return false;
     }
     return true;
 }
@@ -487,15 +491,15 @@ constexpr int PFD = RR_PFD;      // weight fragments requested this many k-step 
 
 // Product T of unit U (every index a compile-time constant: nested loops whose bounds depend on an outer loop's
 // counter are not reliably unrolled, and a rolled one would index the register arrays dynamically).
-template <int NS, bool SAVE, int U, int T>
-__device__ __forceinline__ void run_step(Wave<NS>& w, h16x8 (&af)[PFD + 1][NS], const FwdArgs& a, const Lane& ln,
+template <int NS, int RT, bool SAVE, int U, int T>
+__device__ __forceinline__ void run_step(Wave<NS> (&w)[RT], h16x8 (&af)[PFD + 1][NS], const FwdArgs& a, const Lane (&ln)[RT],
                                          const unsigned lds_base, const unsigned char* lds_lane) {
     constexpr Unit d = unit_desc(NS, U);
     constexpr int L = d.layer, NSTEP = d.nj * d.nk, SP = 1;
     constexpr bool HAS_NEXT = U + 1 < n_units(NS);
     constexpr bool PEND = U > 0 && unit_desc(NS, U > 0 ? U - 1 : 0).last;
     constexpr Unit pd = unit_desc(NS, U > 0 ? U - 1 : 0);
-    constexpr int NCH = PEND ? 8 * pd.nj : 0;
+    constexpr int NCH = PEND ? 8 * pd.nj * RT : 0;
     constexpr int NPC = max_pieces_per_wave<NS>(U + 3);
     constexpr int kk = T / d.nj, sl = T - kk * d.nj;          // (k-step, slab) order: independent accumulators alternate
     if constexpr (T == SP) {
@@ -517,59 +521,66 @@ __device__ __forceinline__ void run_step(Wave<NS>& w, h16x8 (&af)[PFD + 1][NS], 
     }
     if constexpr (PEND && T >= 1 && !(RR_ABLATE & 8)) {
         // the chunks of the pending epilogues that belong to this product: 1 + c * WIN / NCH == T
-        //   <=>  ceil((T - 1) NCH / WIN) <= c < ceil(T NCH / WIN)
-        constexpr int WIN = epi_window(NS, U);
+        //   <=>  ceil((T - 1) NCH / WIN) <= c < ceil(T NCH / WIN);   chunk c = (slab * RT + row tile) * 8 + piece
+        constexpr int WIN = epi_window(NS, RT, U);
         constexpr int c0r = ((T - 1) * NCH + WIN - 1) / WIN, c1r = (T * NCH + WIN - 1) / WIN;
         constexpr int c0 = c0r < NCH ? c0r : NCH, c1 = c1r < NCH ? c1r : NCH;
 #pragma unroll
         for (int c = c0; c < c1; ++c) {
-            epi_chunk<NS, SAVE, pd.layer>(w, pd.j0 + (c >> 3), c & 7, a, ln);
+            const int rt = (c >> 3) % RT, q = c / (8 * RT);
+            epi_chunk<NS, SAVE, pd.layer>(w[rt], pd.j0 + q, c & 7, a, ln[rt]);
             if constexpr (SAVE) {
-                if (c == NCH - 1 && pd.j0 + pd.nj == layer_slabs(pd.layer)) store_mask_row<NS, pd.layer>(w, a, ln);
+                if ((c & 7) == 7 && pd.j0 + q + 1 == layer_slabs(pd.layer)) store_mask_row<NS, pd.layer>(w[rt], a, ln[rt]);
             }
         }
     }
     if constexpr (T > SP && !(RR_ABLATE & 1)) {
         constexpr int q0 = (T - SP - 1) * NPC / (NSTEP - SP - 1), q1 = (T - SP) * NPC / (NSTEP - SP - 1);
 #pragma unroll
-        for (int q = q0; q < q1; ++q) issue_piece<NS, U + 3>(a, lds_base, ln.wave, ln.lane, q);
+        for (int q = q0; q < q1; ++q) issue_piece<NS, U + 3>(a, lds_base, ln[0].wave, ln[0].lane, q);
     }
-    const h16x8 (&bf)[NS] = b_frag<NS, L>(w, d.k0 + kk);
     const h16x8 (&aw)[NS] = af[T % (PFD + 1)];
-    f32x16& acc = w.acc[d.j0 + sl];
-    acc = RR_MFMA(aw[0], bf[0], acc, 0, 0, 0);
-    if constexpr (NS == 2) {
-        acc = RR_MFMA(aw[NS - 1], bf[0], acc, 0, 0, 0);
-        acc = RR_MFMA(aw[0], bf[NS - 1], acc, 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {          // one weight fragment, RT row tiles
+        const h16x8 (&bf)[NS] = b_frag<NS, L>(w[rt], d.k0 + kk);
+        f32x16& acc = w[rt].acc[d.j0 + sl];
+        acc = RR_MFMA(aw[0], bf[0], acc, 0, 0, 0);
+        if constexpr (NS == 2) {
+            acc = RR_MFMA(aw[NS - 1], bf[0], acc, 0, 0, 0);
+            acc = RR_MFMA(aw[0], bf[NS - 1], acc, 0, 0, 0);
+        }
     }
     // keep this order: the scheduler otherwise hoists every LDS read of the region to its top and spills
     if constexpr (RR_SCHED == 1) __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NS, bool SAVE, int U, int... Ts>
-__device__ __forceinline__ void run_steps(Wave<NS>& w, h16x8 (&af)[PFD + 1][NS], const FwdArgs& a, const Lane& ln,
+template <int NS, int RT, bool SAVE, int U, int... Ts>
+__device__ __forceinline__ void run_steps(Wave<NS> (&w)[RT], h16x8 (&af)[PFD + 1][NS], const FwdArgs& a, const Lane (&ln)[RT],
                                           const unsigned lds_base, const unsigned char* lds_lane,
                                           std::integer_sequence<int, Ts...>) {
-    (run_step<NS, SAVE, U, Ts>(w, af, a, ln, lds_base, lds_lane), ...);
+    (run_step<NS, RT, SAVE, U, Ts>(w, af, a, ln, lds_base, lds_lane), ...);
 }
 
-// Unit U: its k-step products in (k-step, slab) order.  The weight fragments of the first PFD products arrive in
-// `carry` (requested by the previous unit); the last PFD products request the next unit's.  The sync point after the
-// first product hands the NEXT unit's slot over: every wave waits for its own DMA pieces of unit U + 1, the barrier
-// makes all pieces visible (and proves that every wave has left unit U - 1, whose slot unit U + 3 may now overwrite).
-// Side work dealt out over the products: the pending epilogues (the slabs completed by the previous unit, eight chunks
-// each), the DMA pieces of unit U + 3.
-template <int NS, bool SAVE, int U>
-__device__ __forceinline__ void run_unit(Wave<NS>& w, h16x8 (&carry)[PFD][NS], const FwdArgs& a, const Lane& ln,
+// Unit U: its k-step products in (k-step, slab) order, each on the wave's RT row tiles.  The weight fragments of the
+// first PFD products arrive in `carry` (requested by the previous unit); the last PFD products request the next unit's.
+// The sync point after the first product hands the NEXT unit's slot over: every wave waits for its own DMA pieces of
+// unit U + 1, the barrier makes all pieces visible (and proves that every wave has left unit U - 1, whose slot unit
+// U + 3 may now overwrite).  Side work dealt out over the products: the pending epilogues (the slabs completed by the
+// previous unit, eight chunks per slab and row tile), the DMA pieces of unit U + 3.
+template <int NS, int RT, bool SAVE, int U>
+__device__ __forceinline__ void run_unit(Wave<NS> (&w)[RT], h16x8 (&carry)[PFD][NS], const FwdArgs& a, const Lane (&ln)[RT],
                                          const unsigned lds_base) {
     constexpr Unit d = unit_desc(NS, U);
     constexpr int L = d.layer, NSTEP = d.nj * d.nk;
-    const unsigned char* lds_lane = ln.lds + ln.lane * 16;
-    if constexpr (d.first && d.j0 == 0 && L == 5) encode_xyz<NS>(w, ln);
-    if constexpr (d.first && d.j0 == 0 && L == 9) encode_dir<NS>(w, ln);
-    if constexpr (d.first) {
+    const unsigned char* lds_lane = ln[0].lds + ln[0].lane * 16;
 #pragma unroll
-        for (int sl = 0; sl < d.nj; ++sl) init_acc<NS, L>(w, d.j0 + sl, ln);
+    for (int rt = 0; rt < RT; ++rt) {
+        if constexpr (d.first && d.j0 == 0 && L == 5) encode_xyz<NS>(w[rt], ln[rt]);
+        if constexpr (d.first && d.j0 == 0 && L == 9) encode_dir<NS>(w[rt], ln[rt]);
+        if constexpr (d.first) {
+#pragma unroll
+            for (int sl = 0; sl < d.nj; ++sl) init_acc<NS, L>(w[rt], d.j0 + sl, ln[rt]);
+        }
     }
     h16x8 af[PFD + 1][NS];
 #pragma unroll
@@ -577,41 +588,44 @@ __device__ __forceinline__ void run_unit(Wave<NS>& w, h16x8 (&carry)[PFD][NS], c
 #pragma unroll
         for (int s = 0; s < NS; ++s) af[p][s] = carry[p][s];
     __builtin_amdgcn_sched_barrier(0);
-    run_steps<NS, SAVE, U>(w, af, a, ln, lds_base, lds_lane, std::make_integer_sequence<int, NSTEP>{});
+    run_steps<NS, RT, SAVE, U>(w, af, a, ln, lds_base, lds_lane, std::make_integer_sequence<int, NSTEP>{});
 #pragma unroll
     for (int p = 0; p < PFD; ++p)
 #pragma unroll
         for (int s = 0; s < NS; ++s) carry[p][s] = af[(NSTEP + p) % (PFD + 1)][s];
 }
 
-template <int NS, bool SAVE, int U>
-__device__ __forceinline__ void run_units(Wave<NS>& w, h16x8 (&carry)[PFD][NS], const FwdArgs& a, const Lane& ln,
+template <int NS, int RT, bool SAVE, int U>
+__device__ __forceinline__ void run_units(Wave<NS> (&w)[RT], h16x8 (&carry)[PFD][NS], const FwdArgs& a, const Lane (&ln)[RT],
                                           const unsigned lds_base) {
     if constexpr (U < n_units(NS)) {
-        run_unit<NS, SAVE, U>(w, carry, a, ln, lds_base);
-        run_units<NS, SAVE, U + 1>(w, carry, a, ln, lds_base);
+        run_unit<NS, RT, SAVE, U>(w, carry, a, ln, lds_base);
+        run_units<NS, RT, SAVE, U + 1>(w, carry, a, ln, lds_base);
     }
 }
 
-constexpr size_t rr_lds_bytes(bool) { return (size_t)NSLOTS * SLOT_BYTES + HEAD_BYTES; }
+constexpr size_t rr_lds_bytes() { return (size_t)NSLOTS * SLOT_BYTES + HEAD_BYTES; }
 
 template <int NS, bool SAVE>
 __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
+    constexpr int RT = row_tiles(NS);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_byte*)smem;
     float* hd = reinterpret_cast<float*>(smem + (size_t)NSLOTS * SLOT_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = blockIdx.x * RR_ROWS;
-    Lane ln;
-    ln.lane = lane; ln.g = lane >> 5; ln.wave = wave;
-    ln.trow = wave * 32 + (lane & 31);
-    ln.rowv = row0 + ln.trow < a.n_rows;
-    ln.grow = min(row0 + ln.trow, a.n_rows - 1);
-    ln.lds = smem; ln.hd = hd; ln.N = sv_rows((size_t)a.n_rows);
-    ln.wrow0 = row0 + wave * 32; ln.n_rows = a.n_rows;
-
+    const int row0 = blockIdx.x * (RR_ROWS * RT);
+    Lane ln[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        ln[rt].lane = lane; ln[rt].g = lane >> 5; ln[rt].wave = wave;
+        ln[rt].trow = (wave * RT + rt) * 32 + (lane & 31);
+        ln[rt].rowv = row0 + ln[rt].trow < a.n_rows;
+        ln[rt].grow = min(row0 + ln[rt].trow, a.n_rows - 1);
+        ln[rt].lds = smem; ln[rt].hd = hd; ln[rt].N = sv_rows((size_t)a.n_rows);
+        ln[rt].wrow0 = row0 + (wave * RT + rt) * 32; ln[rt].n_rows = a.n_rows;
+    }
 #ifdef RR_TRACE
     if (blockIdx.x == (RR_TRACE) && tid == 0) { g_rr_trace[0] = clock64(); g_rr_trace[1] = wall_clock64(); }
 #endif
@@ -624,51 +638,57 @@ __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
         for (int i = tid; i < HEAD_FLOATS / 4; i += RR_THREADS)
             reinterpret_cast<float4*>(hd)[i] = reinterpret_cast<const float4*>(hg)[i];
     }
-    Wave<NS> w;
-    w.sig = w.o0 = w.o1 = w.o2 = w.amax = 0.0f;
-    // ---- this lane's row: position and view direction stay in six registers; the encodings (32 of the 64 xyz
-    // channels, 16 of the 32 direction channels per lane) are evaluated where they are consumed -- before L0 and again
-    // before the skip layer, before the view layer -- rather than held in 48 registers across the network ----
-    w.px = a.pts[3 * (size_t)ln.grow]; w.py = a.pts[3 * (size_t)ln.grow + 1]; w.pz = a.pts[3 * (size_t)ln.grow + 2];
-    {
-        const size_t ray = (size_t)(ln.grow / a.spr);
-        w.dx = a.viewdirs[3 * ray]; w.dy = a.viewdirs[3 * ray + 1]; w.dz = a.viewdirs[3 * ray + 2];
-    }
-    encode_xyz<NS>(w, ln);
-    if constexpr (SAVE) {
-        // saved encoding planes, original channel order: through this wave's corner of ring slot 3 (unused until
-        // unit 3's weights arrive, which the sync point of unit 0 -- after every wave's prologue -- requests)
-        float v[32], u[16];
-        xyz_values(w.px, w.py, w.pz, ln.g, v);
-        dir_values(w.dx, w.dy, w.dz, ln.g, u);
-        _Float16* st = reinterpret_cast<_Float16*>(smem + 3 * SLOT_BYTES) + (size_t)wave * 32 * (PE_K + DPE_K);
-        _Float16* prow = st + (size_t)(lane & 31) * (PE_K + DPE_K);
+    Wave<NS> w[RT];
 #pragma unroll
-        for (int t = 0; t < 32; ++t) prow[rr_pe_channel(ln.g, t)] = (_Float16)v[t];
-#pragma unroll
-        for (int t = 0; t < 16; ++t) prow[PE_K + rr_dpe_channel(ln.g, t)] = (_Float16)u[t];   // (pad slots: zeros)
-        if (ln.g) {
-#pragma unroll
-            for (int c = DIR_CH; c < DPE_K - 1; ++c) prow[PE_K + c] = (_Float16)0.0f;      // channels no slot maps to
+    for (int rt = 0; rt < RT; ++rt) {
+        Wave<NS>& wt = w[rt];
+        const Lane& lt = ln[rt];
+        wt.sig = wt.o0 = wt.o1 = wt.o2 = wt.amax = 0.0f;
+        // ---- this lane's row: position and view direction stay in six registers; the encodings (32 of the 64 xyz
+        // channels, 16 of the 32 direction channels per lane) are evaluated where they are consumed -- before L0 and
+        // again before the skip layer, before the view layer -- rather than held in 48 registers across the network ----
+        wt.px = a.pts[3 * (size_t)lt.grow]; wt.py = a.pts[3 * (size_t)lt.grow + 1]; wt.pz = a.pts[3 * (size_t)lt.grow + 2];
+        {
+            const size_t ray = (size_t)(lt.grow / a.spr);
+            wt.dx = a.viewdirs[3 * ray]; wt.dy = a.viewdirs[3 * ray + 1]; wt.dz = a.viewdirs[3 * ray + 2];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        _Float16* pe_plane = plane_ptr(a, 0, ln.N) + (size_t)SV_PE_OFF * ln.N;
-        _Float16* dpe_plane = plane_ptr(a, 0, ln.N) + (size_t)SV_DPE_OFF * ln.N;
-        const int wrow0 = row0 + wave * 32;
+        encode_xyz<NS>(wt, lt);
+        if constexpr (SAVE) {
+            // saved encoding planes, original channel order: through this wave's corner of ring slot 3 (unused until
+            // unit 3's weights arrive, which the sync point of unit 0 -- after every wave's prologue -- requests); the
+            // wave's row tiles take turns (LDS operations of one wave execute in order)
+            float v[32], u[16];
+            xyz_values(wt.px, wt.py, wt.pz, lt.g, v);
+            dir_values(wt.dx, wt.dy, wt.dz, lt.g, u);
+            _Float16* st = reinterpret_cast<_Float16*>(smem + 3 * SLOT_BYTES) + (size_t)wave * 32 * (PE_K + DPE_K);
+            _Float16* prow = st + (size_t)(lane & 31) * (PE_K + DPE_K);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {            // 32 rows x 8 pieces of 16 B
-            const int idx = q * 64 + lane, r = idx >> 3, c = idx & 7;
-            if (wrow0 + r < a.n_rows)
-                *reinterpret_cast<u32x4*>(pe_plane + (size_t)(wrow0 + r) * PE_K + 8 * c) =
-                    *reinterpret_cast<const u32x4*>(st + (size_t)r * (PE_K + DPE_K) + 8 * c);
-        }
+            for (int t = 0; t < 32; ++t) prow[rr_pe_channel(lt.g, t)] = (_Float16)v[t];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {            // 32 rows x 4 pieces
-            const int idx = q * 64 + lane, r = idx >> 2, c = idx & 3;
-            if (wrow0 + r < a.n_rows)
-                *reinterpret_cast<u32x4*>(dpe_plane + (size_t)(wrow0 + r) * DPE_K + 8 * c) =
-                    *reinterpret_cast<const u32x4*>(st + (size_t)r * (PE_K + DPE_K) + PE_K + 8 * c);
+            for (int t = 0; t < 16; ++t) prow[PE_K + rr_dpe_channel(lt.g, t)] = (_Float16)u[t];   // (pad slots: zeros)
+            if (lt.g) {
+#pragma unroll
+                for (int c = DIR_CH; c < DPE_K - 1; ++c) prow[PE_K + c] = (_Float16)0.0f;      // channels no slot maps to
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            _Float16* pe_plane = plane_ptr(a, 0, lt.N) + (size_t)SV_PE_OFF * lt.N;
+            _Float16* dpe_plane = plane_ptr(a, 0, lt.N) + (size_t)SV_DPE_OFF * lt.N;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {            // 32 rows x 8 pieces of 16 B
+                const int idx = q * 64 + lane, r = idx >> 3, c = idx & 7;
+                if (lt.wrow0 + r < a.n_rows)
+                    *reinterpret_cast<u32x4*>(pe_plane + (size_t)(lt.wrow0 + r) * PE_K + 8 * c) =
+                        *reinterpret_cast<const u32x4*>(st + (size_t)r * (PE_K + DPE_K) + 8 * c);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {            // 32 rows x 4 pieces
+                const int idx = q * 64 + lane, r = idx >> 2, c = idx & 3;
+                if (lt.wrow0 + r < a.n_rows)
+                    *reinterpret_cast<u32x4*>(dpe_plane + (size_t)(lt.wrow0 + r) * DPE_K + 8 * c) =
+                        *reinterpret_cast<const u32x4*>(st + (size_t)r * (PE_K + DPE_K) + PE_K + 8 * c);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
     // unit 0's weights and the head block are in place for everyone
@@ -680,37 +700,44 @@ __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
 #pragma unroll
         for (int p = 0; p < PFD; ++p) load_a<NS>(carry[p], smem + lane * 16, 0, d0.nk, p % d0.nj, p / d0.nj);
     }
-    run_units<NS, SAVE, 0>(w, carry, a, ln, lds_base);
+    run_units<NS, RT, SAVE, 0>(w, carry, a, ln, lds_base);
     // the last unit's slab epilogues (view layer) and the heads
-    {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
         constexpr Unit ld = unit_desc(NS, n_units(NS) - 1);
 #pragma unroll
-        for (int c = 0; c < 8 * ld.nj; ++c) epi_chunk<NS, SAVE, ld.layer>(w, ld.j0 + (c >> 3), c & 7, a, ln);
-        if constexpr (SAVE) store_mask_row<NS, 9>(w, a, ln);
+        for (int c = 0; c < 8 * ld.nj; ++c) epi_chunk<NS, SAVE, ld.layer>(w[rt], ld.j0 + (c >> 3), c & 7, a, ln[rt]);
+        if constexpr (SAVE) store_mask_row<NS, 9>(w[rt], a, ln[rt]);
     }
 #ifdef RR_TRACE
     if (blockIdx.x == (RR_TRACE) && tid == 0) { g_rr_trace[2] = clock64(); g_rr_trace[3] = wall_clock64(); }
 #endif
-    const u32x2 s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w.sig), __float_as_uint(w.sig), false, false);
-    const u32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w.o0), __float_as_uint(w.o0), false, false);
-    const u32x2 s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w.o1), __float_as_uint(w.o1), false, false);
-    const u32x2 s3 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w.o2), __float_as_uint(w.o2), false, false);
-    if (a.status && !(w.amax <= H16_MAX)) atomicOr(a.status, PLNERF_RANGE_ACTIVATION);   // (rare; sticky until cleared)
-    if (ln.g == 0 && ln.rowv) {
-        const float sg = (__uint_as_float(s0[0]) + __uint_as_float(s0[1])) + hd[H_BA];
-        const float r = (__uint_as_float(s1[0]) + __uint_as_float(s1[1])) + hd[H_BR + 0];
-        const float g = (__uint_as_float(s2[0]) + __uint_as_float(s2[1])) + hd[H_BR + 1];
-        const float b = (__uint_as_float(s3[0]) + __uint_as_float(s3[1])) + hd[H_BR + 2];
-        reinterpret_cast<float4*>(a.raw_out)[row0 + ln.trow] = make_float4(r, g, b, sg);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const Wave<NS>& wt = w[rt];
+        const Lane& lt = ln[rt];
+        const u32x2 s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(wt.sig), __float_as_uint(wt.sig), false, false);
+        const u32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(wt.o0), __float_as_uint(wt.o0), false, false);
+        const u32x2 s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(wt.o1), __float_as_uint(wt.o1), false, false);
+        const u32x2 s3 = __builtin_amdgcn_permlane32_swap(__float_as_uint(wt.o2), __float_as_uint(wt.o2), false, false);
+        if (a.status && !(wt.amax <= H16_MAX)) atomicOr(a.status, PLNERF_RANGE_ACTIVATION);   // (rare; sticky until cleared)
+        if (lt.g == 0 && lt.rowv) {
+            const float sg = (__uint_as_float(s0[0]) + __uint_as_float(s0[1])) + hd[H_BA];
+            const float r = (__uint_as_float(s1[0]) + __uint_as_float(s1[1])) + hd[H_BR + 0];
+            const float g = (__uint_as_float(s2[0]) + __uint_as_float(s2[1])) + hd[H_BR + 1];
+            const float b = (__uint_as_float(s3[0]) + __uint_as_float(s3[1])) + hd[H_BR + 2];
+            reinterpret_cast<float4*>(a.raw_out)[row0 + lt.trow] = make_float4(r, g, b, sg);
+        }
     }
 }
 
 template <int NS, bool SAVE>
 int launch(const FwdArgs& a, hipStream_t st) {
-    const size_t lds = rr_lds_bytes(SAVE);
+    const size_t lds = rr_lds_bytes();
+    constexpr int ROWS = RR_ROWS * row_tiles(NS);
     (void)hipFuncSetAttribute((const void*)mlp_fwd_rr_kernel<NS, SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-    hipLaunchKernelGGL((mlp_fwd_rr_kernel<NS, SAVE>), dim3((a.n_rows + RR_ROWS - 1) / RR_ROWS), dim3(RR_THREADS), lds, st, a);
+    hipLaunchKernelGGL((mlp_fwd_rr_kernel<NS, SAVE>), dim3((a.n_rows + ROWS - 1) / ROWS), dim3(RR_THREADS), lds, st, a);
     PLNERF_CHECK_LAUNCH();
     return PLNERF_OK;
 }
