@@ -247,3 +247,80 @@ def test_train_step_from_a_view(P):
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
     for p, q in zip(kw["network_fine"].parameters(), kw2["network_fine"].parameters()):
         assert maxdiff(p, q) <= 3e-4      # (six Adam steps apart: the two routes normalise view directions differently)
+
+
+# ----------------------------------------------------------------------------- data parallel step, two ranks on one GPU
+_DP_GPU_WORKER = r'''
+import os, sys, tempfile, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import plnerf_amd as P
+from plnerf_amd import dp
+from oracle import plnerf_oracle as orc
+from test_gpu_step import _args
+rank, world, _ = dp.init_from_env(backend="gloo")          # both ranks on cuda:0; gloo moves CUDA tensors through the host
+dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+
+
+def make(distributed):
+    d = tempfile.mkdtemp(); os.makedirs(os.path.join(d, "exp"))
+    args = _args(d, "f16x3")
+    kw, _, _, _, opt, opt_c = P.create_nerf(args, device=dev)
+    kw["network_fn"].load_state_dict(orc.closed_form_state_dict(0, False))
+    kw["network_fine"].load_state_dict(orc.closed_form_state_dict(1, False))
+    return kw, P.TrainStep(args, kw, opt, opt_c, distributed=distributed, seed=3)
+
+
+H = W = 64
+K = [[90.0, 0, W / 2], [0, 90.0, H / 2], [0, 0, 1]]
+c2w = P.rays.pose_spherical(20.0, -30.0, 4.0)[:3, :4]
+yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+image = torch.stack([xx, yy, 0.5 * (xx + yy)], -1).to(dev)
+kw, ts = make(True)
+assert ts.bucket is not None and ts.world == 2
+losses = []
+for step in range(3):
+    loss, _ = ts.step_view(H, W, K, c2w, image, near=2.0, far=6.0, n_rand=128)       # 128 rays per rank, 256 global
+    assert ts.bucket.pending() == 0
+    losses.append(float(loss))
+digest = [float(p.detach().double().sum()) for n in ts.nets for p in n.parameters()]
+gathered = [None] * world
+dist.all_gather_object(gathered, digest)
+assert gathered[0] == gathered[1], "replicas diverged"
+if rank == 0:
+    # the same three steps as ONE process over the global batch of 256 rays (same seed: same pixels, same draws)
+    kw1, ts1 = make(False)
+    for step in range(3):
+        ts1.step_view(H, W, K, c2w, image, near=2.0, far=6.0, n_rand=256)
+    worst = max(float((p.detach() - q.detach()).abs().max()) for n, m in zip(ts.nets, ts1.nets)
+                for p, q in zip(n.parameters(), m.parameters()))
+    print("max |param(2 ranks) - param(1 rank, global batch)| =", worst)
+    assert worst <= 2e-4, worst          # three Adam steps (lr 5e-4) apart at most through rounding-level gradient differences
+print(f"rank {rank} ok")
+dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_training_step_two_ranks_on_one_gpu(P, tmp_path):
+    """The multi-GPU step as the driver will launch it, minus the second GPU: two ranks (gloo backend, both on cuda:0)
+    each render their shard of a global batch chosen by the counter-based generator, the post-accumulate hooks enqueue
+    one in-place all-reduce per network from inside backward, the guarded flat Adam steps.  Replicas stay bit-identical
+    over three steps, and the weights land where ONE process stepping the whole global batch lands (same pixels, same
+    draws -- world-size invariance, SURVEY.md section 8e)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "dp_gpu_worker.py"
+    script.write_text(_DP_GPU_WORKER)
+    port = 29700 + (os.getpid() % 200)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), root], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank} failed:\n{out[-3000:]}"
+        assert f"rank {rank} ok" in out
+    print([l for l in outs[0].splitlines() if l.startswith("max |param")])
