@@ -23,6 +23,8 @@ rocprofv3 --kernel-trace --stats -d $out/prof2 -o x -- python $R/tools/bench_mlp
 db=$(find $out/prof2 -name '*.db' | head -1)
 python $R/tools/rocpd_summary.py $db 2>/dev/null | head -6 > $out/f16x3_mlp_inference_kernel_stats.csv
 rm -rf $out/prof2
+PLNERF_ALLOW_TOOLS_BUILD=1 PLNERF_HIP_LIB=$R/tools/_head/librr_trace.so python $R/tools/trace_rr.py f16x3 f16 2>/dev/null | grep cycles > $out/rr_tile_walk_clock.txt
+cd $R && bash tools/pmc_traffic.sh > $out/pmc_traffic.log 2>&1; cp $R/gpurun_out/pmc_traffic/traffic.json $out/traffic.json; cp $R/gpurun_out/pmc_traffic/summary.txt $out/f16x3_hbm_traffic_pmc.txt
 tail -1 $out/bench_default_f16x3.json | cut -c1-300
 head -8 $out/f16x3_bench_kernel_stats.csv | cut -c1-150
 cat $out/stream_kernels_262144rays.jsonl | cut -c1-200

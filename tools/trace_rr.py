@@ -1,5 +1,5 @@
 """Shader-clock / wall-clock stamps of one workgroup of the register-resident forward kernel (a library built with
--DRR_TRACE=<block>, see tools/ab_libs.sh): cycles per 128-row tile, time per tile, effective shader clock."""
+-DRR_TRACE=<block>, see tools/ab_libs.sh): cycles per tile, time per tile, effective shader clock."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,5 +20,5 @@ for prec in sys.argv[1:] or ["f16x3", "f16"]:
     fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
     fn(buf)
     cyc, wall = buf[2] - buf[0], (buf[3] - buf[1]) * 10.0     # wall clock: 100 MHz
-    print(f"{prec}: {cyc} shader cycles, {wall / 1000:.1f} us per 128-row tile -> {cyc / wall:.3f} GHz effective; "
-          f"MFMA floor {3480 * 32 if prec.endswith('x3') else 1160 * 32} cycles = {100.0 * (3480 * 32 if prec.endswith('x3') else 1160 * 32) / cyc:.1f} % of the walk")
+    print(f"{prec}: {cyc} shader cycles, {wall / 1000:.1f} us per tile -> {cyc / wall:.3f} GHz effective; "
+          f"rows per tile {128 if prec.endswith('x3') else 256}; MFMA floor {3480 * 32 if prec.endswith('x3') else 2320 * 32} cycles = {100.0 * (3480 * 32 if prec.endswith('x3') else 2320 * 32) / cyc:.1f} % of the walk")
