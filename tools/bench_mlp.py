@@ -42,6 +42,10 @@ for prec in a.precisions.split(","):
     print(json.dumps({"what": "fused MLP forward (inference)", "precision": prec, "rows": rows, "ms": ms,
                       "tflops": tf, "peak": PEAK[prec], "frac": tf / PEAK[prec]}), flush=True)
     Rt = a.train_rays
+    if Rt <= 0:
+        del net, pts, vd
+        torch.cuda.empty_cache()
+        continue
     ptst, vdt = pts[:Rt].contiguous(), vd[:Rt].contiguous()
     cot = torch.randn(Rt, S, 4, device=dev)
 
