@@ -78,7 +78,7 @@ extern "C" int plnerf_mlp_pack_weights(const float* const* params, int precision
 extern "C" size_t plnerf_mlp_saved_bytes(int n_rows, int precision) {
     if (!known(precision) || n_rows < 0) return 0;
     if (precision == PLNERF_PREC_FP32) return (size_t)lay::SAVED_PER_ROW * (size_t)n_rows * sizeof(float);
-    return (size_t)lay::SVH_BYTES_PER_ROW * lay::sv_rows((size_t)n_rows);      // rows padded to whole 32-row tiles
+    return (size_t)lay::SVH_BYTES_PER_ROW * lay::sv_rows((size_t)n_rows);      // rows padded to whole workgroup tiles (SV_ROW_PAD)
 }
 
 // layout of the 256-wide saved planes the forward of this configuration writes (lay::SV_LAYOUT_*): the backward is

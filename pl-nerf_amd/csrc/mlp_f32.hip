@@ -678,7 +678,7 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
             b_row[j] = q / B_C8; b_col[j] = (q % B_C8) * 8;
         }
     }
-    const int last_tile = (int)(sv_rows((size_t)a.n_rows) / 32) - 1;
+    const int last_tile = (a.n_rows + 31) / 32 - 1;      // the last tile that holds a real row
     const bool b_owner = tid < B_THREADS;
     struct Set { wh8 a[SA]; wh8 b[SB]; };
     Set s0, s1;      // (s1 only in the DEEP variant)

@@ -98,7 +98,8 @@ constexpr int DZ_PER_ROW = DZ_V_OFF + HV;    // 2432
 // conversion saturating); the reduction kernel divides it back out.  Both halve the bytes the
 // backward pass moves through HBM.
 // Rows are padded to a multiple of SV_ROW_PAD in every offset of the half state (plane p starts at
-// plane_off(p) * sv_rows(n_rows)), so that the TILED layout below never runs from one plane into the next.
+// plane_off(p) * sv_rows(n_rows)), so that the TILED layout below never runs from one plane into the next and every
+// wave of the forward kernel that writes it owns a whole tile (rows past n_rows: padding, written, never read).
 //
 // Layouts of the 256-wide planes h0..h7, feature and of hv (128 wide) -- the encoding planes and the relu bits are
 // always row-major:
@@ -109,7 +110,7 @@ constexpr int DZ_PER_ROW = DZ_V_OFF + HV;    // 2432
 //                    accumulator layout holds, so a wave stores a fragment as ONE contiguous KiB straight from its
 //                    registers.  4 consecutive features of a row stay contiguous, which is all the weight-gradient
 //                    kernel's transposing LDS reads need.
-constexpr int SV_ROW_PAD = 32;
+constexpr int SV_ROW_PAD = 256;     // = the register-resident forward's largest workgroup tile: its plane stores are unconditional
 constexpr int SV_LAYOUT_ROWS = 0, SV_LAYOUT_TILED = 1;
 __host__ __device__ constexpr size_t sv_rows(size_t n_rows) { return (n_rows + SV_ROW_PAD - 1) / SV_ROW_PAD * SV_ROW_PAD; }
 // position (in halves) of element (row, col) of a `width`-wide plane in the tiled layout

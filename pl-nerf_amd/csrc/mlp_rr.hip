@@ -77,6 +77,7 @@ constexpr int H_BIAS = HB_BIAS - HB, H_BF = HB_BF - HB, H_BV = HB_BV - HB, H_WA 
 constexpr float H16_MAX_SPLIT = 65504.0f;
 constexpr int RR_THREADS = 256;     // four waves, one per SIMD
 constexpr int RR_ROWS = 128;        // rows per workgroup and row tile (32 per wave)
+static_assert(SV_ROW_PAD % (2 * RR_ROWS) == 0, "saved planes are padded to whole workgroup tiles (up to two row tiles per wave)");
 constexpr int SLOT_BYTES = 32768;   // one ring slot = one unit's weight fragments
 constexpr int NSLOTS = 4;
 constexpr int N_LAYERS = 10;        // L0..L7, feature, view layer (= FwdGemm order)
@@ -183,6 +184,17 @@ constexpr int epi_window(int ns, int rt, int u) {
     for (int wdw = d.nj * d.nk - 1; wdw >= 1; --wdw)
         if (epi_window_ok(ns, rt, u, wdw)) return wdw;
     return 0;
+}
+// Vector-memory STORES a wave issues while it runs unit u (training): the pending epilogues of unit u - 1's slabs put
+// out two plane fragments per slab and row tile, and the layer's relu-bit row once its last slab is done (the feature
+// layer, 8, has no relu).  They share the vmcnt counter with the weight DMA, in issue order, so the hand-over wait of
+// unit u + 1 has to allow for them on top of the DMA pieces that may still fly.
+constexpr int stores_in_unit(int ns, int rt, int u) {
+    if (u < 1 || u >= n_units(ns)) return 0;
+    const Unit p = unit_desc(ns, u - 1);
+    if (!p.last) return 0;
+    const bool layer_done = p.j0 + p.nj == layer_slabs(p.layer);
+    return 2 * p.nj * rt + ((layer_done && p.layer != 8) ? rt : 0);
 }
 // row tiles (32 rows each) a wave carries through the network: the split mode's two operand planes leave room for one;
 // the plain mode takes two, so that every weight fragment fetched from LDS feeds two MFMAs
@@ -334,6 +346,7 @@ __device__ __forceinline__ void dir_values(const float x, const float y, const f
 
 struct Lane {
     int lane, g, wave, trow, grow;      // trow: row within the tile; grow: global row (clamped)
+    int prow;                           // global row, not clamped: < sv_rows(n_rows), the padded row count of the saved planes
     bool rowv;                          // the row exists
     int wrow0, n_rows;                  // first global row of the wave; rows in the launch
     const unsigned char* lds;           // the workgroup's LDS
@@ -368,9 +381,10 @@ __device__ __forceinline__ unsigned char* mask_ptr(const FwdArgs& a, const int p
 // it, one contiguous KiB per store instruction: no transposition, no LDS, two stores per 32-feature slab ----
 __device__ __forceinline__ void store_frag_tiled(const h16x8 f, _Float16* tile, const int width, const int j, const int frag,
                                                  const Lane& ln) {
-    // (rows past n_rows inside the last tile land in the planes' row padding; a wave whose 32 rows all lie past
-    // n_rows has no tile)
-    if (ln.wrow0 < ln.n_rows && !(RR_ABLATE & 16))
+    // Unconditional: the planes' rows are padded to whole workgroup tiles (SV_ROW_PAD, mlp_layout.h), so every wave of
+    // every workgroup has a tile -- rows past n_rows land in padding nobody reads.  A store that may or may not be
+    // issued could not be counted in the hand-over waits (stores_in_unit), and its branch sat in the MFMA stream.
+    if (!(RR_ABLATE & 16))
         *reinterpret_cast<h16x8*>(tile + ((size_t)((j * 2 + frag) * 64 + ln.lane)) * 8) = f;
     (void)width;
 }
@@ -447,13 +461,13 @@ __device__ __forceinline__ void epi_chunk(Wave<NS>& w, const int j, const int c,
 template <int NS, int L>
 __device__ __forceinline__ void store_mask_row(const Wave<NS>& w, const FwdArgs& a, const Lane& ln) {
     if constexpr (L <= 7) {
-        unsigned char* row = mask_ptr(a, L, ln.N) + (size_t)ln.grow * (W / 8);
+        unsigned char* row = mask_ptr(a, L, ln.N) + (size_t)ln.prow * (W / 8);      // (padded row: always inside the plane)
         const u32x4 q = ln.g ? u32x4{w.mw[4], w.mw[5], w.mw[6], w.mw[7]} : u32x4{w.mw[0], w.mw[1], w.mw[2], w.mw[3]};
-        if (ln.rowv) *reinterpret_cast<u32x4*>(row + 16 * ln.g) = q;
+        *reinterpret_cast<u32x4*>(row + 16 * ln.g) = q;
     } else if constexpr (L == 9) {
-        unsigned char* row = mask_ptr(a, 8, ln.N) + (size_t)ln.grow * (HV / 8);
+        unsigned char* row = mask_ptr(a, 8, ln.N) + (size_t)ln.prow * (HV / 8);
         const u32x2 q = ln.g ? u32x2{w.mw[2], w.mw[3]} : u32x2{w.mw[0], w.mw[1]};
-        if (ln.rowv) *reinterpret_cast<u32x2*>(row + 8 * ln.g) = q;
+        *reinterpret_cast<u32x2*>(row + 8 * ln.g) = q;
     }
 }
 
@@ -503,7 +517,9 @@ __device__ __forceinline__ void run_step(Wave<NS> (&w)[RT], h16x8 (&af)[PFD + 1]
     constexpr int NPC = max_pieces_per_wave<NS>(U + 3);
     constexpr int kk = T / d.nj, sl = T - kk * d.nj;          // (k-step, slab) order: independent accumulators alternate
     if constexpr (T == SP) {
-        wait_vm<pieces_per_wave<NS>(U + 2)>();                 // my pieces of unit U + 1 have landed (U + 2's may fly)
+        // my pieces of unit U + 1 have landed; what was issued after them may fly: unit U + 2's pieces and (training) the
+        // plane stores of unit U - 1's run, interleaved with them
+        wait_vm<pieces_per_wave<NS>(U + 2) + (SAVE ? stores_in_unit(NS, RT, U - 1) : 0)>();
         if (!(RR_ABLATE & 4)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
@@ -623,6 +639,7 @@ __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
         ln[rt].trow = (wave * RT + rt) * 32 + (lane & 31);
         ln[rt].rowv = row0 + ln[rt].trow < a.n_rows;
         ln[rt].grow = min(row0 + ln[rt].trow, a.n_rows - 1);
+        ln[rt].prow = row0 + ln[rt].trow;
         ln[rt].lds = smem; ln[rt].hd = hd; ln[rt].N = sv_rows((size_t)a.n_rows);
         ln[rt].wrow0 = row0 + (wave * RT + rt) * 32; ln[rt].n_rows = a.n_rows;
     }
@@ -677,22 +694,21 @@ __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {            // 32 rows x 8 pieces of 16 B
                 const int idx = q * 64 + lane, r = idx >> 3, c = idx & 7;
-                if (lt.wrow0 + r < a.n_rows)
-                    *reinterpret_cast<u32x4*>(pe_plane + (size_t)(lt.wrow0 + r) * PE_K + 8 * c) =
-                        *reinterpret_cast<const u32x4*>(st + (size_t)r * (PE_K + DPE_K) + 8 * c);
+                *reinterpret_cast<u32x4*>(pe_plane + (size_t)(lt.wrow0 + r) * PE_K + 8 * c) =
+                    *reinterpret_cast<const u32x4*>(st + (size_t)r * (PE_K + DPE_K) + 8 * c);
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {            // 32 rows x 4 pieces
                 const int idx = q * 64 + lane, r = idx >> 2, c = idx & 3;
-                if (lt.wrow0 + r < a.n_rows)
-                    *reinterpret_cast<u32x4*>(dpe_plane + (size_t)(lt.wrow0 + r) * DPE_K + 8 * c) =
-                        *reinterpret_cast<const u32x4*>(st + (size_t)r * (PE_K + DPE_K) + PE_K + 8 * c);
+                *reinterpret_cast<u32x4*>(dpe_plane + (size_t)(lt.wrow0 + r) * DPE_K + 8 * c) =
+                    *reinterpret_cast<const u32x4*>(st + (size_t)r * (PE_K + DPE_K) + PE_K + 8 * c);
             }
             __builtin_amdgcn_wave_barrier();
         }
     }
     // unit 0's weights and the head block are in place for everyone
-    wait_vm<pieces_per_wave<NS>(1) + pieces_per_wave<NS>(2)>();
+    // (training: the prologue's six encoding-plane stores per row tile were issued after all three units' pieces)
+    wait_vm<pieces_per_wave<NS>(1) + pieces_per_wave<NS>(2) + (SAVE ? 6 * RT : 0)>();
     __syncthreads();
     h16x8 carry[PFD][NS];
     {

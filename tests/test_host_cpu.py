@@ -55,7 +55,7 @@ def test_buffer_size_queries(built):
     L = _lib.lib()
     assert L.plnerf_mlp_packed_bytes(0) > 595844 * 4          # padded fwd + bwd layouts
     assert L.plnerf_mlp_saved_bytes(1000, 0) == 1000 * 2596 * 4
-    assert L.plnerf_mlp_saved_bytes(1000, 3) == 1024 * (2528 * 2 + 272)      # 16-bit modes: half planes + relu masks, rows padded to 32-row tiles
+    assert L.plnerf_mlp_saved_bytes(1000, 3) == 1024 * (2528 * 2 + 272)      # 16-bit modes: half planes + relu masks, rows padded to whole 256-row workgroup tiles
     assert L.plnerf_mlp_bwd_workspace_bytes(1000, 3) < L.plnerf_mlp_bwd_workspace_bytes(1000, 0)
     assert L.plnerf_mlp_bwd_workspace_bytes(1000, 0) > 1000 * 2432 * 4
     assert L.plnerf_mlp_packed_bytes(7) == 0
