@@ -48,6 +48,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define RR_MFMA __builtin_amdgcn_mfma_f32_32x32x16_f16
+// LDS-space views.  The ring (128 KB) and the head block behind it lie beyond the 64 KB a DS instruction's immediate
+// offset reaches; three base registers (ring slots 0-1, slots 2-3, head block), opaque to the optimiser, keep every
+// access at "base + immediate" -- left alone, the compiler rebuilds an address with a v_add_u32 per read.
+typedef __attribute__((address_space(3))) const unsigned char lds_cbyte;
+typedef __attribute__((address_space(3))) const h16x8 lds_h16x8;
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+typedef __attribute__((address_space(3))) const f32x2 lds_f32x2;
+typedef __attribute__((address_space(3))) const f32x4 lds_f32x4;
 
 #ifdef RR_TRACE
 __device__ unsigned long long g_rr_trace[8];
@@ -224,8 +232,11 @@ struct FwdArgs {
 // counting (cdna_hip_programming.md section 5.7): completion = the issuing wave's vmcnt, then a barrier.
 // (M0 carries the LDS destination; it is compiler-reserved, never allocated to a value, and nothing else in this
 // kernel uses it, so it is written in the statement that needs it and not restored.)
-__device__ __forceinline__ void dma_1k(const void* gsrc, const unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
+// Address = wave-uniform base (an SGPR pair, advanced by scalar adds) + the lane's 16-byte slot (one VGPR for the whole
+// kernel): no vector ALU work per piece.
+__device__ __forceinline__ void dma_1k(const void* gsrc_uniform, const unsigned lane_off, const unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(gsrc_uniform), "s"(lds_dst)
+                 : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
@@ -241,7 +252,7 @@ __device__ __forceinline__ void issue_unit(const FwdArgs& a, const unsigned lds_
         for (int p = 0; p < (NP + 3) / 4; ++p) {
             const int piece = 4 * p + wave;
             if (4 * p + 3 < NP || piece < NP)        // (the view layer's 18 pieces in plain mode: waves 0, 1 take five)
-                dma_1k(src + (size_t)piece * 1024 + lane * 16, slot + piece * 1024);
+                dma_1k(src + (size_t)piece * 1024, lane * 16, slot + piece * 1024);
         }
     }
 }
@@ -256,7 +267,7 @@ __device__ __forceinline__ void issue_piece(const FwdArgs& a, const unsigned lds
         const unsigned char* src = reinterpret_cast<const unsigned char*>(a.wrr) + (size_t)unit_elem_off(NS, d) * 2;
         const unsigned slot = lds_base + (U % NSLOTS) * SLOT_BYTES;
         const int piece = 4 * q + wave;
-        if (4 * q + 3 < NP || piece < NP) dma_1k(src + (size_t)piece * 1024 + lane * 16, slot + piece * 1024);
+        if (4 * q + 3 < NP || piece < NP) dma_1k(src + (size_t)piece * 1024, lane * 16, slot + piece * 1024);
     }
 }
 template <int NS>
@@ -287,9 +298,14 @@ __device__ __forceinline__ void put_split(h16x8 (&dst)[NS], const int e0, const 
     d0[e0 >> 1] = __builtin_bit_cast(unsigned, h);
     dst[0] = __builtin_bit_cast(h16x8, d0);
     if constexpr (NS == 2) {
-        const h16x2 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x2), h16x2);
+        // lo = f16(v - f32(hi)), one v_fma_mix per value: f32(hi) * -1 + v evaluated in fp32 (exact), rounded once to half
+        // -- bit-identical to convert / subtract / convert (tools/probes/fma_mix_split_probe.hip), 2 instructions for 5
+        unsigned l;
+        const unsigned hb = __builtin_bit_cast(unsigned, h);
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hb), "v"(v0));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hb), "v"(v1));
         u32x4 d1 = __builtin_bit_cast(u32x4, dst[1]);
-        d1[e0 >> 1] = __builtin_bit_cast(unsigned, l);
+        d1[e0 >> 1] = l;
         dst[1] = __builtin_bit_cast(h16x8, d1);
     }
 }
@@ -351,6 +367,9 @@ struct Lane {
     int wrow0, n_rows;                  // first global row of the wave; rows in the launch
     const unsigned char* lds;           // the workgroup's LDS
     const float* hd;                    // head block in LDS
+    lds_cbyte* ring01;                  // LDS: ring slots 0, 1 + 16 lane   (opaque bases, see lds_cbyte)
+    lds_cbyte* ring23;                  //      ring slots 2, 3 + 16 lane
+    lds_cfloat* hdg;                    //      head block + 4 g floats
     size_t N;
 };
 
@@ -413,16 +432,16 @@ __device__ __forceinline__ void epi_chunk(Wave<NS>& w, const int j, const int c,
     asm volatile("" : "+v"(w.amax));
     const int f0 = 32 * j + 8 * i + 4 * ln.g + r0;
     if constexpr (L == 7) {          // sigma = w_alpha . relu(h7)
-        const f32x2 wa = *reinterpret_cast<const f32x2*>(ln.hd + H_WA + f0);
+        const f32x2 wa = *reinterpret_cast<lds_f32x2*>(ln.hdg + H_WA + (f0 - 4 * ln.g));
         w.sig = fmaf(v[0], wa[0], w.sig);
         w.sig = fmaf(v[1], wa[1], w.sig);
         asm volatile("" : "+v"(w.sig));      // (keeps the partial sums here: LLVM otherwise sinks the whole chain to the
                                              // kernel's end and holds every operand live until then)
     }
     if constexpr (L == 9) {          // rgb = W_rgb . relu(hv); training: the hv plane and its relu bits
-        const f32x2 w0 = *reinterpret_cast<const f32x2*>(ln.hd + H_WR + f0);
-        const f32x2 w1 = *reinterpret_cast<const f32x2*>(ln.hd + H_WR + HV + f0);
-        const f32x2 w2 = *reinterpret_cast<const f32x2*>(ln.hd + H_WR + 2 * HV + f0);
+        const f32x2 w0 = *reinterpret_cast<lds_f32x2*>(ln.hdg + H_WR + (f0 - 4 * ln.g));
+        const f32x2 w1 = *reinterpret_cast<lds_f32x2*>(ln.hdg + H_WR + HV + (f0 - 4 * ln.g));
+        const f32x2 w2 = *reinterpret_cast<lds_f32x2*>(ln.hdg + H_WR + 2 * HV + (f0 - 4 * ln.g));
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             w.o0 = fmaf(v[r], w0[r], w.o0);
@@ -462,11 +481,16 @@ template <int NS, int L>
 __device__ __forceinline__ void store_mask_row(const Wave<NS>& w, const FwdArgs& a, const Lane& ln) {
     if constexpr (L <= 7) {
         unsigned char* row = mask_ptr(a, L, ln.N) + (size_t)ln.prow * (W / 8);      // (padded row: always inside the plane)
-        const u32x4 q = ln.g ? u32x4{w.mw[4], w.mw[5], w.mw[6], w.mw[7]} : u32x4{w.mw[0], w.mw[1], w.mw[2], w.mw[3]};
+        // (element-wise selects: a vector-valued ?: is lowered through a scratch array indexed by g)
+        u32x4 q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = ln.g ? w.mw[4 + e] : w.mw[e];
         *reinterpret_cast<u32x4*>(row + 16 * ln.g) = q;
     } else if constexpr (L == 9) {
         unsigned char* row = mask_ptr(a, 8, ln.N) + (size_t)ln.prow * (HV / 8);
-        const u32x2 q = ln.g ? u32x2{w.mw[2], w.mw[3]} : u32x2{w.mw[0], w.mw[1]};
+        u32x2 q;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) q[e] = ln.g ? w.mw[2 + e] : w.mw[e];
         *reinterpret_cast<u32x2*>(row + 8 * ln.g) = q;
     }
 }
@@ -476,7 +500,7 @@ __device__ __forceinline__ void init_acc(Wave<NS>& w, const int j, const Lane& l
     constexpr int boff = L < 8 ? H_BIAS + L * W : (L == 8 ? H_BF : H_BV);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(ln.hd + boff + 32 * j + 8 * i + 4 * ln.g);
+        const f32x4 b = *reinterpret_cast<lds_f32x4*>(ln.hdg + boff + 32 * j + 8 * i);
 #pragma unroll
         for (int r = 0; r < 4; ++r) w.acc[j][4 * i + r] = b[r];
     }
@@ -494,11 +518,12 @@ __device__ __forceinline__ const h16x8 (&b_frag(const Wave<NS>& w, const int k))
 
 // weight fragment (slab sl, k-step kk of the unit in slot `slot`) for this lane
 template <int NS>
-__device__ __forceinline__ void load_a(h16x8 (&af)[NS], const unsigned char* lds_lane, const int slot, const int nk,
+__device__ __forceinline__ void load_a(h16x8 (&af)[NS], const Lane& ln, const int slot, const int nk,
                                        const int sl, const int kk) {
+    lds_cbyte* base = slot < 2 ? ln.ring01 : ln.ring23;
 #pragma unroll
     for (int s = 0; s < NS; ++s)
-        af[s] = *reinterpret_cast<const h16x8*>(lds_lane + slot * SLOT_BYTES + ((sl * nk + kk) * NS + s) * 1024);
+        af[s] = *reinterpret_cast<lds_h16x8*>(base + (slot & 1) * SLOT_BYTES + ((sl * nk + kk) * NS + s) * 1024);
 }
 
 constexpr int PFD = RR_PFD;      // weight fragments requested this many k-step products ahead
@@ -507,7 +532,7 @@ constexpr int PFD = RR_PFD;      // weight fragments requested this many k-step 
 // counter are not reliably unrolled, and a rolled one would index the register arrays dynamically).
 template <int NS, int RT, bool SAVE, int U, int T>
 __device__ __forceinline__ void run_step(Wave<NS> (&w)[RT], h16x8 (&af)[PFD + 1][NS], const FwdArgs& a, const Lane (&ln)[RT],
-                                         const unsigned lds_base, const unsigned char* lds_lane) {
+                                         const unsigned lds_base) {
     constexpr Unit d = unit_desc(NS, U);
     constexpr int L = d.layer, NSTEP = d.nj * d.nk, SP = 1;
     constexpr bool HAS_NEXT = U + 1 < n_units(NS);
@@ -528,11 +553,11 @@ __device__ __forceinline__ void run_step(Wave<NS> (&w)[RT], h16x8 (&af)[PFD + 1]
         if constexpr (RR_ABLATE & 2) {
         } else if constexpr (tn < NSTEP) {
             constexpr int kn = tn / d.nj, sn = tn - kn * d.nj;
-            load_a<NS>(af[tn % (PFD + 1)], lds_lane, U % NSLOTS, d.nk, sn, kn);
+            load_a<NS>(af[tn % (PFD + 1)], ln[0], U % NSLOTS, d.nk, sn, kn);
         } else if constexpr (HAS_NEXT) {
             constexpr Unit nd = unit_desc(NS, HAS_NEXT ? U + 1 : U);
             constexpr int t2 = tn - NSTEP, kn = t2 / nd.nj, sn = t2 - kn * nd.nj;
-            load_a<NS>(af[tn % (PFD + 1)], lds_lane, (U + 1) % NSLOTS, nd.nk, sn, kn);
+            load_a<NS>(af[tn % (PFD + 1)], ln[0], (U + 1) % NSLOTS, nd.nk, sn, kn);
         }
     }
     if constexpr (PEND && T >= 1 && !(RR_ABLATE & 8)) {
@@ -572,9 +597,9 @@ __device__ __forceinline__ void run_step(Wave<NS> (&w)[RT], h16x8 (&af)[PFD + 1]
 
 template <int NS, int RT, bool SAVE, int U, int... Ts>
 __device__ __forceinline__ void run_steps(Wave<NS> (&w)[RT], h16x8 (&af)[PFD + 1][NS], const FwdArgs& a, const Lane (&ln)[RT],
-                                          const unsigned lds_base, const unsigned char* lds_lane,
+                                          const unsigned lds_base,
                                           std::integer_sequence<int, Ts...>) {
-    (run_step<NS, RT, SAVE, U, Ts>(w, af, a, ln, lds_base, lds_lane), ...);
+    (run_step<NS, RT, SAVE, U, Ts>(w, af, a, ln, lds_base), ...);
 }
 
 // Unit U: its k-step products in (k-step, slab) order, each on the wave's RT row tiles.  The weight fragments of the
@@ -588,7 +613,6 @@ __device__ __forceinline__ void run_unit(Wave<NS> (&w)[RT], h16x8 (&carry)[PFD][
                                          const unsigned lds_base) {
     constexpr Unit d = unit_desc(NS, U);
     constexpr int L = d.layer, NSTEP = d.nj * d.nk;
-    const unsigned char* lds_lane = ln[0].lds + ln[0].lane * 16;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         if constexpr (d.first && d.j0 == 0 && L == 5) encode_xyz<NS>(w[rt], ln[rt]);
@@ -604,7 +628,7 @@ __device__ __forceinline__ void run_unit(Wave<NS> (&w)[RT], h16x8 (&carry)[PFD][
 #pragma unroll
         for (int s = 0; s < NS; ++s) af[p][s] = carry[p][s];
     __builtin_amdgcn_sched_barrier(0);
-    run_steps<NS, RT, SAVE, U>(w, af, a, ln, lds_base, lds_lane, std::make_integer_sequence<int, NSTEP>{});
+    run_steps<NS, RT, SAVE, U>(w, af, a, ln, lds_base, std::make_integer_sequence<int, NSTEP>{});
 #pragma unroll
     for (int p = 0; p < PFD; ++p)
 #pragma unroll
@@ -632,6 +656,12 @@ __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row0 = blockIdx.x * (RR_ROWS * RT);
+    lds_cbyte* ring01 = (lds_cbyte*)smem + lane * 16;
+    lds_cbyte* ring23 = ring01 + 2 * SLOT_BYTES;
+    lds_cfloat* hdg = (lds_cfloat*)hd + 4 * (lane >> 5);
+    asm volatile("" : "+v"(ring01));
+    asm volatile("" : "+v"(ring23));
+    asm volatile("" : "+v"(hdg));
     Lane ln[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -641,6 +671,7 @@ __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
         ln[rt].grow = min(row0 + ln[rt].trow, a.n_rows - 1);
         ln[rt].prow = row0 + ln[rt].trow;
         ln[rt].lds = smem; ln[rt].hd = hd; ln[rt].N = sv_rows((size_t)a.n_rows);
+        ln[rt].ring01 = ring01; ln[rt].ring23 = ring23; ln[rt].hdg = hdg;
         ln[rt].wrow0 = row0 + (wave * RT + rt) * 32; ln[rt].n_rows = a.n_rows;
     }
 #ifdef RR_TRACE
@@ -714,7 +745,7 @@ __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
     {
         constexpr Unit d0 = unit_desc(NS, 0);
 #pragma unroll
-        for (int p = 0; p < PFD; ++p) load_a<NS>(carry[p], smem + lane * 16, 0, d0.nk, p % d0.nj, p / d0.nj);
+        for (int p = 0; p < PFD; ++p) load_a<NS>(carry[p], ln[0], 0, d0.nk, p % d0.nj, p / d0.nj);
     }
     run_units<NS, RT, SAVE, 0>(w, carry, a, ln, lds_base);
     // the last unit's slab epilogues (view layer) and the heads
