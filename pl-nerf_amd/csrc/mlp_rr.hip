@@ -216,6 +216,27 @@ constexpr bool schedule_ok(int ns) {
     return true;
 }
 static_assert(schedule_ok(1) && schedule_ok(2), "unit schedule: a unit fits a slot; pending epilogues precede their readers");
+constexpr int INIT_AHEAD = 4;
+// The accumulators of unit u + 1 are loaded with their biases INIT_AHEAD products before unit u ends (run_step).  Where unit
+// u + 1 reuses an accumulator that unit u - 1's pending epilogue still reads during unit u (L0's four-slab units
+// followed by L1's slab 0), the epilogue's last chunk on it must come earlier.
+constexpr bool init_hoist_ok(int ns) {
+    const int rt = row_tiles(ns);
+    for (int u = 1; u + 1 < n_units(ns); ++u) {
+        const Unit d = unit_desc(ns, u), p = unit_desc(ns, u - 1), n = unit_desc(ns, u + 1);
+        if (!p.last || !n.first) continue;
+        const int nch = 8 * p.nj * rt, win = epi_window(ns, rt, u), t_init = d.nj * d.nk - INIT_AHEAD;
+        for (int sl = n.j0; sl < n.j0 + n.nj; ++sl) {
+            if (sl < p.j0 || sl >= p.j0 + p.nj) continue;
+            const int c_last = (sl - p.j0 + 1) * 8 * rt - 1;
+            if (1 + c_last * win / nch >= t_init) return false;
+        }
+        for (int sl = n.j0; sl < n.j0 + n.nj; ++sl)          // (and never the running unit's own accumulators)
+            if (sl >= d.j0 && sl < d.j0 + d.nj) return false;
+    }
+    return true;
+}
+static_assert(init_hoist_ok(1) && init_hoist_ok(2), "hoisted accumulator set-up overwrites a slab that is still in use");
 
 struct FwdArgs {
     const void* packed;     // head block at the start
@@ -284,6 +305,7 @@ struct Wave {
     float px, py, pz, dx, dy, dz;   // the row's position and view direction
     f32x16 acc[8];
     float sig, o0, o1, o2;          // head partials
+    f32x2 hw[3];                    // head weights (w_alpha | the three w_rgb rows) of the NEXT epilogue chunk, requested one chunk ahead
     float amax;                     // largest activation magnitude split into halves so far (range check)
     unsigned mw[8];                 // relu bit words of the layer in flight (training)
     h16x8 hvf[1];                   // the view layer's half fragment being assembled (training)
@@ -431,17 +453,29 @@ __device__ __forceinline__ void epi_chunk(Wave<NS>& w, const int j, const int c,
     w.amax = fmaxf(w.amax, fmaxf(fabsf(acc[4 * i + r0]), fabsf(acc[4 * i + r0 + 1])));
     asm volatile("" : "+v"(w.amax));
     const int f0 = 32 * j + 8 * i + 4 * ln.g + r0;
+    // head weights: this chunk's arrive in w.hw (asked for by the previous chunk of this row tile -- an LDS read whose
+    // result is needed at once would stall the wave, and with it the MFMA issue, for the LDS latency); ask for the next
+    const int jn = c < 7 ? j : j + 1, cn = (c + 1) & 7;
+    const int f0n = 32 * jn + 8 * (cn >> 1) + 2 * (cn & 1);      // (without the lane half's 4 g: that is in hdg)
     if constexpr (L == 7) {          // sigma = w_alpha . relu(h7)
-        const f32x2 wa = *reinterpret_cast<lds_f32x2*>(ln.hdg + H_WA + (f0 - 4 * ln.g));
+        if (j == 0 && c == 0) w.hw[0] = *reinterpret_cast<lds_f32x2*>(ln.hdg + H_WA + (f0 - 4 * ln.g));
+        const f32x2 wa = w.hw[0];
+        if (jn < W / 32) w.hw[0] = *reinterpret_cast<lds_f32x2*>(ln.hdg + H_WA + f0n);
         w.sig = fmaf(v[0], wa[0], w.sig);
         w.sig = fmaf(v[1], wa[1], w.sig);
         asm volatile("" : "+v"(w.sig));      // (keeps the partial sums here: LLVM otherwise sinks the whole chain to the
                                              // kernel's end and holds every operand live until then)
     }
     if constexpr (L == 9) {          // rgb = W_rgb . relu(hv); training: the hv plane and its relu bits
-        const f32x2 w0 = *reinterpret_cast<lds_f32x2*>(ln.hdg + H_WR + (f0 - 4 * ln.g));
-        const f32x2 w1 = *reinterpret_cast<lds_f32x2*>(ln.hdg + H_WR + HV + (f0 - 4 * ln.g));
-        const f32x2 w2 = *reinterpret_cast<lds_f32x2*>(ln.hdg + H_WR + 2 * HV + (f0 - 4 * ln.g));
+        if (j == 0 && c == 0) {
+#pragma unroll
+            for (int o = 0; o < 3; ++o) w.hw[o] = *reinterpret_cast<lds_f32x2*>(ln.hdg + H_WR + o * HV + (f0 - 4 * ln.g));
+        }
+        const f32x2 w0 = w.hw[0], w1 = w.hw[1], w2 = w.hw[2];
+        if (jn < HV / 32) {
+#pragma unroll
+            for (int o = 0; o < 3; ++o) w.hw[o] = *reinterpret_cast<lds_f32x2*>(ln.hdg + H_WR + o * HV + f0n);
+        }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             w.o0 = fmaf(v[r], w0[r], w.o0);
@@ -580,6 +614,17 @@ __device__ __forceinline__ void run_step(Wave<NS> (&w)[RT], h16x8 (&af)[PFD + 1]
 #pragma unroll
         for (int q = q0; q < q1; ++q) issue_piece<NS, U + 3>(a, lds_base, ln[0].wave, ln[0].lane, q);
     }
+    if constexpr (HAS_NEXT && T == NSTEP - INIT_AHEAD) {
+        // the next unit's accumulators start from the biases: the LDS reads go out a few products early, so that its first
+        // MFMA does not wait for them (the registers are free: slab j + 1's last use was a whole layer ago)
+        constexpr Unit nd = unit_desc(NS, HAS_NEXT ? U + 1 : U);
+        if constexpr (nd.first) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int q = 0; q < nd.nj; ++q) init_acc<NS, nd.layer>(w[rt], nd.j0 + q, ln[rt]);
+        }
+    }
     const h16x8 (&aw)[NS] = af[T % (PFD + 1)];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {          // one weight fragment, RT row tiles
@@ -617,7 +662,7 @@ __device__ __forceinline__ void run_unit(Wave<NS> (&w)[RT], h16x8 (&carry)[PFD][
     for (int rt = 0; rt < RT; ++rt) {
         if constexpr (d.first && d.j0 == 0 && L == 5) encode_xyz<NS>(w[rt], ln[rt]);
         if constexpr (d.first && d.j0 == 0 && L == 9) encode_dir<NS>(w[rt], ln[rt]);
-        if constexpr (d.first) {
+        if constexpr (d.first && U == 0) {      // (every later unit's accumulators are set up inside the unit before it)
 #pragma unroll
             for (int sl = 0; sl < d.nj; ++sl) init_acc<NS, L>(w[rt], d.j0 + sl, ln[rt]);
         }
