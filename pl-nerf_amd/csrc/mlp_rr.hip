@@ -58,7 +58,7 @@ typedef __attribute__((address_space(3))) const f32x2 lds_f32x2;
 typedef __attribute__((address_space(3))) const f32x4 lds_f32x4;
 
 #ifdef RR_TRACE
-__device__ unsigned long long g_rr_trace[8];
+__device__ unsigned long long g_rr_trace[128];     // [0..3] walk begin / end (shader clock, wall clock); [8 + u] start of unit u
 #endif
 
 namespace {
@@ -658,6 +658,9 @@ __device__ __forceinline__ void run_unit(Wave<NS> (&w)[RT], h16x8 (&carry)[PFD][
                                          const unsigned lds_base) {
     constexpr Unit d = unit_desc(NS, U);
     constexpr int L = d.layer, NSTEP = d.nj * d.nk;
+#ifdef RR_TRACE
+    if (blockIdx.x == (RR_TRACE) && threadIdx.x == 0) g_rr_trace[8 + U] = clock64();
+#endif
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         if constexpr (d.first && d.j0 == 0 && L == 5) encode_xyz<NS>(w[rt], ln[rt]);
@@ -689,7 +692,11 @@ __device__ __forceinline__ void run_units(Wave<NS> (&w)[RT], h16x8 (&carry)[PFD]
     }
 }
 
-constexpr size_t rr_lds_bytes() { return (size_t)NSLOTS * SLOT_BYTES + HEAD_BYTES; }
+// the head block comes in by DMA like the weights: 16 pieces of 1 KB (four per wave; the block itself is 12,320 bytes,
+// what follows it in the packed buffer rides along unused)
+constexpr int HEAD_PIECES = 16;
+static_assert(HEAD_PIECES * 1024 >= (int)HEAD_BYTES && HEAD_PIECES % 4 == 0, "head block DMA");
+constexpr size_t rr_lds_bytes() { return (size_t)NSLOTS * SLOT_BYTES + (size_t)HEAD_PIECES * 1024; }
 
 template <int NS, bool SAVE>
 __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
@@ -722,15 +729,35 @@ __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
 #ifdef RR_TRACE
     if (blockIdx.x == (RR_TRACE) && tid == 0) { g_rr_trace[0] = clock64(); g_rr_trace[1] = wall_clock64(); }
 #endif
-    // the first three units' weights are on their way before anything else
+    // The rows' six input floats first, as loads the compiler does not track (it would wait for them with vmcnt(0) and
+    // drain the DMA queue behind them); then the head block and the first three units' weights, all by DMA.  One
+    // counted wait below covers the inputs: they are older than every DMA piece.
+    float in6[RT][6];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const float* pp = a.pts + 3 * (size_t)ln[rt].grow;
+        const float* pv = a.viewdirs + 3 * (size_t)(ln[rt].grow / a.spr);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            asm volatile("global_load_dword %0, %1, off" : "=v"(in6[rt][c]) : "v"(pp + c) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(in6[rt][3 + c]) : "v"(pv + c) : "memory");
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < HEAD_PIECES / 4; ++p)
+        dma_1k(reinterpret_cast<const unsigned char*>(a.packed) + (size_t)(4 * p + wave) * 1024, lane * 16,
+               lds_base + NSLOTS * SLOT_BYTES + (4 * p + wave) * 1024);
     issue_unit<NS, 0>(a, lds_base, wave, lane);
     issue_unit<NS, 1>(a, lds_base, wave, lane);
     issue_unit<NS, 2>(a, lds_base, wave, lane);
-    {
-        const float* hg = reinterpret_cast<const float*>(a.packed);
-        for (int i = tid; i < HEAD_FLOATS / 4; i += RR_THREADS)
-            reinterpret_cast<float4*>(hd)[i] = reinterpret_cast<const float4*>(hg)[i];
-    }
+    wait_vm<HEAD_PIECES / 4 + pieces_per_wave<NS>(0) + pieces_per_wave<NS>(1) + pieces_per_wave<NS>(2)>();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) asm volatile("" : "+v"(in6[rt][c]));      // (nothing reads them above the wait)
+#ifdef RR_TRACE
+    if (blockIdx.x == (RR_TRACE) && tid == 0) g_rr_trace[4] = clock64();
+#endif
     Wave<NS> w[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -740,11 +767,8 @@ __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
         // ---- this lane's row: position and view direction stay in six registers; the encodings (32 of the 64 xyz
         // channels, 16 of the 32 direction channels per lane) are evaluated where they are consumed -- before L0 and
         // again before the skip layer, before the view layer -- rather than held in 48 registers across the network ----
-        wt.px = a.pts[3 * (size_t)lt.grow]; wt.py = a.pts[3 * (size_t)lt.grow + 1]; wt.pz = a.pts[3 * (size_t)lt.grow + 2];
-        {
-            const size_t ray = (size_t)(lt.grow / a.spr);
-            wt.dx = a.viewdirs[3 * ray]; wt.dy = a.viewdirs[3 * ray + 1]; wt.dz = a.viewdirs[3 * ray + 2];
-        }
+        wt.px = in6[rt][0]; wt.py = in6[rt][1]; wt.pz = in6[rt][2];
+        wt.dx = in6[rt][3]; wt.dy = in6[rt][4]; wt.dz = in6[rt][5];
         encode_xyz<NS>(wt, lt);
         if constexpr (SAVE) {
             // saved encoding planes, original channel order: through this wave's corner of ring slot 3 (unused until
@@ -782,10 +806,16 @@ __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
             __builtin_amdgcn_wave_barrier();
         }
     }
+#ifdef RR_TRACE
+    if (blockIdx.x == (RR_TRACE) && tid == 0) g_rr_trace[5] = clock64();
+#endif
     // unit 0's weights and the head block are in place for everyone
     // (training: the prologue's six encoding-plane stores per row tile were issued after all three units' pieces)
     wait_vm<pieces_per_wave<NS>(1) + pieces_per_wave<NS>(2) + (SAVE ? 6 * RT : 0)>();
     __syncthreads();
+#ifdef RR_TRACE
+    if (blockIdx.x == (RR_TRACE) && tid == 0) g_rr_trace[6] = clock64();
+#endif
     h16x8 carry[PFD][NS];
     {
         constexpr Unit d0 = unit_desc(NS, 0);
@@ -839,7 +869,7 @@ int launch(const FwdArgs& a, hipStream_t st) {
 
 #ifdef RR_TRACE
 extern "C" int plnerf_debug_rr_trace(unsigned long long* out8) {
-    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(plnerf_rr::g_rr_trace), 8 * sizeof(unsigned long long));
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(plnerf_rr::g_rr_trace), 128 * sizeof(unsigned long long));
 }
 #endif
 
