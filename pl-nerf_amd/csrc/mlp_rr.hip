@@ -434,6 +434,29 @@ __device__ __forceinline__ unsigned or_halves(const unsigned w) {      // w | (t
     const u32x2 s = __builtin_amdgcn_permlane32_swap(w, w, false, false);
     return s[0] | s[1];
 }
+// relu bits of a finished slab, from the slab's two hi-plane operand fragments (every half is f16(relu(x)) >= +0, so
+// "x > 0" is "half != 0", the ping-pong kernel's test as well).  Dword q of fragment f holds features
+// 16 f + 8 (q >> 1) + 2 (q & 1) + {0, 1} (+ 4 g); min(half, 1) is the bit, pair by pair:
+//     sum_q  min_u16x2(d_q, {1, 1}) << (8 (q >> 1) + 2 (q & 1))     low halves at their positions, high halves 16 above
+// folded (high part one position up) into 16 bits per fragment, instead of a compare, a select and an OR per value.
+__device__ __forceinline__ unsigned relu_half_word(const h16x8 frag) {
+    const u32x4 d = __builtin_bit_cast(u32x4, frag);
+    const unsigned one = 0x00010001u;
+    unsigned acc = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        // (the instruction itself: written as __builtin_elementwise_min on a two-short vector, this compiler's lowering
+        // -- compares, a byte permute, a multiply -- returned wrong bits; tools/probes/relu_bits_probe.hip checks both)
+        unsigned b;
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(b) : "v"(d[q]), "v"(one));
+        acc |= b << (8 * (q >> 1) + 2 * (q & 1));
+    }
+    return (acc | ((acc >> 16) << 1)) & 0xFFFFu;
+}
+__device__ __forceinline__ unsigned relu_word(const h16x8 f0, const h16x8 f1, const Lane& ln) {
+    const unsigned bits = relu_half_word(f0) | (relu_half_word(f1) << 16);
+    return or_halves(bits << (4 * ln.g));
+}
 
 // ---- epilogue of slab j of layer L in eight chunks (chunk c = accumulator registers 2 c, 2 c + 1 = features
 // 32 j + 8 i + 4 g + r0, + 1 with i = c >> 1, r0 = 2 (c & 1); bias included): ReLU, operand split into one dword per
@@ -501,9 +524,7 @@ __device__ __forceinline__ void epi_chunk(Wave<NS>& w, const int j, const int c,
             // the hi plane IS the saved half plane (f16(x)).  relu bits: x > 0 (a compare and a select per value; the
             // word is assembled at the lane-half-0 positions and moves by 4 g once, in the last chunk)
             if constexpr (L <= 7) {
-                unsigned bits = c == 0 ? 0u : w.mw[j];
-                bits |= (v[0] > 0.0f ? 1u << (8 * i + r0) : 0u) | (v[1] > 0.0f ? 1u << (8 * i + r0 + 1) : 0u);
-                w.mw[j] = c == 7 ? or_halves(bits << (4 * ln.g)) : bits;
+                if (c == 7) w.mw[j] = relu_word(((L % 2 == 0) ? w.X : w.Y)[2 * j][0], ((L % 2 == 0) ? w.X : w.Y)[2 * j + 1][0], ln);
             }
             if (c % 4 == 3) store_frag_tiled(dst[0], plane_ptr(a, L, ln.N) + (size_t)ln.wrow0 * W, W, j, i >> 1, ln);
         }
