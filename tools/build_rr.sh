@@ -4,7 +4,7 @@
 #   bash tools/build_rr.sh <name> -DRR_...      -> tools/_head/librr_<name>.so (git-ignored A/B variant)
 R=/root/repo; C=$R/pl-nerf_amd/csrc
 name=$1; shift
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form"
 if [ -z "$name" ]; then
   cd $C && /opt/rocm/bin/hipcc $FLAGS -c mlp_rr.hip -o mlp_rr.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "error|warning|ScratchSize|VGPRs Spill|AGPRs:|VGPRs:" | grep -v "Spill: 0\|Size \[bytes/lane\]: 0" | sort | uniq -c
 else
