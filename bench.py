@@ -287,9 +287,9 @@ def main():
         peak = PEAK_TFLOPS[a.precision]
         traffic = None
         fwd_kernel = FWD_KERNEL[a.precision]
-        if a.workload == "depth_128_64" and a.precision in ("f16x3", "f16"):
-            # the caller-embedded 57|3 input of the depth variant runs on the ping-pong kernel (mlp_api.hip)
-            fwd_kernel = f"mlp_fwd_pp_kernel<{2 if a.precision == 'f16x3' else 1},true>"
+        if a.workload == "depth_128_64" and a.precision == "f16":
+            # the caller-embedded 57|3 input of the depth variant: plain f16 has no register-resident variant for it
+            fwd_kernel = "mlp_fwd_pp_kernel<1,true>"
         try:   # measured offline with rocprofv3 --pmc (cannot be collected from inside this process)
             t = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json"))).get(a.precision)
             if t and t["rows_per_launch"] == rows_fine and t.get("kernel", fwd_kernel) == fwd_kernel:

@@ -21,13 +21,13 @@ inline bool known(int precision) { return precision >= PLNERF_PREC_FP32 && preci
 inline bool geometry_ok(int input_ch, int input_ch_views) {
     return input_ch >= 1 && input_ch <= lay::PE_K && input_ch_views >= 1 && input_ch_views <= lay::DPE_K;
 }
-// Forward kernels of the half-element modes with the in-kernel encoding.  The split mode (f16x3) runs on the
-// register-resident kernel (mlp_rr.hip), inference (+8...10 %) and training (-4 % per launch); its saved planes leave
-// in the tiled layout of mlp_layout.h, which the weight-gradient stage reads as it is.  The plain mode (f16) uses it
-// for inference (two row tiles per wave: +12 %) and keeps the ping-pong kernel for the training forward (with one
-// MFMA per product and 512 registers in use, the register-resident kernel's plane stores and relu bits are not
-// hidden: 9.0 vs 8.6 ms forward + backward at 8192 x 192 rows).  PLNERF_FWD_KERNEL=rr | pp forces one kernel for
-// everything (A/B measurements, and the test suite's other passes).  Read once.
+// Forward kernels of the half-element modes.  The split mode (f16x3) runs on the register-resident kernel (mlp_rr.hip),
+// inference (+20 % over the ping-pong kernel) and training (-15 % per launch), with the in-kernel encoding or a
+// caller-embedded input; its saved planes leave in the tiled layout of mlp_layout.h, which the weight-gradient stage
+// reads as it is.  The plain mode (f16) uses it for inference with the in-kernel encoding (two row tiles per wave:
+// +18 %) and keeps the ping-pong kernel for the training forward (its 5.3 KB of plane stores per row come out of eight
+// waves per CU there, out of four here: 1.22 vs 1.39 ms) and for embedded inputs.  PLNERF_FWD_KERNEL=rr | pp forces
+// one kernel wherever it exists (A/B measurements, and the test suite's other passes).  Read once.
 inline int forced_kernel() {      // 0 = default split, 1 = rr, 2 = pp
     static const int v = [] {
         const char* e = std::getenv("PLNERF_FWD_KERNEL");
@@ -37,7 +37,8 @@ inline int forced_kernel() {      // 0 = default split, 1 = rr, 2 = pp
     }();
     return v;
 }
-inline bool use_rr(const void* saved, int ns) {
+inline bool use_rr(const void* saved, int ns, bool embedded) {
+    if (embedded && !impl::rr_embedded_ok(ns)) return false;      // a caller-embedded input: split mode only
     return forced_kernel() == 1 || (forced_kernel() == 0 && (ns == 2 || !saved));
 }
 }  // namespace
@@ -84,8 +85,8 @@ extern "C" size_t plnerf_mlp_saved_bytes(int n_rows, int precision) {
 // layout of the 256-wide saved planes the forward of this configuration writes (lay::SV_LAYOUT_*): the backward is
 // told, so that whichever forward kernel ran, the weight-gradient stage reads its planes as they are
 extern "C" int plnerf_mlp_saved_layout(int precision, int has_embedded) {
-    return (f16_of(precision) && !has_embedded && use_rr((const void*)1, ns_of(precision))) ? lay::SV_LAYOUT_TILED
-                                                                                             : lay::SV_LAYOUT_ROWS;
+    return (f16_of(precision) && use_rr((const void*)1, ns_of(precision), has_embedded != 0)) ? lay::SV_LAYOUT_TILED
+                                                                                               : lay::SV_LAYOUT_ROWS;
 }
 
 extern "C" size_t plnerf_mlp_bwd_workspace_bytes(int n_rows, int precision) {
@@ -109,10 +110,10 @@ extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pt
     if (precision == PLNERF_PREC_FP32)
         return impl::f32_fwd(packed, pts, viewdirs, embedded, input_ch, input_ch_views, n_rows, samples_per_ray,
                              raw_out, saved, (hipStream_t)stream);
-    if (f16_of(precision) && !embedded && use_rr(saved, ns_of(precision)))
+    if (f16_of(precision) && use_rr(saved, ns_of(precision), embedded != nullptr))
         return impl::rr_fwd(packed, (const unsigned char*)packed + impl::bf16_packed_bytes(ns_of(precision)),
-                            ns_of(precision), pts, viewdirs, n_rows, samples_per_ray, raw_out, saved,
-                            status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);
+                            ns_of(precision), pts, viewdirs, embedded, input_ch, input_ch_views, n_rows, samples_per_ray,
+                            raw_out, saved, status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);
     return impl::bf16_fwd(packed, ns_of(precision), f16_of(precision), pts, viewdirs, embedded, input_ch,
                           input_ch_views, n_rows, samples_per_ray, raw_out, saved,
                           status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);

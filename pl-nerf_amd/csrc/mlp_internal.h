@@ -38,8 +38,10 @@ int bf16_dgrad(const void* packed, int ns, const float* g_raw, int n_rows, const
 // accumulator layout) appended to the packed buffer of the half modes.
 size_t rr_packed_bytes(int ns);
 int rr_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, void* section, hipStream_t st);
-int rr_fwd(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs, int n_rows,
-           int samples_per_ray, float* raw_out, void* saved, unsigned* status, hipStream_t st);
+bool rr_embedded_ok(int ns);
+int rr_fwd(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs, const float* embedded,
+           int in_ch, int view_ch, int n_rows, int samples_per_ray, float* raw_out, void* saved, unsigned* status,
+           hipStream_t st);
 
 }  // namespace impl
 }  // namespace plnerf

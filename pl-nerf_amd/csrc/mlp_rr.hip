@@ -95,12 +95,13 @@ constexpr int N_LAYERS = 10;        // L0..L7, feature, view layer (= FwdGemm or
 // accumulators of slab s / 2 leave it.  Encoding channels are assigned so that each lane half evaluates whole
 // frequency bands: xyz (63 channels + 1 pad): lane half g, slot t = 8 s + e in 0..31: t < 30: band 5 g + t / 6,
 // function/axis t % 6 (sin x, sin y, sin z, cos x, cos y, cos z, the reference's order); t = 30, 31: x, y | z, pad.
-// Direction (27 + 5 pad): slot t in 0..15: t < 12: band 2 g + t / 6; then x, y, z, pad | four pads.
+// Direction (27 + 5 pad): slot t in 0..15: t < 12: band 2 g + t / 6; then x, y, z, channel 27 | channels 28..31 (the five
+// channels the reference's encoding does not have: zero weights there; a caller-embedded input may use all 32).
 __host__ __device__ constexpr int rr_pe_channel(int g, int t) {
     return t < 30 ? 3 + 6 * (5 * g + t / 6) + t % 6 : (t == 30 ? (g ? 2 : 0) : (g ? PE_K - 1 : 1));
 }
-__host__ __device__ constexpr int rr_dpe_channel(int g, int t) {
-    return t < 12 ? 3 + 6 * (2 * g + t / 6) + t % 6 : ((!g && t < 15) ? t - 12 : DPE_K - 1);
+__host__ __device__ constexpr int rr_dpe_channel(int g, int t) {      // a bijection onto 0 .. 31, like rr_pe_channel onto 0 .. 63
+    return t < 12 ? 3 + 6 * (2 * g + t / 6) + t % 6 : (g ? 28 + (t - 12) : (t < 15 ? t - 12 : 27));
 }
 // padded input index (the `k` of mlp_pack_src.h's fwd_src) held by k-step s, lane half g, element e of GEMM gm
 __host__ __device__ constexpr int rr_k_index(int gm, int s, int g, int e) {
@@ -247,6 +248,8 @@ struct FwdArgs {
     float* raw_out;
     void* saved;
     unsigned* status;       // range status word of the packed buffer
+    const float* embedded;  // caller-supplied encoding [n_rows][in_ch + view_ch] (EMB kernels), else pts / viewdirs
+    int in_ch, view_ch;
 };
 
 // ---- LDS-DMA: 64 lanes x 16 B from global memory to LDS at a wave-uniform address, not visible to hipcc's wait
@@ -309,6 +312,7 @@ struct Wave {
     float amax;                     // largest activation magnitude split into halves so far (range check)
     unsigned mw[8];                 // relu bit words of the layer in flight (training)
     h16x8 hvf[1];                   // the view layer's half fragment being assembled (training)
+    float ud[16];                   // caller-embedded input only: this lane's direction slots, kept for the view layer
 };
 
 // two fp32 values -> one dword (two halves) of the hi plane (+ one of the lo plane) of an operand fragment
@@ -406,6 +410,20 @@ template <int NS>
 __device__ __forceinline__ void encode_dir(Wave<NS>& w, const Lane& ln) {
     float u[16];
     dir_values(w.dx, w.dy, w.dz, ln.g, u);
+#pragma unroll
+    for (int t = 0; t < 16; t += 2) put_split<NS>(w.P[t >> 3], t & 7, u[t], u[t + 1]);
+}
+
+// caller-embedded input: the 32 + 16 slot values of this lane (rr_pe_channel / rr_dpe_channel order) are loaded once per
+// tile (kernel prologue) -- v[] goes into the operand registers P for L0 AND the skip layer (they stay live in between,
+// there is nothing to re-evaluate them from), the direction channels wait in w.ud until the view layer.
+template <int NS>
+__device__ __forceinline__ void split_xyz(Wave<NS>& w, const float (&v)[32]) {
+#pragma unroll
+    for (int t = 0; t < 32; t += 2) put_split<NS>(w.P[t >> 3], t & 7, v[t], v[t + 1]);
+}
+template <int NS>
+__device__ __forceinline__ void split_dir(Wave<NS>& w, const float (&u)[16]) {
 #pragma unroll
     for (int t = 0; t < 16; t += 2) put_split<NS>(w.P[t >> 3], t & 7, u[t], u[t + 1]);
 }
@@ -674,7 +692,7 @@ __device__ __forceinline__ void run_steps(Wave<NS> (&w)[RT], h16x8 (&af)[PFD + 1
 // unit U + 1, the barrier makes all pieces visible (and proves that every wave has left unit U - 1, whose slot unit
 // U + 3 may now overwrite).  Side work dealt out over the products: the pending epilogues (the slabs completed by the
 // previous unit, eight chunks per slab and row tile), the DMA pieces of unit U + 3.
-template <int NS, int RT, bool SAVE, int U>
+template <int NS, int RT, bool SAVE, bool EMB, int U>
 __device__ __forceinline__ void run_unit(Wave<NS> (&w)[RT], h16x8 (&carry)[PFD][NS], const FwdArgs& a, const Lane (&ln)[RT],
                                          const unsigned lds_base) {
     constexpr Unit d = unit_desc(NS, U);
@@ -684,8 +702,11 @@ __device__ __forceinline__ void run_unit(Wave<NS> (&w)[RT], h16x8 (&carry)[PFD][
 #endif
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-        if constexpr (d.first && d.j0 == 0 && L == 5) encode_xyz<NS>(w[rt], ln[rt]);
-        if constexpr (d.first && d.j0 == 0 && L == 9) encode_dir<NS>(w[rt], ln[rt]);
+        if constexpr (d.first && d.j0 == 0 && L == 5 && !EMB) encode_xyz<NS>(w[rt], ln[rt]);      // (EMB: P still holds it)
+        if constexpr (d.first && d.j0 == 0 && L == 9) {
+            if constexpr (EMB) split_dir<NS>(w[rt], w[rt].ud);
+            else encode_dir<NS>(w[rt], ln[rt]);
+        }
         if constexpr (d.first && U == 0) {      // (every later unit's accumulators are set up inside the unit before it)
 #pragma unroll
             for (int sl = 0; sl < d.nj; ++sl) init_acc<NS, L>(w[rt], d.j0 + sl, ln[rt]);
@@ -704,12 +725,12 @@ __device__ __forceinline__ void run_unit(Wave<NS> (&w)[RT], h16x8 (&carry)[PFD][
         for (int s = 0; s < NS; ++s) carry[p][s] = af[(NSTEP + p) % (PFD + 1)][s];
 }
 
-template <int NS, int RT, bool SAVE, int U>
+template <int NS, int RT, bool SAVE, bool EMB, int U>
 __device__ __forceinline__ void run_units(Wave<NS> (&w)[RT], h16x8 (&carry)[PFD][NS], const FwdArgs& a, const Lane (&ln)[RT],
                                           const unsigned lds_base) {
     if constexpr (U < n_units(NS)) {
-        run_unit<NS, RT, SAVE, U>(w, carry, a, ln, lds_base);
-        run_units<NS, RT, SAVE, U + 1>(w, carry, a, ln, lds_base);
+        run_unit<NS, RT, SAVE, EMB, U>(w, carry, a, ln, lds_base);
+        run_units<NS, RT, SAVE, EMB, U + 1>(w, carry, a, ln, lds_base);
     }
 }
 
@@ -719,7 +740,7 @@ constexpr int HEAD_PIECES = 16;
 static_assert(HEAD_PIECES * 1024 >= (int)HEAD_BYTES && HEAD_PIECES % 4 == 0, "head block DMA");
 constexpr size_t rr_lds_bytes() { return (size_t)NSLOTS * SLOT_BYTES + (size_t)HEAD_PIECES * 1024; }
 
-template <int NS, bool SAVE>
+template <int NS, bool SAVE, bool EMB>
 __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
     constexpr int RT = row_tiles(NS);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -754,14 +775,32 @@ __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
     // drain the DMA queue behind them); then the head block and the first three units' weights, all by DMA.  One
     // counted wait below covers the inputs: they are older than every DMA piece.
     float in6[RT][6];
+    float ev[EMB ? RT : 1][32], eu[EMB ? RT : 1][16];      // caller-embedded input: this lane's slot values
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-        const float* pp = a.pts + 3 * (size_t)ln[rt].grow;
-        const float* pv = a.viewdirs + 3 * (size_t)(ln[rt].grow / a.spr);
+        if constexpr (EMB) {
+            // slot (g, t) <- channel rr_pe_channel(g, t) / rr_dpe_channel(g, t) of the row; channels the network does not
+            // have (in_ch < 64, view_ch < 32) are read from the row's first element and zeroed after the wait
+            const float* row = a.embedded + (size_t)ln[rt].grow * (size_t)(a.in_ch + a.view_ch);
+            const int g = ln[rt].g;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            asm volatile("global_load_dword %0, %1, off" : "=v"(in6[rt][c]) : "v"(pp + c) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "=v"(in6[rt][3 + c]) : "v"(pv + c) : "memory");
+            for (int t = 0; t < 32; ++t) {
+                const int ch = t < 30 ? 3 + 30 * g + t : (t == 30 ? (g ? 2 : 0) : (g ? PE_K - 1 : 1));      // = rr_pe_channel(g, t)
+                asm volatile("global_load_dword %0, %1, off" : "=v"(ev[rt][t]) : "v"(row + (ch < a.in_ch ? ch : 0)) : "memory");
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int ch = t < 12 ? 3 + 12 * g + t : (g ? 28 + (t - 12) : (t < 15 ? t - 12 : 27));        // = rr_dpe_channel(g, t)
+                asm volatile("global_load_dword %0, %1, off" : "=v"(eu[rt][t]) : "v"(row + (ch < a.view_ch ? a.in_ch + ch : 0)) : "memory");
+            }
+        } else {
+            const float* pp = a.pts + 3 * (size_t)ln[rt].grow;
+            const float* pv = a.viewdirs + 3 * (size_t)(ln[rt].grow / a.spr);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                asm volatile("global_load_dword %0, %1, off" : "=v"(in6[rt][c]) : "v"(pp + c) : "memory");
+                asm volatile("global_load_dword %0, %1, off" : "=v"(in6[rt][3 + c]) : "v"(pv + c) : "memory");
+            }
         }
     }
 #pragma unroll
@@ -773,9 +812,26 @@ __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
     issue_unit<NS, 2>(a, lds_base, wave, lane);
     wait_vm<HEAD_PIECES / 4 + pieces_per_wave<NS>(0) + pieces_per_wave<NS>(1) + pieces_per_wave<NS>(2)>();
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int rt = 0; rt < RT; ++rt) {      // (nothing reads them above the wait)
+        if constexpr (EMB) {
+            const int g = ln[rt].g;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) asm volatile("" : "+v"(in6[rt][c]));      // (nothing reads them above the wait)
+            for (int t = 0; t < 32; ++t) {
+                asm volatile("" : "+v"(ev[rt][t]));
+                const int ch = t < 30 ? 3 + 30 * g + t : (t == 30 ? (g ? 2 : 0) : (g ? PE_K - 1 : 1));
+                ev[rt][t] = ch < a.in_ch ? ev[rt][t] : 0.0f;
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                asm volatile("" : "+v"(eu[rt][t]));
+                const int ch = t < 12 ? 3 + 12 * g + t : (g ? 28 + (t - 12) : (t < 15 ? t - 12 : 27));
+                eu[rt][t] = ch < a.view_ch ? eu[rt][t] : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) asm volatile("" : "+v"(in6[rt][c]));
+        }
+    }
 #ifdef RR_TRACE
     if (blockIdx.x == (RR_TRACE) && tid == 0) g_rr_trace[4] = clock64();
 #endif
@@ -788,26 +844,35 @@ __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
         // ---- this lane's row: position and view direction stay in six registers; the encodings (32 of the 64 xyz
         // channels, 16 of the 32 direction channels per lane) are evaluated where they are consumed -- before L0 and
         // again before the skip layer, before the view layer -- rather than held in 48 registers across the network ----
-        wt.px = in6[rt][0]; wt.py = in6[rt][1]; wt.pz = in6[rt][2];
-        wt.dx = in6[rt][3]; wt.dy = in6[rt][4]; wt.dz = in6[rt][5];
-        encode_xyz<NS>(wt, lt);
+        if constexpr (EMB) {
+            split_xyz<NS>(wt, ev[rt]);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) wt.ud[t] = eu[rt][t];
+        } else {
+            wt.px = in6[rt][0]; wt.py = in6[rt][1]; wt.pz = in6[rt][2];
+            wt.dx = in6[rt][3]; wt.dy = in6[rt][4]; wt.dz = in6[rt][5];
+            encode_xyz<NS>(wt, lt);
+        }
         if constexpr (SAVE) {
             // saved encoding planes, original channel order: through this wave's corner of ring slot 3 (unused until
             // unit 3's weights arrive, which the sync point of unit 0 -- after every wave's prologue -- requests); the
             // wave's row tiles take turns (LDS operations of one wave execute in order)
             float v[32], u[16];
-            xyz_values(wt.px, wt.py, wt.pz, lt.g, v);
-            dir_values(wt.dx, wt.dy, wt.dz, lt.g, u);
+            if constexpr (EMB) {
+#pragma unroll
+                for (int t = 0; t < 32; ++t) v[t] = ev[rt][t];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) u[t] = eu[rt][t];
+            } else {
+                xyz_values(wt.px, wt.py, wt.pz, lt.g, v);
+                dir_values(wt.dx, wt.dy, wt.dz, lt.g, u);
+            }
             _Float16* st = reinterpret_cast<_Float16*>(smem + 3 * SLOT_BYTES) + (size_t)wave * 32 * (PE_K + DPE_K);
             _Float16* prow = st + (size_t)(lane & 31) * (PE_K + DPE_K);
 #pragma unroll
             for (int t = 0; t < 32; ++t) prow[rr_pe_channel(lt.g, t)] = (_Float16)v[t];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) prow[PE_K + rr_dpe_channel(lt.g, t)] = (_Float16)u[t];   // (pad slots: zeros)
-            if (lt.g) {
-#pragma unroll
-                for (int c = DIR_CH; c < DPE_K - 1; ++c) prow[PE_K + c] = (_Float16)0.0f;      // channels no slot maps to
-            }
+            for (int t = 0; t < 16; ++t) prow[PE_K + rr_dpe_channel(lt.g, t)] = (_Float16)u[t];   // (every channel has a slot)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             _Float16* pe_plane = plane_ptr(a, 0, lt.N) + (size_t)SV_PE_OFF * lt.N;
@@ -843,7 +908,7 @@ __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
 #pragma unroll
         for (int p = 0; p < PFD; ++p) load_a<NS>(carry[p], ln[0], 0, d0.nk, p % d0.nj, p / d0.nj);
     }
-    run_units<NS, RT, SAVE, 0>(w, carry, a, ln, lds_base);
+    run_units<NS, RT, SAVE, EMB, 0>(w, carry, a, ln, lds_base);
     // the last unit's slab epilogues (view layer) and the heads
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -874,13 +939,13 @@ __global__ __launch_bounds__(RR_THREADS) void mlp_fwd_rr_kernel(FwdArgs a) {
     }
 }
 
-template <int NS, bool SAVE>
+template <int NS, bool SAVE, bool EMB>
 int launch(const FwdArgs& a, hipStream_t st) {
     const size_t lds = rr_lds_bytes();
     constexpr int ROWS = RR_ROWS * row_tiles(NS);
-    (void)hipFuncSetAttribute((const void*)mlp_fwd_rr_kernel<NS, SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)mlp_fwd_rr_kernel<NS, SAVE, EMB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-    hipLaunchKernelGGL((mlp_fwd_rr_kernel<NS, SAVE>), dim3((a.n_rows + ROWS - 1) / ROWS), dim3(RR_THREADS), lds, st, a);
+    hipLaunchKernelGGL((mlp_fwd_rr_kernel<NS, SAVE, EMB>), dim3((a.n_rows + ROWS - 1) / ROWS), dim3(RR_THREADS), lds, st, a);
     PLNERF_CHECK_LAUNCH();
     return PLNERF_OK;
 }
@@ -918,12 +983,19 @@ int rr_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, void* se
     return PLNERF_OK;
 }
 
-int rr_fwd(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs, int n_rows,
-           int samples_per_ray, float* raw_out, void* saved, unsigned* status, hipStream_t st) {
+// `embedded` (a caller-supplied encoding, [n_rows][in_ch + view_ch]) is served in split mode only (ns == 2: rr_embedded_ok)
+bool rr_embedded_ok(int ns) { return ns == 2; }
+int rr_fwd(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs, const float* embedded,
+           int in_ch, int view_ch, int n_rows, int samples_per_ray, float* raw_out, void* saved, unsigned* status,
+           hipStream_t st) {
     plnerf_rr::FwdArgs a{packed, section, pts, viewdirs, n_rows, samples_per_ray < 1 ? 1 : samples_per_ray, raw_out, saved,
-                         status};
-    if (ns == 1) return saved ? plnerf_rr::launch<1, true>(a, st) : plnerf_rr::launch<1, false>(a, st);
-    return saved ? plnerf_rr::launch<2, true>(a, st) : plnerf_rr::launch<2, false>(a, st);
+                         status, embedded, in_ch, view_ch};
+    if (embedded) {
+        if (ns != 2) return PLNERF_EINVAL;
+        return saved ? plnerf_rr::launch<2, true, true>(a, st) : plnerf_rr::launch<2, false, true>(a, st);
+    }
+    if (ns == 1) return saved ? plnerf_rr::launch<1, true, false>(a, st) : plnerf_rr::launch<1, false, false>(a, st);
+    return saved ? plnerf_rr::launch<2, true, false>(a, st) : plnerf_rr::launch<2, false, false>(a, st);
 }
 
 }  // namespace impl
