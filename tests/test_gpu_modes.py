@@ -381,6 +381,70 @@ def test_register_resident_and_ping_pong_forward_kernels_agree(P, tmp_path):
             assert cos >= 0.99
 
 
+# ----------------------------------------------------------------------------- caller-embedded inputs, split kernel
+@pytest.mark.parametrize("widths", [(63, 27), (57, 3), (64, 32), (5, 1)])
+def test_embedded_inputs_on_the_split_kernel(P, widths):
+    """NeRF.forward's own signature -- a caller-supplied encoding [N, input_ch + input_ch_views] -- in f16x3: served by
+    the register-resident kernel (slot values loaded per tile, mlp_rr.hip) for every width the C ABI admits, the
+    depth-supervised variant's 57 | 3 among them.  A ragged row count (three 128-row tiles, the last one cut inside a
+    wave), forward against the fp32 oracle at the 1e-5 contract, all 24 gradient tensors at the split modes' bound."""
+    in_ch, view_ch = widths
+    torch.manual_seed(23)
+    ref_net = P.NeRF(D=8, W=256, input_ch=in_ch, input_ch_views=view_ch, output_ch=5, skips=[4], use_viewdirs=True)
+    sd = {k: v.detach().clone() for k, v in ref_net.state_dict().items()}
+    gen = torch.Generator().manual_seed(29)
+    N = 300
+    emb = torch.randn(N, in_ch + view_ch, generator=gen)
+    cot = torch.randn(N, 4, generator=gen)
+
+    def oracle(sd_, pre=None):          # the trunk of oracle.nerf_mlp with the input widths read off the weights
+        F = torch.nn.functional
+        x, v = emb[:, :in_ch], emb[:, in_ch:]
+        h = x
+        for i in range(8):
+            z = F.linear(h, sd_[f"pts_linears.{i}.weight"], sd_[f"pts_linears.{i}.bias"])
+            if pre is not None:
+                pre.append(z.detach())
+            h = F.relu(z)
+            if i == 4:
+                h = torch.cat([x, h], -1)
+        sigma = F.linear(h, sd_["alpha_linear.weight"], sd_["alpha_linear.bias"])
+        feat = F.linear(h, sd_["feature_linear.weight"], sd_["feature_linear.bias"])
+        zv = F.linear(torch.cat([feat, v], -1), sd_["views_linears.0.weight"], sd_["views_linears.0.bias"])
+        if pre is not None:
+            pre.append(zv.detach())
+        return torch.cat([F.linear(F.relu(zv), sd_["rgb_linear.weight"], sd_["rgb_linear.bias"]), sigma], -1)
+
+    sd_o = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    emb, cot = emb.double(), cot.double()
+    # ReLU makes the parameter gradients discontinuous: a pre-activation within the forward's rounding error of zero may
+    # take the other branch and move gradient entries by O(1e-2) (DESIGN.md section 6).  Rows with such a value get a
+    # zero cotangent; the comparison is sharp on the rest.
+    pre = []
+    oracle({k: v.double() for k, v in sd.items()}, pre)
+    near = torch.stack([(z.abs() < 1e-5).any(-1) for z in pre]).any(0)
+    cot = cot * (~near).double()[:, None]
+    ref = oracle(sd_o)
+    (ref * cot).sum().backward()
+    net = P.NeRF(D=8, W=256, input_ch=in_ch, input_ch_views=view_ch, output_ch=5, skips=[4], use_viewdirs=True,
+                 precision="f16x3")
+    net.load_state_dict(sd)
+    net = net.to(dev())
+    out = net(g(emb.float()))
+    err = maxdiff(out, ref.detach().float())
+    print(f"embedded {in_ch}|{view_ch}, f16x3: forward max err {err:.2e}")
+    assert err <= 1e-5 * max(1.0, float(ref.detach().abs().max()))
+    (out * g(cot.float())).sum().backward()
+    worst = 0.0
+    for name, prm in net.named_parameters():
+        r = sd_o[name].grad.float()
+        scale = max(float(r.abs().max()), 1e-6)
+        worst = max(worst, maxdiff(prm.grad, r) / scale)
+    print(f"embedded {in_ch}|{view_ch}, f16x3: worst gradient error / max|g| over the 24 tensors {worst:.2e} "
+          f"({int(near.sum())} of {N} rows muted)")
+    assert worst <= 6e-3
+
+
 # ----------------------------------------------------------------------------- range of the half modes
 def test_half_modes_flag_range_overflow_and_withhold_the_step(P):
     """`f16x3` / `f16` clamp at the IEEE-half maximum (65,504).  A forward that gets there must not pass silently: the
