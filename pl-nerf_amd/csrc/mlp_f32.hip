@@ -643,7 +643,11 @@ __device__ __forceinline__ wh8 tr_frag_tiled(const _Float16* stage, int srows, i
 template <int O, int I, int NI, bool DEEP, bool TILED = false>
 __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& job, unsigned char* smem_raw) {
     static_assert(!TILED || I == W, "the tiled layout exists for the 256-wide planes");
+    // the A operand: a half dz plane -- TILED too when it is 256 wide (written by the dgrad kernel's MFMA epilogues,
+    // mlp_layout.h); dz_view (O = 128) is row-major
+    constexpr bool ATILED = O == W;
     constexpr int NO = 2, WI = 2, KST = TR_STEPS, SROWS = TR_ROWS * KST, SPLANE = SROWS * TR_RS;
+    static_assert(32 * (SROWS * 8 + TRB_PAD) <= SPLANE, "a tiled stage fits the operand's LDS plane");
     constexpr int A_C8 = O / 8, B_C8 = I / 8;
     constexpr int SA = SROWS * A_C8 / 512;                  // A chunks per thread and stage: 4 (O = 256) or 2
     constexpr int B_CHUNKS = SROWS * B_C8;                  // B chunks per stage: 2048 (I = 256), 512 (64), 256 (32)
@@ -662,11 +666,12 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
     const int split = blockIdx.y;
     const int m_begin = split * a.rows_per_split;
     const int m_end = min(a.n_rows, m_begin + a.rows_per_split);
-    int a_row[SA], a_col[SA];
+    int a_row[SA], a_col[SA];        // ATILED: row of the stage | piece block of the chunk (as b_row / b_col below)
 #pragma unroll
     for (int j = 0; j < SA; ++j) {
         const int q = tid + 512 * j;
-        a_row[j] = q / A_C8; a_col[j] = (q % A_C8) * 8;
+        if (ATILED) { a_row[j] = (q >> 10) * 32 + (q & 31); a_col[j] = (q & 1023) >> 5; }
+        else { a_row[j] = q / A_C8; a_col[j] = (q % A_C8) * 8; }
     }
     int b_row[SB], b_col[SB];        // TILED: row of the stage | piece block of the chunk
 #pragma unroll
@@ -682,17 +687,26 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
     const bool b_owner = tid < B_THREADS;
     struct Set { wh8 a[SA]; wh8 b[SB]; };
     Set s0, s1;      // (s1 only in the DEEP variant)
-    float bs[8];
+    // bias partial = column sums of the dz stage.  Row-major A: a thread's chunks share one chunk column.  Tiled A: its
+    // chunks alternate between two piece blocks (q and q + 512: blocks pb and pb + 16), one set of sums each.
+    float bs[ATILED ? 2 : 1][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bs[e] = 0.0f;
+    for (int h = 0; h < (ATILED ? 2 : 1); ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[h][e] = 0.0f;
     const wh8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     // (the zeroing select lives in stash, not here: a consumer right behind the load would put the new stage's
     // latency back in front of this stage's MFMAs)
     auto fetch = [&](Set& s, const int m) {
         const int last = m_end - 1;
 #pragma unroll
-        for (int j = 0; j < SA; ++j)
-            s.a[j] = *reinterpret_cast<const wh8*>(Ag + (size_t)min(m + a_row[j], last) * O + a_col[j]);
+        for (int j = 0; j < SA; ++j) {
+            if (ATILED)     // (m is a multiple of 32; a tile past the plane re-reads the last one and is zeroed in stash)
+                s.a[j] = *reinterpret_cast<const wh8*>(
+                    Ag + ((size_t)min((m >> 5) + (a_row[j] >> 5), last_tile) * 1024 + a_col[j] * 32 + (a_row[j] & 31)) * 8);
+            else
+                s.a[j] = *reinterpret_cast<const wh8*>(Ag + (size_t)min(m + a_row[j], last) * O + a_col[j]);
+        }
 #pragma unroll
         for (int j = 0; j < SB; ++j) {
             if (TILED)      // (m is a multiple of 64: a stage is two whole tiles; a tile past the plane re-reads the last one)
@@ -708,9 +722,10 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
 #pragma unroll
         for (int j = 0; j < SA; ++j) {
             const wh8 v = m + a_row[j] < m_end ? s.a[j] : zero8;
-            *reinterpret_cast<wh8*>(A0 + a_row[j] * TR_RS + a_col[j]) = v;
+            _Float16* dst = ATILED ? A0 + (size_t)a_col[j] * (SROWS * 8 + TRB_PAD) + a_row[j] * 8 : A0 + a_row[j] * TR_RS + a_col[j];
+            *reinterpret_cast<wh8*>(dst) = v;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bs[e] += (float)v[e];
+            for (int e = 0; e < 8; ++e) bs[ATILED ? (j & 1) : 0][e] += (float)v[e];
         }
         if (b_owner) {
 #pragma unroll
@@ -731,7 +746,8 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
         for (int k = 0; k < KST; ++k) {
             wh8 af[NO];
 #pragma unroll
-            for (int o = 0; o < NO; ++o) af[o] = tr_frag(A0 + k * TR_PLANE, lane, o_base + 32 * o);
+            for (int o = 0; o < NO; ++o)
+                af[o] = ATILED ? tr_frag_tiled(A0, SROWS, k, lane, o_base + 32 * o) : tr_frag(A0 + k * TR_PLANE, lane, o_base + 32 * o);
 #pragma unroll
             for (int i = 0; i < NI; ++i) {      // one B fragment live at a time (register budget of the two sets)
                 const wh8 bf = TILED ? tr_frag_tiled(B0, SROWS, k, lane, i_base + 32 * i)
@@ -790,11 +806,23 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
     }
     if (job.bias_off >= 0) {
         // bias partial = column sums of the dz slabs: a thread's slots share one chunk column (512 % A_C8 == 0)
-        float* red = reinterpret_cast<float*>(smem_raw);      // [512 / A_C8 rows][O] floats, reusing the LDS
-        constexpr int RED_ROWS = 512 / A_C8;
+        float* red = reinterpret_cast<float*>(smem_raw);      // [RED_ROWS][O] floats, reusing the LDS
+        constexpr int RED_ROWS = ATILED ? 32 : 512 / A_C8;
         __syncthreads();
+        if (ATILED) {
+            // chunk of piece block pb = (slab, fragment, lane half g): halves e = features 32 slab + 16 fragment + 4 g + (e & 3)
+            // + 8 (e >> 2) of one row; the 32 threads (tid & 31) of a block pair each hold partial sums over their rows
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[a_row[0] * O + a_col[0] + e] = bs[e];
+            for (int h = 0; h < 2; ++h) {
+                const int pb = a_col[h];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    red[(tid & 31) * O + 32 * (pb >> 2) + 16 * ((pb >> 1) & 1) + 4 * (pb & 1) + (e & 3) + 8 * (e >> 2)] = bs[ATILED ? h : 0][e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[a_row[0] * O + a_col[0] + e] = bs[0][e];
+        }
         __syncthreads();
         for (int f = tid; f < O; f += 512) {
             float sum = 0.0f;
@@ -1137,15 +1165,16 @@ int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, co
     int splits_thin = splits;
     if (h16) { splits_thin = (n_rows + 1023) / 1024; splits_thin = splits_thin < 1 ? 1 : (splits_thin > 85 ? 85 : splits_thin); }
     int rps_thin = (n_rows + splits_thin - 1) / splits_thin;
-    rps_thin = (rps_thin + 15) & ~15;
+    rps_thin = h16 ? (rps_thin + 63) & ~63 : (rps_thin + 15) & ~15;      // (half: whole tiles of the tiled dz planes)
     const unsigned char* sv = (const unsigned char*)saved;
     const unsigned char* dz = (const unsigned char*)dzv;
     auto splane = [&](int p) { return (const void*)(sv + (size_t)p * W * NS_ * es); };
-    auto dplane = [&](int p) { return (const void*)(dz + (size_t)p * W * N * es); };
+    const size_t ND = h16 ? dz_rows(N) : N;        // row stride of the dz planes (half: padded to the dgrad kernel's tiles)
+    auto dplane = [&](int p) { return (const void*)(dz + (size_t)p * W * ND * es); };
     const void* hv_plane = sv + (size_t)SV_HV_OFF * NS_ * es;
     const void* pe_plane = sv + (size_t)SV_PE_OFF * NS_ * es;
     const void* dpe_plane = sv + (size_t)SV_DPE_OFF * NS_ * es;
-    const void* dzv_plane = dz + (size_t)DZ_V_OFF * N * es;
+    const void* dzv_plane = dz + (size_t)DZ_V_OFF * ND * es;
     {
         // main: 256 x 256 layer jobs + the view layer's feature columns
         WgradArgs a{};
