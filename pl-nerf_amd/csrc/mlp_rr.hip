@@ -443,8 +443,10 @@ __device__ __forceinline__ void store_frag_tiled(const h16x8 f, _Float16* tile, 
     // Unconditional: the planes' rows are padded to whole workgroup tiles (SV_ROW_PAD, mlp_layout.h), so every wave of
     // every workgroup has a tile -- rows past n_rows land in padding nobody reads.  A store that may or may not be
     // issued could not be counted in the hand-over waits (stores_in_unit), and its branch sat in the MFMA stream.
+    // (non-temporal: the backward reads the planes after the whole launch has written 4.2 GB past them; -1 % on the
+    // training forward against plain stores, same box)
     if (!(RR_ABLATE & 16))
-        *reinterpret_cast<h16x8*>(tile + ((size_t)((j * 2 + frag) * 64 + ln.lane)) * 8) = f;
+        __builtin_nontemporal_store(f, reinterpret_cast<h16x8*>(tile + ((size_t)((j * 2 + frag) * 64 + ln.lane)) * 8));
     (void)width;
 }
 
