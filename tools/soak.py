@@ -1,39 +1,40 @@
-"""Soak run of the training step: N steps of bench.py's configuration, reporting loss finiteness, step-time drift and
-whether device memory grows (allocator high-water marks at 10 % and 100 % of the run)."""
-import argparse, json, os, sys, tempfile, time
+"""Soak run of the training step: N steps of bench.py's own step (device-side pixel choice .. Adam), reporting loss
+finiteness, step-time drift, the range status word, and whether device memory grows (allocator high-water marks at
+10 % and 100 % of the run)."""
+import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-import plnerf_amd as P
 import bench
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--steps", type=int, default=2000)
+ap.add_argument("--steps", type=int, default=3000)
 ap.add_argument("--precision", default="f16x3")
-a = ap.parse_args()
-dev = torch.device("cuda:0")
-ck = tempfile.mkdtemp(); os.makedirs(os.path.join(ck, "exp"))
-args = bench.make_args(argparse.Namespace(precision=a.precision, n_samples=64, n_importance=128, rays=4096), ck)
-torch.manual_seed(0)
-so = sys.stdout; sys.stdout = open(os.devnull, "w")
-kw, _, _, _, opt, opt_c = P.create_nerf(args, device=dev)
-sys.stdout = so
-batch, target, K = P.rays.synthetic_blender_rays(4096, seed=0, device="cpu")
-rays = (batch[0].to(dev), batch[1].to(dev)); target = target.to(dev)
+ap.add_argument("--workload", default="blender_64_128")
+sa = ap.parse_args()
+sys.argv = [sys.argv[0], "--precision", sa.precision, "--workload", sa.workload]
+a = bench.parse()
+ns, ni, _ = bench.WORKLOADS[a.workload]
+a.n_samples, a.n_importance = ns, ni
+import plnerf_amd as P
+dev = torch.device("cuda", 0)
+scene = bench.Scene(P, a.workload, a.views, dev)
+step, nets = bench.build_step(P, a, a.precision, scene, dev, 0, 1, False)
 losses, marks, times = [], {}, []
-t0 = time.perf_counter()
-for i in range(a.steps):
-    rgb, disp, acc, extras = P.render(800, 800, K, chunk=32768, rays=rays, near=2.0, far=6.0, retraw=True, **kw)
-    opt.zero_grad(); opt_c.zero_grad()
-    loss = P.img2mse(rgb, target) + P.img2mse(extras["rgb0"], target)
-    loss.backward(); opt.step(); opt_c.step()
-    if i % 100 == 99 or i == 0:
-        torch.cuda.synchronize()
-        losses.append(float(loss.detach())); times.append(time.perf_counter() - t0)
-    if i in (a.steps // 10, a.steps - 1):
-        marks[i] = torch.cuda.max_memory_allocated() / 1e9
+block = max(sa.steps // 10, 1)
 torch.cuda.synchronize()
-per = [(times[k + 1] - times[k]) / 100 * 1e3 for k in range(1, len(times) - 1)]
-print(json.dumps({"precision": a.precision, "steps": a.steps, "loss_first": losses[0], "loss_last": losses[-1],
-                  "all_finite": all(l == l and abs(l) < 1e9 for l in losses),
-                  "ms_per_step_first_100s": round(per[0], 3), "ms_per_step_last_100s": round(per[-1], 3),
-                  "max_mem_GB": {str(k): round(v, 3) for k, v in marks.items()}}))
+t0 = time.perf_counter()
+for i in range(sa.steps):
+    loss = step(i)
+    if i % block == block - 1:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        times.append(1e3 * (t1 - t0) / block)
+        losses.append(float(loss))
+        marks[i + 1] = torch.cuda.max_memory_allocated() / 2**30
+        t0 = time.perf_counter()
+status = [int(n.range_status()) if hasattr(n, "range_status") else 0 for n in nets]
+print(json.dumps({"what": f"soak, {sa.workload}, {sa.precision}", "steps": sa.steps,
+                  "ms_per_step_by_tenth": [round(t, 3) for t in times],
+                  "loss_by_tenth": [round(l, 6) for l in losses], "all_finite": all(l == l and abs(l) < 1e30 for l in losses),
+                  "max_memory_allocated_GiB_by_tenth": {k: round(v, 3) for k, v in marks.items()},
+                  "range_status_words": status}))
