@@ -257,7 +257,8 @@ size_t plnerf_mlp_bwd_workspace_bytes(int n_rows, int precision);
 /* Layout tag of the saved state the forward of this configuration writes (has_embedded: the call passes `embedded`
  * instead of pts / viewdirs).  Opaque to the caller: hand it to plnerf_mlp_bwd with the saved buffer.  (The half
  * modes have two forward kernels; one stores its 256-wide planes row-major, the other in 32-row tiles of the MFMA
- * accumulator layout, which the weight-gradient stage reads directly.) */
+ * accumulator layout, which the weight-gradient stage reads directly.  Rows of the saved state are padded to a
+ * multiple of 256: plnerf_mlp_saved_bytes accounts for it.) */
 int plnerf_mlp_saved_layout(int precision, int has_embedded);
 
 /* Forward.  Either (pts [n_rows,3] AND viewdirs [n_rows/samples_per_ray, 3]) with

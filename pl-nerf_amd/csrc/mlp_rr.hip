@@ -23,8 +23,15 @@
 //     kernels read that layout as it is.
 //
 // Per unit (one 32-feature slab x 16 k-steps in split mode) a wave issues 48 MFMAs, 32 ds_read_b128 of weight
-// fragments shared by all four waves, and the previous slab's ~70 VALU epilogue; HBM sees pts in, raw (and the saved
+// fragments shared by all four waves, and the previous slab's ~45 VALU epilogue; HBM sees pts in, raw (and the saved
 // planes) out.
+//
+// With one wave per SIMD nothing hides an instruction except the MFMA in flight ahead of it, so the stream is kept
+// lean on purpose (each item a measured step): lo halves by v_fma_mix, SGPR-based DMA
+// addresses, three opaque LDS base registers so that every DS access is base + immediate, no LDS read whose result
+// the next MFMA waits for (accumulator set-up and head weights are requested ahead), no branch and no uncounted store
+// in the stream (saved rows are padded to whole workgroup tiles; stores share vmcnt with the weight DMA and are
+// counted in the hand-over waits), non-temporal plane stores, accumulators in architectural VGPRs (Makefile).
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
