@@ -1,0 +1,8 @@
+// One instantiation of the register-resident forward (mlp_rr_body.inc) per translation unit: see mlp_rr.hip.
+#include "mlp_rr_body.inc"
+
+namespace plnerf {
+namespace impl {
+int rr_launch_2_train(const plnerf_rr::FwdArgs& a, hipStream_t st) { return plnerf_rr::launch<2, true, false>(a, st); }
+}  // namespace impl
+}  // namespace plnerf

@@ -6,9 +6,9 @@ R=/root/repo; C=$R/pl-nerf_amd/csrc
 name=$1; shift
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form"
 if [ -z "$name" ]; then
-  cd $C && /opt/rocm/bin/hipcc $FLAGS -c mlp_rr.hip -o mlp_rr.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "error|warning|ScratchSize|VGPRs Spill|AGPRs:|VGPRs:" | grep -v "Spill: 0\|Size \[bytes/lane\]: 0" | sort | uniq -c
+  cd $C && /opt/rocm/bin/hipcc $FLAGS -DRR_SINGLE_TU -c mlp_rr.hip -o /tmp/rr/v/mlp_rr_report.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "error|warning|ScratchSize|VGPRs Spill|AGPRs:|VGPRs:" | grep -v "Spill: 0\|Size \[bytes/lane\]: 0" | sort | uniq -c
 else
   mkdir -p /tmp/rr/v $R/tools/_head
-  cd $C && /opt/rocm/bin/hipcc $FLAGS "$@" -c mlp_rr.hip -o /tmp/rr/v/mlp_rr_$name.o 2>&1 | grep -E "error" 
+  cd $C && /opt/rocm/bin/hipcc $FLAGS "$@" -DRR_SINGLE_TU -c mlp_rr.hip -o /tmp/rr/v/mlp_rr_$name.o 2>&1 | grep -E "error" 
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/_head/librr_$name.so capi.o quad.o sampler.o epilogue.o step.o mlp_api.o mlp_f32.o mlp_bf16.o /tmp/rr/v/mlp_rr_$name.o
 fi
