@@ -1,5 +1,5 @@
 #!/bin/bash
-# What each ingredient of the register-resident forward (csrc/mlp_rr.hip) costs: the kernel rebuilt with RR_ABLATE bits
+# What each ingredient of the register-resident forward (csrc/mlp_rr_body.inc) costs: the kernel rebuilt with RR_ABLATE bits
 # (results WRONG by construction; tools builds only) and timed against the product library in one gpurun call.
 #   here:        bash tools/ablate_rr.sh build     -> tools/_head/librr_abl_{nodma,nolds,nobar,noepi,all}.so
 #   on the GPU:  bash tools/ablate_rr.sh           -> gpurun_out/rr_ablation.txt

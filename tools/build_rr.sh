@@ -1,6 +1,6 @@
 #!/bin/bash
 # (Re)compile csrc/mlp_rr.hip with extra flags and link a library variant.
-#   bash tools/build_rr.sh                      -> csrc/mlp_rr.o (the product object), resource report
+#   bash tools/build_rr.sh                      -> resource report of all six instantiations (single translation unit)
 #   bash tools/build_rr.sh <name> -DRR_...      -> tools/_head/librr_<name>.so (git-ignored A/B variant)
 R=/root/repo; C=$R/pl-nerf_amd/csrc
 name=$1; shift

@@ -24,7 +24,7 @@ for prec in sys.argv[1:] or ["f16x3", "f16"]:
           f"rows per tile {128 if prec.endswith('x3') else 256}; MFMA floor {3480 * 32 if prec.endswith('x3') else 2320 * 32} cycles = {100.0 * (3480 * 32 if prec.endswith('x3') else 2320 * 32) / cyc:.1f} % of the walk")
     # per unit: shader cycles from the start of unit u to the start of unit u + 1, against the unit's MFMA issue time
     split = prec.endswith("x3")
-    units = []          # (layer, products) in schedule order, as csrc/mlp_rr.hip's unit_desc lays them out
+    units = []          # (layer, products) in schedule order, as csrc/mlp_rr_body.inc's unit_desc lays them out
     ks = [4, 16, 16, 16, 16, 20, 16, 16, 16, 18]
     slabs = [8, 8, 8, 8, 8, 8, 8, 8, 8, 4]
     for l in range(10):
