@@ -58,6 +58,16 @@ def test_buffer_size_queries(built):
     assert L.plnerf_mlp_saved_bytes(1000, 3) == 1024 * (2528 * 2 + 272)      # 16-bit modes: half planes + relu masks, rows padded to whole 256-row workgroup tiles
     assert L.plnerf_mlp_bwd_workspace_bytes(1000, 3) < L.plnerf_mlp_bwd_workspace_bytes(1000, 0)
     assert L.plnerf_mlp_bwd_workspace_bytes(1000, 0) > 1000 * 2432 * 4
+    # half dz planes: rows padded to the dgrad kernel's 64-row tiles (tiled planes, mlp_layout.h)
+    assert L.plnerf_mlp_bwd_workspace_bytes(961, 3) == L.plnerf_mlp_bwd_workspace_bytes(1024, 3)
+    assert L.plnerf_mlp_bwd_workspace_bytes(1025, 3) - L.plnerf_mlp_bwd_workspace_bytes(1024, 3) == 64 * 2432 * 2
+    assert L.plnerf_mlp_saved_bytes(1025, 3) - L.plnerf_mlp_saved_bytes(1024, 3) == 256 * (2528 * 2 + 272)
+    # the layout tag a caller hands back to plnerf_mlp_bwd: the split half mode writes tiled planes, with or without a
+    # caller-embedded input; exact fp32 and the bf16-element modes row-major
+    assert L.plnerf_mlp_saved_layout(0, 0) == 0 and L.plnerf_mlp_saved_layout(1, 0) == 0
+    if not os.environ.get("PLNERF_FWD_KERNEL"):
+        assert L.plnerf_mlp_saved_layout(3, 0) == 1 and L.plnerf_mlp_saved_layout(3, 1) == 1
+        assert L.plnerf_mlp_saved_layout(4, 0) == 0 and L.plnerf_mlp_saved_layout(4, 1) == 0
     assert L.plnerf_mlp_packed_bytes(7) == 0
 
 
