@@ -2,6 +2,8 @@
 # One gpurun call that regenerates round 2's evidence from the working tree:
 #   gpurun --timeout 2400 -- 'bash tools/refresh_profiles_r02.sh'
 # then, in the build container: copy gpurun_out/r02/* over the matching profiles/r02_* files.
+# (The tile-walk trace needs tools/_head/librr_trace.so: `bash tools/build_rr.sh trace -DRR_TRACE=100` before the call;
+#  tools/pmc_sq.sh, tools/soak.py, tools/train_curve.py and tools/ablate_rr.sh produce the remaining r02 files.)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/r02
 mkdir -p $out
