@@ -249,6 +249,34 @@ def test_train_step_from_a_view(P):
         assert maxdiff(p, q) <= 3e-4      # (six Adam steps apart: the two routes normalise view directions differently)
 
 
+def test_training_step_is_bitwise_reproducible(P):
+    """Two runs of the benchmark-sized step (4096 rays x (64 + 128) samples, f16x3) from the same weights and seed end in
+    bit-identical parameters, step after step.  Every reduction of the path is ordered (split-K partials summed in a
+    fixed order, no floating-point atomics) and every draw is a counter-based function of (seed, step, ray), so anything
+    else -- a weight fragment read before its DMA landed, a plane overwritten early -- would show up here as a
+    difference: the test is the race detector for the register-resident kernel's counted vmcnt waits."""
+    H = W = 200
+    K = [[280.0, 0, W / 2], [0, 280.0, H / 2], [0, 0, 1]]
+    gen = torch.Generator().manual_seed(3)
+    image = g(torch.rand(H, W, 3, generator=gen))
+    poses = [P.rays.pose_spherical(-180.0 + 90.0 * i, -30.0, 4.0)[:3, :4] for i in range(4)]
+
+    def run():
+        args, kw, opt, opt_c = _nets(P)
+        ts = P.TrainStep(args, kw, opt, opt_c, distributed=False, seed=11)
+        digests = []
+        for step in range(8):
+            loss, _ = ts.step_view(H, W, K, poses[step % 4], image, near=2.0, far=6.0, n_rand=4096)
+            digests.append((float(loss), [p.detach().clone() for n in ts.nets for p in n.parameters()]))
+        return digests
+
+    a, b = run(), run()
+    for step, ((la, pa), (lb, pb)) in enumerate(zip(a, b)):
+        assert la == lb, (step, la, lb)
+        for x, y in zip(pa, pb):
+            assert torch.equal(x, y), f"parameters differ after step {step}"
+
+
 # ----------------------------------------------------------------------------- data parallel step, two ranks on one GPU
 _DP_GPU_WORKER = r'''
 import os, sys, tempfile, torch, torch.distributed as dist
