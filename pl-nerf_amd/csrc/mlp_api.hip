@@ -47,7 +47,7 @@ inline bool use_rr(const void* saved, int ns, bool embedded) {
 inline size_t sections_bytes(int precision) {
     if (precision == PLNERF_PREC_FP32) return impl::f32_packed_bytes();
     if (ns_of(precision))
-        return impl::bf16_packed_bytes(ns_of(precision)) + (f16_of(precision) ? impl::rr_packed_bytes(ns_of(precision)) : 0);
+        return impl::bf16_packed_bytes(ns_of(precision)) + impl::rr_packed_bytes(ns_of(precision));      // (+ the register-resident section)
     return 0;
 }
 inline unsigned* status_word(void* packed, int precision) {
@@ -70,9 +70,10 @@ extern "C" int plnerf_mlp_pack_weights(const float* const* params, int precision
     if (precision == PLNERF_PREC_FP32) return impl::f32_pack(params, input_ch, input_ch_views, packed, (hipStream_t)stream);
     const int rc = impl::bf16_pack(params, input_ch, input_ch_views, ns_of(precision), f16_of(precision), packed,
                                    status_word(packed, precision), (hipStream_t)stream);
-    if (rc || !f16_of(precision)) return rc;
-    return impl::rr_pack(params, input_ch, input_ch_views, ns_of(precision),
-                         (unsigned char*)packed + impl::bf16_packed_bytes(ns_of(precision)), (hipStream_t)stream);
+    if (rc) return rc;
+    void* rr_section = (unsigned char*)packed + impl::bf16_packed_bytes(ns_of(precision));
+    return f16_of(precision) ? impl::rr_pack(params, input_ch, input_ch_views, ns_of(precision), rr_section, (hipStream_t)stream)
+                             : impl::rr_pack_bf16(params, input_ch, input_ch_views, ns_of(precision), rr_section, (hipStream_t)stream);
 }
 
 // fp32 mode: fp32 planes; 16-bit MFMA modes: half planes (mlp_layout.h)
@@ -114,6 +115,10 @@ extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pt
         return impl::rr_fwd(packed, (const unsigned char*)packed + impl::bf16_packed_bytes(ns_of(precision)),
                             ns_of(precision), pts, viewdirs, embedded, input_ch, input_ch_views, n_rows, samples_per_ray,
                             raw_out, saved, status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);
+    // bf16 elements: the register-resident kernel serves inference with the in-kernel encoding (unless pp is forced)
+    if (!f16_of(precision) && !saved && !embedded && forced_kernel() != 2)
+        return impl::rr_fwd_bf16(packed, (const unsigned char*)packed + impl::bf16_packed_bytes(ns_of(precision)),
+                                 ns_of(precision), pts, viewdirs, n_rows, samples_per_ray, raw_out, (hipStream_t)stream);
     return impl::bf16_fwd(packed, ns_of(precision), f16_of(precision), pts, viewdirs, embedded, input_ch,
                           input_ch_views, n_rows, samples_per_ray, raw_out, saved,
                           status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);

@@ -38,10 +38,26 @@ int bf16_dgrad(const void* packed, int ns, const float* g_raw, int n_rows, const
 // accumulator layout) appended to the packed buffer of the half modes.
 size_t rr_packed_bytes(int ns);
 int rr_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, void* section, hipStream_t st);
+struct RrFwdArgs {
+    const void* packed;     // head block at the start
+    const void* wrr;        // the register-resident section of the packed weights
+    const float* pts;
+    const float* viewdirs;
+    int n_rows, spr;
+    float* raw_out;
+    void* saved;
+    unsigned* status;       // range status word of the packed buffer
+    const float* embedded;  // caller-supplied encoding [n_rows][in_ch + view_ch] (EMB kernels), else pts / viewdirs
+    int in_ch, view_ch;
+};
 bool rr_embedded_ok(int ns);
 int rr_fwd(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs, const float* embedded,
            int in_ch, int view_ch, int n_rows, int samples_per_ray, float* raw_out, void* saved, unsigned* status,
            hipStream_t st);
+// the same kernel on bf16 elements (mlp_rr_body.inc compiled with RR_BF16): inference with the in-kernel encoding
+int rr_pack_bf16(const float* const* params, int xyz_ch, int dir_ch, int ns, void* section, hipStream_t st);
+int rr_fwd_bf16(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs, int n_rows,
+                int samples_per_ray, float* raw_out, hipStream_t st);
 
 }  // namespace impl
 }  // namespace plnerf

@@ -23,9 +23,9 @@ namespace impl {
 // kernel<NS, SAVE, EMB> behind a plain function each
 #ifdef RR_SINGLE_TU
 #define RR_LAUNCH(name, NS, SAVE, EMB) \
-    int name(const plnerf_rr::FwdArgs& a, hipStream_t st) { return plnerf_rr::launch<NS, SAVE, EMB>(a, st); }
+    int name(const RrFwdArgs& a, hipStream_t st) { return plnerf_rr::launch<NS, SAVE, EMB>(a, st); }
 #else
-#define RR_LAUNCH(name, NS, SAVE, EMB) int name(const plnerf_rr::FwdArgs& a, hipStream_t st);
+#define RR_LAUNCH(name, NS, SAVE, EMB) int name(const RrFwdArgs& a, hipStream_t st);
 #endif
 RR_LAUNCH(rr_launch_1_infer, 1, false, false)
 RR_LAUNCH(rr_launch_1_train, 1, true, false)
@@ -53,7 +53,7 @@ bool rr_embedded_ok(int ns) { return ns == 2; }
 int rr_fwd(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs, const float* embedded,
            int in_ch, int view_ch, int n_rows, int samples_per_ray, float* raw_out, void* saved, unsigned* status,
            hipStream_t st) {
-    plnerf_rr::FwdArgs a{packed, section, pts, viewdirs, n_rows, samples_per_ray < 1 ? 1 : samples_per_ray, raw_out, saved,
+    RrFwdArgs a{packed, section, pts, viewdirs, n_rows, samples_per_ray < 1 ? 1 : samples_per_ray, raw_out, saved,
                          status, embedded, in_ch, view_ch};
     if (embedded) {
         if (ns != 2) return PLNERF_EINVAL;

@@ -3,6 +3,6 @@
 
 namespace plnerf {
 namespace impl {
-int rr_launch_2_infer_emb(const plnerf_rr::FwdArgs& a, hipStream_t st) { return plnerf_rr::launch<2, false, true>(a, st); }
+int rr_launch_2_infer_emb(const RrFwdArgs& a, hipStream_t st) { return plnerf_rr::launch<2, false, true>(a, st); }
 }  // namespace impl
 }  // namespace plnerf

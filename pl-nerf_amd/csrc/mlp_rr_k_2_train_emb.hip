@@ -3,6 +3,6 @@
 
 namespace plnerf {
 namespace impl {
-int rr_launch_2_train_emb(const plnerf_rr::FwdArgs& a, hipStream_t st) { return plnerf_rr::launch<2, true, true>(a, st); }
+int rr_launch_2_train_emb(const RrFwdArgs& a, hipStream_t st) { return plnerf_rr::launch<2, true, true>(a, st); }
 }  // namespace impl
 }  // namespace plnerf
