@@ -44,10 +44,10 @@ MFMA_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "bf16": 1, "f16x3": 3, "f16": 1}
 DTYPE = {"fp32": "f32", "bf16x3": "bf16x3 (3-term bf16 split, f32 accumulate)", "bf16": "bf16 (f32 accumulate)",
          "f16x3": "f16x3 (3-term f16 split, f32 accumulate)", "f16": "f16 (f32 accumulate)"}
 FWD_KERNEL = {"fp32": "mlp_fwd_f32_kernel<2,true>", "f16x3": "mlp_fwd_rr_kernel<2,true>", "f16": "mlp_fwd_pp_kernel<1,true>",
-              "bf16x3": "mlp_fwd_pp_kernel<2,true>", "bf16": "mlp_fwd_pp_kernel<1,true>"}
-# (PLNERF_FWD_KERNEL=pp in the environment puts f16x3 back on mlp_fwd_pp_kernel<2,true>; the line then names that one)
+              "bf16x3": "mlp_fwd_rr_kernel<2,true> [bf16 elements]", "bf16": "mlp_fwd_pp_kernel<1,true>"}
+# (PLNERF_FWD_KERNEL=pp in the environment puts the split modes back on mlp_fwd_pp_kernel<2,true>; the line then names that one)
 if os.environ.get("PLNERF_FWD_KERNEL") == "pp":
-    FWD_KERNEL["f16x3"] = "mlp_fwd_pp_kernel<2,true>"
+    FWD_KERNEL["f16x3"] = FWD_KERNEL["bf16x3"] = "mlp_fwd_pp_kernel<2,true>"
 elif os.environ.get("PLNERF_FWD_KERNEL") == "rr":
     FWD_KERNEL["f16"] = "mlp_fwd_rr_kernel<1,true>"
 
@@ -287,9 +287,10 @@ def main():
         peak = PEAK_TFLOPS[a.precision]
         traffic = None
         fwd_kernel = FWD_KERNEL[a.precision]
-        if a.workload == "depth_128_64" and a.precision == "f16":
-            # the caller-embedded 57|3 input of the depth variant: plain f16 has no register-resident variant for it
-            fwd_kernel = "mlp_fwd_pp_kernel<1,true>"
+        if a.workload == "depth_128_64" and a.precision != "f16x3":
+            # the caller-embedded 57|3 input of the depth variant: only f16x3 has a register-resident variant for it
+            fwd_kernel = "mlp_fwd_f32_kernel<2,true>" if a.precision == "fp32" else \
+                f"mlp_fwd_pp_kernel<{2 if a.precision == 'bf16x3' else 1},true>"
         try:   # measured offline with rocprofv3 --pmc (cannot be collected from inside this process)
             t = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json"))).get(a.precision)
             if t and t["rows_per_launch"] == rows_fine and t.get("kernel", fwd_kernel) == fwd_kernel:

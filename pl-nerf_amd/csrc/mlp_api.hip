@@ -41,6 +41,11 @@ inline bool use_rr(const void* saved, int ns, bool embedded) {
     if (embedded && !impl::rr_embedded_ok(ns)) return false;      // a caller-embedded input: split mode only
     return forced_kernel() == 1 || (forced_kernel() == 0 && (ns == 2 || !saved));
 }
+// bf16 elements: inference of both modes and the training forward of the split mode, in-kernel encoding only
+inline bool use_rr_bf16(const void* saved, int ns, bool embedded) {
+    if (embedded || forced_kernel() == 2) return false;
+    return !saved || ns == 2;
+}
 }  // namespace
 
 // bytes of the weight sections; the 16-byte status block follows them
@@ -86,8 +91,8 @@ extern "C" size_t plnerf_mlp_saved_bytes(int n_rows, int precision) {
 // layout of the 256-wide saved planes the forward of this configuration writes (lay::SV_LAYOUT_*): the backward is
 // told, so that whichever forward kernel ran, the weight-gradient stage reads its planes as they are
 extern "C" int plnerf_mlp_saved_layout(int precision, int has_embedded) {
-    return (f16_of(precision) && use_rr((const void*)1, ns_of(precision), has_embedded != 0)) ? lay::SV_LAYOUT_TILED
-                                                                                               : lay::SV_LAYOUT_ROWS;
+    if (f16_of(precision)) return use_rr((const void*)1, ns_of(precision), has_embedded != 0) ? lay::SV_LAYOUT_TILED : lay::SV_LAYOUT_ROWS;
+    return use_rr_bf16((const void*)1, ns_of(precision), has_embedded != 0) ? lay::SV_LAYOUT_TILED : lay::SV_LAYOUT_ROWS;
 }
 
 extern "C" size_t plnerf_mlp_bwd_workspace_bytes(int n_rows, int precision) {
@@ -116,9 +121,9 @@ extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pt
                             ns_of(precision), pts, viewdirs, embedded, input_ch, input_ch_views, n_rows, samples_per_ray,
                             raw_out, saved, status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);
     // bf16 elements: the register-resident kernel serves inference with the in-kernel encoding (unless pp is forced)
-    if (!f16_of(precision) && !saved && !embedded && forced_kernel() != 2)
+    if (!f16_of(precision) && use_rr_bf16(saved, ns_of(precision), embedded != nullptr))
         return impl::rr_fwd_bf16(packed, (const unsigned char*)packed + impl::bf16_packed_bytes(ns_of(precision)),
-                                 ns_of(precision), pts, viewdirs, n_rows, samples_per_ray, raw_out, (hipStream_t)stream);
+                                 ns_of(precision), pts, viewdirs, n_rows, samples_per_ray, raw_out, saved, (hipStream_t)stream);
     return impl::bf16_fwd(packed, ns_of(precision), f16_of(precision), pts, viewdirs, embedded, input_ch,
                           input_ch_views, n_rows, samples_per_ray, raw_out, saved,
                           status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);

@@ -8,6 +8,7 @@ namespace impl {
 
 int rr_launch_bf16_1_infer(const RrFwdArgs& a, hipStream_t st);
 int rr_launch_bf16_2_infer(const RrFwdArgs& a, hipStream_t st);
+int rr_launch_bf16_2_train(const RrFwdArgs& a, hipStream_t st);
 
 int rr_pack_bf16(const float* const* params, int xyz_ch, int dir_ch, int ns, void* section, hipStream_t st) {
     ParamPtrs P;
@@ -21,9 +22,10 @@ int rr_pack_bf16(const float* const* params, int xyz_ch, int dir_ch, int ns, voi
 }
 
 int rr_fwd_bf16(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs, int n_rows,
-                int samples_per_ray, float* raw_out, hipStream_t st) {
-    RrFwdArgs a{packed, section, pts, viewdirs, n_rows, samples_per_ray < 1 ? 1 : samples_per_ray, raw_out, nullptr,
+                int samples_per_ray, float* raw_out, void* saved, hipStream_t st) {
+    RrFwdArgs a{packed, section, pts, viewdirs, n_rows, samples_per_ray < 1 ? 1 : samples_per_ray, raw_out, saved,
                 nullptr, nullptr, 0, 0};
+    if (saved) return ns == 2 ? rr_launch_bf16_2_train(a, st) : PLNERF_EINVAL;      // (training: split mode only)
     return ns == 1 ? rr_launch_bf16_1_infer(a, st) : rr_launch_bf16_2_infer(a, st);
 }
 
