@@ -41,10 +41,10 @@ inline bool use_rr(const void* saved, int ns, bool embedded) {
     if (embedded && !impl::rr_embedded_ok(ns)) return false;      // a caller-embedded input: split mode only
     return forced_kernel() == 1 || (forced_kernel() == 0 && (ns == 2 || !saved));
 }
-// bf16 elements: inference of both modes and the training forward of the split mode, in-kernel encoding only
+// bf16 elements: inference of both modes; the split mode also for the training forward and caller-embedded inputs
 inline bool use_rr_bf16(const void* saved, int ns, bool embedded) {
-    if (embedded || forced_kernel() == 2) return false;
-    return !saved || ns == 2;
+    if (forced_kernel() == 2) return false;
+    return ns == 2 || (!saved && !embedded);
 }
 }  // namespace
 
@@ -123,7 +123,8 @@ extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pt
     // bf16 elements: the register-resident kernel serves inference with the in-kernel encoding (unless pp is forced)
     if (!f16_of(precision) && use_rr_bf16(saved, ns_of(precision), embedded != nullptr))
         return impl::rr_fwd_bf16(packed, (const unsigned char*)packed + impl::bf16_packed_bytes(ns_of(precision)),
-                                 ns_of(precision), pts, viewdirs, n_rows, samples_per_ray, raw_out, saved, (hipStream_t)stream);
+                                 ns_of(precision), pts, viewdirs, embedded, input_ch, input_ch_views, n_rows, samples_per_ray,
+                                 raw_out, saved, (hipStream_t)stream);
     return impl::bf16_fwd(packed, ns_of(precision), f16_of(precision), pts, viewdirs, embedded, input_ch,
                           input_ch_views, n_rows, samples_per_ray, raw_out, saved,
                           status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);

@@ -54,11 +54,12 @@ bool rr_embedded_ok(int ns);
 int rr_fwd(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs, const float* embedded,
            int in_ch, int view_ch, int n_rows, int samples_per_ray, float* raw_out, void* saved, unsigned* status,
            hipStream_t st);
-// the same kernel on bf16 elements (mlp_rr_body.inc compiled with RR_BF16), in-kernel encoding: inference, and the
-// training forward of the split mode (saved != NULL needs ns == 2)
+// the same kernel on bf16 elements (mlp_rr_body.inc compiled with RR_BF16): inference, and -- split mode only -- the
+// training forward and caller-embedded inputs
 int rr_pack_bf16(const float* const* params, int xyz_ch, int dir_ch, int ns, void* section, hipStream_t st);
-int rr_fwd_bf16(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs, int n_rows,
-                int samples_per_ray, float* raw_out, void* saved, hipStream_t st);
+int rr_fwd_bf16(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs,
+                const float* embedded, int in_ch, int view_ch, int n_rows, int samples_per_ray, float* raw_out, void* saved,
+                hipStream_t st);
 
 }  // namespace impl
 }  // namespace plnerf

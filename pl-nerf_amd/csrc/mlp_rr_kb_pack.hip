@@ -9,6 +9,8 @@ namespace impl {
 int rr_launch_bf16_1_infer(const RrFwdArgs& a, hipStream_t st);
 int rr_launch_bf16_2_infer(const RrFwdArgs& a, hipStream_t st);
 int rr_launch_bf16_2_train(const RrFwdArgs& a, hipStream_t st);
+int rr_launch_bf16_2_infer_emb(const RrFwdArgs& a, hipStream_t st);
+int rr_launch_bf16_2_train_emb(const RrFwdArgs& a, hipStream_t st);
 
 int rr_pack_bf16(const float* const* params, int xyz_ch, int dir_ch, int ns, void* section, hipStream_t st) {
     ParamPtrs P;
@@ -21,10 +23,15 @@ int rr_pack_bf16(const float* const* params, int xyz_ch, int dir_ch, int ns, voi
     return PLNERF_OK;
 }
 
-int rr_fwd_bf16(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs, int n_rows,
-                int samples_per_ray, float* raw_out, void* saved, hipStream_t st) {
+int rr_fwd_bf16(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs,
+                const float* embedded, int in_ch, int view_ch, int n_rows, int samples_per_ray, float* raw_out, void* saved,
+                hipStream_t st) {
     RrFwdArgs a{packed, section, pts, viewdirs, n_rows, samples_per_ray < 1 ? 1 : samples_per_ray, raw_out, saved,
-                nullptr, nullptr, 0, 0};
+                nullptr, embedded, in_ch, view_ch};
+    if (embedded) {      // (split mode only, like the IEEE-half build)
+        if (ns != 2) return PLNERF_EINVAL;
+        return saved ? rr_launch_bf16_2_train_emb(a, st) : rr_launch_bf16_2_infer_emb(a, st);
+    }
     if (saved) return ns == 2 ? rr_launch_bf16_2_train(a, st) : PLNERF_EINVAL;      // (training: split mode only)
     return ns == 1 ? rr_launch_bf16_1_infer(a, st) : rr_launch_bf16_2_infer(a, st);
 }

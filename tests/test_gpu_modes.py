@@ -384,10 +384,11 @@ def test_register_resident_and_ping_pong_forward_kernels_agree(P, tmp_path):
 
 
 # ----------------------------------------------------------------------------- caller-embedded inputs, split kernel
+@pytest.mark.parametrize("precision", SPLIT_MODES)
 @pytest.mark.parametrize("widths", [(63, 27), (57, 3), (64, 32), (5, 1)])
-def test_embedded_inputs_on_the_split_kernel(P, widths):
-    """NeRF.forward's own signature -- a caller-supplied encoding [N, input_ch + input_ch_views] -- in f16x3: served by
-    the register-resident kernel (slot values loaded per tile, mlp_rr.hip) for every width the C ABI admits, the
+def test_embedded_inputs_on_the_split_kernel(P, widths, precision):
+    """NeRF.forward's own signature -- a caller-supplied encoding [N, input_ch + input_ch_views] -- in the split modes:
+    served by the register-resident kernel (slot values loaded per tile, mlp_rr.hip) for every width the C ABI admits, the
     depth-supervised variant's 57 | 3 among them.  A ragged row count (three 128-row tiles, the last one cut inside a
     wave), forward against the fp32 oracle at the 1e-5 contract, all 24 gradient tensors at the split modes' bound."""
     in_ch, view_ch = widths
@@ -429,12 +430,12 @@ def test_embedded_inputs_on_the_split_kernel(P, widths):
     ref = oracle(sd_o)
     (ref * cot).sum().backward()
     net = P.NeRF(D=8, W=256, input_ch=in_ch, input_ch_views=view_ch, output_ch=5, skips=[4], use_viewdirs=True,
-                 precision="f16x3")
+                 precision=precision)
     net.load_state_dict(sd)
     net = net.to(dev())
     out = net(g(emb.float()))
     err = maxdiff(out, ref.detach().float())
-    print(f"embedded {in_ch}|{view_ch}, f16x3: forward max err {err:.2e}")
+    print(f"embedded {in_ch}|{view_ch}, {precision}: forward max err {err:.2e}")
     assert err <= 1e-5 * max(1.0, float(ref.detach().abs().max()))
     (out * g(cot.float())).sum().backward()
     worst = 0.0
@@ -442,7 +443,7 @@ def test_embedded_inputs_on_the_split_kernel(P, widths):
         r = sd_o[name].grad.float()
         scale = max(float(r.abs().max()), 1e-6)
         worst = max(worst, maxdiff(prm.grad, r) / scale)
-    print(f"embedded {in_ch}|{view_ch}, f16x3: worst gradient error / max|g| over the 24 tensors {worst:.2e} "
+    print(f"embedded {in_ch}|{view_ch}, {precision}: worst gradient error / max|g| over the 24 tensors {worst:.2e} "
           f"({int(near.sum())} of {N} rows muted)")
     assert worst <= 6e-3
 

@@ -62,12 +62,12 @@ def test_buffer_size_queries(built):
     assert L.plnerf_mlp_bwd_workspace_bytes(961, 3) == L.plnerf_mlp_bwd_workspace_bytes(1024, 3)
     assert L.plnerf_mlp_bwd_workspace_bytes(1025, 3) - L.plnerf_mlp_bwd_workspace_bytes(1024, 3) == 64 * 2432 * 2
     assert L.plnerf_mlp_saved_bytes(1025, 3) - L.plnerf_mlp_saved_bytes(1024, 3) == 256 * (2528 * 2 + 272)
-    # the layout tag a caller hands back to plnerf_mlp_bwd: the split modes write tiled planes (f16x3 with or without a
-    # caller-embedded input, bf16x3 with the in-kernel encoding); exact fp32 and the plain 16-bit modes row-major
+    # the layout tag a caller hands back to plnerf_mlp_bwd: the split modes write tiled planes (with or without a
+    # caller-embedded input); exact fp32 and the plain 16-bit modes row-major
     assert L.plnerf_mlp_saved_layout(0, 0) == 0 and L.plnerf_mlp_saved_layout(0, 1) == 0
     if not os.environ.get("PLNERF_FWD_KERNEL"):
         assert L.plnerf_mlp_saved_layout(3, 0) == 1 and L.plnerf_mlp_saved_layout(3, 1) == 1
-        assert L.plnerf_mlp_saved_layout(1, 0) == 1 and L.plnerf_mlp_saved_layout(1, 1) == 0
+        assert L.plnerf_mlp_saved_layout(1, 0) == 1 and L.plnerf_mlp_saved_layout(1, 1) == 1
         assert L.plnerf_mlp_saved_layout(4, 0) == 0 and L.plnerf_mlp_saved_layout(4, 1) == 0
         assert L.plnerf_mlp_saved_layout(2, 0) == 0 and L.plnerf_mlp_saved_layout(2, 1) == 0
     assert L.plnerf_mlp_packed_bytes(7) == 0
