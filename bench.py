@@ -287,10 +287,9 @@ def main():
         peak = PEAK_TFLOPS[a.precision]
         traffic = None
         fwd_kernel = FWD_KERNEL[a.precision]
-        if a.workload == "depth_128_64" and a.precision != "f16x3":
-            # the caller-embedded 57|3 input of the depth variant: only f16x3 has a register-resident variant for it
-            fwd_kernel = "mlp_fwd_f32_kernel<2,true>" if a.precision == "fp32" else \
-                f"mlp_fwd_pp_kernel<{2 if a.precision == 'bf16x3' else 1},true>"
+        if a.workload == "depth_128_64" and a.precision in ("f16", "bf16"):
+            # the caller-embedded 57|3 input of the depth variant: the plain modes have no register-resident variant for it
+            fwd_kernel = "mlp_fwd_pp_kernel<1,true>"
         try:   # measured offline with rocprofv3 --pmc (cannot be collected from inside this process)
             t = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json"))).get(a.precision)
             if t and t["rows_per_launch"] == rows_fine and t.get("kernel", fwd_kernel) == fwd_kernel:
