@@ -311,7 +311,7 @@ class MlpFn(torch.autograd.Function):
             ev[0].record()
         L.check(L.lib().plnerf_mlp_fwd(
             L.dptr(packed, "packed"), prec, L.dptr(pts_c, "pts"), L.dptr(vd_c, "viewdirs"),
-            L.dptr(emb_c, "embedded"), int(net.input_ch), int(net.view_ch), n_rows, int(spr), L.dptr(raw),
+            L.dptr(emb_c, "embedded"), int(net.input_ch), int(net.hip_view_ch), n_rows, int(spr), L.dptr(raw),
             L.dptr(saved), L.stream()), "plnerf_mlp_fwd")
         if timer is not None:
             ev[1].record()
@@ -344,7 +344,7 @@ class MlpFn(torch.autograd.Function):
             ev = timer.bracket(f"mlp_bwd[{n_rows}]")
             ev[0].record()
         L.check(L.lib().plnerf_mlp_bwd(
-            L.dptr(ctx.packed), prec, L.dptr(g, "g_raw"), int(ctx.net.input_ch), int(ctx.net.view_ch), n_rows,
+            L.dptr(ctx.packed), prec, L.dptr(g, "g_raw"), int(ctx.net.input_ch), int(ctx.net.hip_view_ch), n_rows,
             L.dptr(ctx.saved_acts), ctx.saved_layout, L.dptr(ws), L.ptr_table(grads, "grads"), L.stream()),
             "plnerf_mlp_bwd")
         if timer is not None:

@@ -115,12 +115,16 @@ class NeRF(nn.Module):
 
     # -- HIP plumbing ---------------------------------------------------------------
     def is_supported(self):
-        return (self.D == SUPPORTED["D"] and self.W == SUPPORTED["W"] and
-                1 <= self.input_ch <= MAX_INPUT_CH and 1 <= self.view_ch <= MAX_VIEW_CH and
-                list(self.skips) == SUPPORTED["skips"] and self.use_viewdirs)
+        trunk = (self.D == SUPPORTED["D"] and self.W == SUPPORTED["W"] and 1 <= self.input_ch <= MAX_INPUT_CH and
+                 list(self.skips) == SUPPORTED["skips"])
+        if not self.use_viewdirs:      # (see param_list; the reference ignores the view columns of x, if any)
+            return trunk
+        return trunk and 1 <= self.view_ch <= MAX_VIEW_CH
 
     def has_fused_encoding(self):
         """True when the kernel's own positional encoding (3 + 6*10 | 3 + 6*4 channels) is this network's."""
+        if not self.use_viewdirs:
+            return self.input_ch == SUPPORTED["input_ch"]
         return (self.input_ch == SUPPORTED["input_ch"] and self.input_ch_views == SUPPORTED["input_ch_views"] and
                 self.input_ch_cam == 0)
 
@@ -133,14 +137,52 @@ class NeRF(nn.Module):
                 f"input_ch={self.input_ch}, input_ch_views={self.input_ch_views}, input_ch_cam={self.input_ch_cam}, "
                 f"skips={self.skips}, use_viewdirs={self.use_viewdirs}.  There is no generic/CPU fallback.")
 
+    def _outputs(self, raw):
+        """The kernels' four channels as the reference module returns them: with output_linear the reference has
+        output_ch columns (5 when N_importance > 0, run_plnerf.py:424); raw2outputs reads the first four, the rest is
+        returned as zeros."""
+        raw = self._activate(raw)
+        if not self.use_viewdirs and self.output_linear.out_features > 4:
+            raw = torch.cat([raw, raw.new_zeros(*raw.shape[:-1], self.output_linear.out_features - 4)], -1)
+        return raw
+
     def _activate(self, raw):
         if self.density_activation == "softplus":   # depth_supervised_exps/model/run_nerf_helpers.py:200
             return torch.cat([raw[..., :3], F.softplus(raw[..., 3:], beta=10)], -1)
         return raw
 
     def param_list(self):
-        """The 24 parameter tensors in state_dict order (the C ABI's `params[24]`)."""
-        return list(self.parameters())
+        """The 24 parameter tensors in state_dict order (the C ABI's `params[24]`).
+
+        use_viewdirs=False (run_nerf_helpers.py:102-103, 125-126: `output_linear` straight from the trunk) has no kernel
+        of its own: its four outputs are expressed EXACTLY in the view-dependent head the kernels implement --
+        feature rows 0..2 = W_out[rgb], rows 3..5 = -W_out[rgb]; the view layer copies those six features (identity
+        weights, zero direction columns); rgb = relu(F) - relu(-F) + b = F + b; sigma = alpha row = W_out[3] -- with
+        differentiable torch ops, so autograd carries the kernels' 24 gradients back to `output_linear`."""
+        if self.use_viewdirs:
+            return list(self.parameters())
+        W = self.W
+        Wo, bo = self.output_linear.weight, self.output_linear.bias
+        if Wo.shape[0] < 4:
+            raise NotImplementedError("plnerf_amd: output_linear needs at least 4 outputs (rgb, sigma)")
+        key = (str(Wo.device), Wo.dtype)
+        if getattr(self, "_head_consts", None) is None or self._head_consts[0] != key:
+            views_w = torch.zeros(W // 2, W + self.hip_view_ch, device=Wo.device, dtype=Wo.dtype)
+            rgb_w = torch.zeros(3, W // 2, device=Wo.device, dtype=Wo.dtype)
+            for c in range(6):
+                views_w[c, c] = 1.0
+            for c in range(3):
+                rgb_w[c, c], rgb_w[c, 3 + c] = 1.0, -1.0
+            self._head_consts = (key, views_w, Wo.new_zeros(W // 2), rgb_w, Wo.new_zeros(W - 6, W), Wo.new_zeros(W))
+        _, views_w, views_b, rgb_w, pad, feat_b = self._head_consts
+        trunk = [t for l in self.pts_linears for t in (l.weight, l.bias)]
+        return trunk + [views_w, views_b, torch.cat([Wo[0:3], -Wo[0:3], pad], 0), feat_b, Wo[3:4], bo[3:4], rgb_w, bo[0:3]]
+
+    @property
+    def hip_view_ch(self):
+        """Direction channels as the kernels see them: without view directions, the in-kernel encoding's 27 (all of
+        them multiplied by zero weights)."""
+        return self.view_ch if self.use_viewdirs else SUPPORTED["input_ch_views"]
 
     def packed_weights(self):
         """Weights re-laid-out in MFMA fragment order (plnerf_mlp_pack_weights).  Re-packed on EVERY
@@ -156,7 +198,7 @@ class NeRF(nn.Module):
         dev = params[0].device
         flat = [p.detach() for p in params]
         self._ensure_packed(dev, nbytes)
-        L.check(L.lib().plnerf_mlp_pack_weights(L.ptr_table(flat), prec, int(self.input_ch), int(self.view_ch),
+        L.check(L.lib().plnerf_mlp_pack_weights(L.ptr_table(flat), prec, int(self.input_ch), int(self.hip_view_ch),
                                                 L.dptr(self._packed), L.stream()), "plnerf_mlp_pack_weights")
         return self._packed
 
@@ -204,8 +246,10 @@ class NeRF(nn.Module):
         flat = x.reshape(-1, x.shape[-1])
         if flat.shape[-1] != self.input_ch + self.view_ch:
             raise ValueError(f"NeRF.forward expects {self.input_ch + self.view_ch} embedded channels, got {flat.shape[-1]}")
+        if not self.use_viewdirs:      # the kernels' direction channels: zeros (their weights are zero as well)
+            flat = torch.cat([flat[:, :self.input_ch], flat.new_zeros(flat.shape[0], self.hip_view_ch)], -1)
         out = MlpFn.apply(None, None, flat, 1, self, torch.is_grad_enabled(), *self.param_list())
-        return self._activate(out.reshape(*lead, 4))
+        return self._outputs(out.reshape(*lead, 4))
 
     def query(self, pts, viewdirs):
         """Fused entry: pts [R,S,3], viewdirs [R,3] -> raw [R,S,4]; the encoding happens in
@@ -215,5 +259,9 @@ class NeRF(nn.Module):
             raise NotImplementedError("the in-kernel encoding is the reference default (63 | 27 channels); "
                                       "embed on the caller side and use forward()")
         R, S = pts.shape[0], pts.shape[1]
+        if viewdirs is None:
+            if self.use_viewdirs:
+                raise ValueError("this network takes view directions")
+            viewdirs = pts.new_zeros(R, 3)
         out = MlpFn.apply(pts.reshape(-1, 3), viewdirs, None, S, self, torch.is_grad_enabled(), *self.param_list())
-        return self._activate(out.reshape(R, S, 4))
+        return self._outputs(out.reshape(R, S, 4))

@@ -26,9 +26,12 @@ def batchify(fn, chunk):
 
 
 def _fusable(fn, embed_fn, embeddirs_fn, viewdirs):
-    return (isinstance(fn, NeRF) and fn.is_supported() and fn.has_fused_encoding() and viewdirs is not None and
-            isinstance(embed_fn, Embedder) and embed_fn.is_standard(10) and
-            isinstance(embeddirs_fn, Embedder) and embeddirs_fn.is_standard(4))
+    if not (isinstance(fn, NeRF) and fn.is_supported() and fn.has_fused_encoding() and
+            isinstance(embed_fn, Embedder) and embed_fn.is_standard(10)):
+        return False
+    if not fn.use_viewdirs:      # (output_linear on the trunk: the view directions, if any were passed, are not used)
+        return True
+    return viewdirs is not None and isinstance(embeddirs_fn, Embedder) and embeddirs_fn.is_standard(4)
 
 
 def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64):
@@ -42,9 +45,11 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
     if _fusable(fn, embed_fn, embeddirs_fn, viewdirs):
         R, S = inputs.shape[0], inputs.shape[1]
         rays_per_launch = max(1, MAX_ROWS_PER_LAUNCH // max(S, 1))
+        if not fn.use_viewdirs:
+            viewdirs = None
         if R <= rays_per_launch:
             return fn.query(inputs, viewdirs)
-        outs = [fn.query(inputs[i:i + rays_per_launch], viewdirs[i:i + rays_per_launch])
+        outs = [fn.query(inputs[i:i + rays_per_launch], None if viewdirs is None else viewdirs[i:i + rays_per_launch])
                 for i in range(0, R, rays_per_launch)]
         return torch.cat(outs, 0)
     inputs_flat = torch.reshape(inputs, [-1, inputs.shape[-1]])

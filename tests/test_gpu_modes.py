@@ -448,6 +448,85 @@ def test_embedded_inputs_on_the_split_kernel(P, widths, precision):
     assert worst <= 6e-3
 
 
+# ----------------------------------------------------------------------------- networks without view directions
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_network_without_view_directions(P, precision, tmp_path):
+    """use_viewdirs=False (run_nerf_helpers.py:102-103, 125-126: `output_linear` on the trunk's last layer): the four
+    outputs are expressed exactly in the view-dependent head the kernels implement (NeRF.param_list) and autograd
+    carries the gradients back to output_linear.  Both entries -- forward(embedded) and the fused query(pts, None) --
+    against the same network in fp64 torch; then the reference's own route: create_nerf(args) with
+    use_viewdirs=False, render, loss.backward(), both Adams."""
+    F = torch.nn.functional
+    torch.manual_seed(31)
+    net = P.NeRF(D=8, W=256, input_ch=63, input_ch_views=0, output_ch=5, skips=[4], use_viewdirs=False,
+                 precision=precision).to(dev())
+    sd = {k: v.detach().cpu().double() for k, v in net.state_dict().items()}
+    gen = torch.Generator().manual_seed(37)
+    pts = (torch.rand(7, 43, 3, generator=gen) * 2 - 1) * 1.5          # 301 rows: a ragged tile
+    cot = torch.randn(7, 43, 4, generator=gen)
+
+    def ref(sd_, x, pre=None):
+        h = x
+        for i in range(8):
+            z = F.linear(h, sd_[f"pts_linears.{i}.weight"], sd_[f"pts_linears.{i}.bias"])
+            if pre is not None:
+                pre.append(z.detach())
+            h = F.relu(z)
+            if i == 4:
+                h = torch.cat([x, h], -1)
+        return F.linear(h, sd_["output_linear.weight"], sd_["output_linear.bias"])
+
+    emb_fn, _ = P.get_embedder(10, 0)
+    x = emb_fn(pts.reshape(-1, 3)).double()
+    # (rows with a trunk pre-activation within the forward's rounding error of zero get no cotangent: DESIGN.md section 6)
+    pre = []
+    ref(sd, x, pre)
+    near = torch.stack([(z.abs() < 1e-5).any(-1) for z in pre]).any(0)
+    cot = cot * (~near).float().reshape(7, 43, 1)
+    sd_o = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out_ref = ref(sd_o, x)
+    (out_ref[:, :4] * cot.reshape(-1, 4).double()).sum().backward()
+    tol = 1e-5
+    out_q = net.query(g(pts), None)
+    assert out_q.shape == (7, 43, 5) and float(out_q[..., 4].detach().abs().max()) == 0.0
+    err_q = maxdiff(out_q[..., :4].reshape(-1, 4), out_ref[:, :4].detach().float())
+    out_f = net(g(x.float()))
+    err_f = maxdiff(out_f[..., :4], out_ref[:, :4].detach().float())
+    print(f"no view directions, {precision}: forward max err query {err_q:.2e}, forward(embedded) {err_f:.2e}")
+    assert err_q <= tol and err_f <= tol
+    (out_q[..., :4] * g(cot)).sum().backward()
+    gtol = 2e-4 if precision == "fp32" else 6e-3
+    worst = 0.0
+    for name, prm in net.named_parameters():
+        r = sd_o[name].grad
+        if r is None:                       # views_linears: unused by this network, in the reference as well
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0
+            continue
+        r = r.float()
+        if name.startswith("output_linear"):
+            r, got = r[:4], prm.grad[:4].cpu()      # (the fifth output never reaches the loss)
+        else:
+            got = prm.grad.cpu()
+        worst = max(worst, float((got - r).abs().max()) / max(float(r.abs().max()), 1e-6))
+    print(f"no view directions, {precision}: worst gradient error / max|g| {worst:.2e}")
+    assert worst <= gtol
+    # the reference's route
+    (tmp_path / "exp").mkdir()
+    args = _args(str(tmp_path), precision, use_viewdirs=False)
+    kw, _, _, grad_vars, opt, opt_c = P.create_nerf(args, device=dev())
+    batch, target = orc.synthetic_blender_rays(64, seed=2)
+    K = [[1111.111, 0, 400], [0, 1111.111, 400], [0, 0, 1]]
+    before = [p.detach().clone() for p in kw["network_fine"].parameters()]
+    rgb, disp, acc, extras = P.render(800, 800, K, chunk=32768, rays=(g(batch[:, 0:3]), g(batch[:, 3:6])), near=2.0,
+                                      far=6.0, retraw=True, **kw)
+    loss = P.img2mse(rgb, g(target)) + P.img2mse(extras["rgb0"], g(target))
+    opt.zero_grad(); opt_c.zero_grad()
+    loss.backward()
+    opt.step(); opt_c.step()
+    moved = max(float((a - b.detach()).abs().max()) for a, b in zip(before, kw["network_fine"].parameters()))
+    assert torch.isfinite(rgb).all() and 0.0 < moved <= 5.5e-4
+
+
 # ----------------------------------------------------------------------------- range of the half modes
 def test_half_modes_flag_range_overflow_and_withhold_the_step(P):
     """`f16x3` / `f16` clamp at the IEEE-half maximum (65,504).  A forward that gets there must not pass silently: the

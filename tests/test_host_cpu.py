@@ -73,6 +73,31 @@ def test_buffer_size_queries(built):
     assert L.plnerf_mlp_packed_bytes(7) == 0
 
 
+def test_network_without_view_directions_maps_onto_the_kernels_head(built):
+    """use_viewdirs=False: NeRF.param_list() expresses output_linear in the 24 tensors of the view-dependent head the
+    kernels implement (shapes of a use_viewdirs network with 27 direction channels), and that head -- evaluated here in
+    plain torch -- reproduces output_linear exactly; the state_dict keeps the reference's keys."""
+    import torch
+    import plnerf_amd as P
+    torch.manual_seed(3)
+    net = P.NeRF(D=8, W=256, input_ch=63, input_ch_views=0, output_ch=5, skips=[4], use_viewdirs=False)
+    ref = P.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+    assert net.is_supported() and net.has_fused_encoding() and net.hip_view_ch == 27
+    assert "output_linear.weight" in net.state_dict() and "alpha_linear.weight" not in net.state_dict()
+    mine, theirs = net.param_list(), list(ref.parameters())
+    assert [tuple(t.shape) for t in mine] == [tuple(t.shape) for t in theirs]
+    F = torch.nn.functional
+    h = torch.randn(50, 256)
+    views_w, views_b, feat_w, feat_b, alpha_w, alpha_b, rgb_w, rgb_b = mine[16:]
+    feat = F.linear(h, feat_w, feat_b)
+    hv = F.relu(F.linear(torch.cat([feat, torch.randn(50, 27)], -1), views_w, views_b))
+    out = torch.cat([F.linear(hv, rgb_w, rgb_b), F.linear(h, alpha_w, alpha_b)], -1)
+    want = F.linear(h, net.output_linear.weight, net.output_linear.bias)[:, :4]
+    assert float((out - want).abs().max()) <= 1e-6
+    out.sum().backward()
+    assert net.output_linear.weight.grad is not None and float(net.output_linear.weight.grad[:4].abs().max()) > 0
+
+
 def test_no_cpu_fallback(built):
     net = built.NeRF(input_ch=63, input_ch_views=27, use_viewdirs=True)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
