@@ -134,6 +134,7 @@ class GradientBucket:
             work.wait()
             flat.mul_(1.0 / world)
         self._works = []
+        self._arrived = [0] * len(self.modules)           # (a module with parameters that never receive a gradient never completes)
         rest = [m for mi, m in enumerate(self.modules) if not self._reduced[mi]]
         self._reduced = [False] * len(self.modules)
         if rest:
