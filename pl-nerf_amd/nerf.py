@@ -115,8 +115,9 @@ class NeRF(nn.Module):
 
     # -- HIP plumbing ---------------------------------------------------------------
     def is_supported(self):
-        trunk = (self.D == SUPPORTED["D"] and self.W == SUPPORTED["W"] and 1 <= self.input_ch <= MAX_INPUT_CH and
-                 list(self.skips) == SUPPORTED["skips"])
+        # (narrower and slightly shallower trunks are padded into the compiled one: param_list)
+        trunk = (SUPPORTED["D"] - 2 <= self.D <= SUPPORTED["D"] and 8 <= self.W <= SUPPORTED["W"] and self.W % 2 == 0 and
+                 1 <= self.input_ch <= MAX_INPUT_CH and list(self.skips) == SUPPORTED["skips"])
         if not self.use_viewdirs:      # (see param_list; the reference ignores the view columns of x, if any)
             return trunk
         return trunk and 1 <= self.view_ch <= MAX_VIEW_CH
@@ -131,9 +132,11 @@ class NeRF(nn.Module):
     def _require_supported(self):
         if not self.is_supported():
             raise NotImplementedError(
-                "plnerf_amd's HIP MLP is specialised for the reference's trunk "
-                f"(D={SUPPORTED['D']}, W={SUPPORTED['W']}, skips={SUPPORTED['skips']}, use_viewdirs, input_ch <= "
-                f"{MAX_INPUT_CH}, input_ch_views + input_ch_cam <= {MAX_VIEW_CH}); got D={self.D}, W={self.W}, "
+                "plnerf_amd's HIP MLP is compiled for the reference's trunk "
+                f"(D={SUPPORTED['D']}, W={SUPPORTED['W']}, skips={SUPPORTED['skips']}) and runs what can be expressed exactly "
+                f"in it: netdepth {SUPPORTED['D'] - 2}..{SUPPORTED['D']}, even netwidth 8..{SUPPORTED['W']}, input_ch <= "
+                f"{MAX_INPUT_CH}, input_ch_views + input_ch_cam <= {MAX_VIEW_CH}, with or without view directions; got "
+                f"D={self.D}, W={self.W}, "
                 f"input_ch={self.input_ch}, input_ch_views={self.input_ch_views}, input_ch_cam={self.input_ch_cam}, "
                 f"skips={self.skips}, use_viewdirs={self.use_viewdirs}.  There is no generic/CPU fallback.")
 
@@ -152,31 +155,56 @@ class NeRF(nn.Module):
         return raw
 
     def param_list(self):
-        """The 24 parameter tensors in state_dict order (the C ABI's `params[24]`).
+        """The 24 parameter tensors of the network the kernels are compiled for (D = 8, W = 256, skip after layer 4,
+        view-dependent head), in state_dict order: the C ABI's `params[24]`.  The reference's own configuration IS
+        that network and passes its parameters through.  Other shapes of the reference class are expressed EXACTLY in
+        it with differentiable torch ops, so autograd carries the kernels' 24 gradients back to the real parameters:
 
-        use_viewdirs=False (run_nerf_helpers.py:102-103, 125-126: `output_linear` straight from the trunk) has no kernel
-        of its own: its four outputs are expressed EXACTLY in the view-dependent head the kernels implement --
-        feature rows 0..2 = W_out[rgb], rows 3..5 = -W_out[rgb]; the view layer copies those six features (identity
-        weights, zero direction columns); rgb = relu(F) - relu(-F) + b = F + b; sigma = alpha row = W_out[3] -- with
-        differentiable torch ops, so autograd carries the kernels' 24 gradients back to `output_linear`."""
-        if self.use_viewdirs:
+          * netwidth < 256: weights and biases zero-padded (the extra units compute relu(0) = 0 and feed nothing);
+          * netdepth 6 or 7: the missing trunk layers as identities (their inputs are post-ReLU, so relu(I h) = h);
+          * use_viewdirs=False (run_nerf_helpers.py:102-103, 125-126: `output_linear` on the trunk): feature rows
+            0..2 = W_out[rgb], rows 3..5 = -W_out[rgb]; the view layer copies those six features (identity weights, zero
+            direction columns); rgb = relu(F) - relu(-F) + b = F + b; sigma = the alpha row = W_out[3]."""
+        if self.use_viewdirs and self.D == SUPPORTED["D"] and self.W == SUPPORTED["W"]:
             return list(self.parameters())
-        W = self.W
+        import torch.nn.functional as F
+        KW, W, D, cin = SUPPORTED["W"], self.W, self.D, self.input_ch
+        ref = self.pts_linears[0].weight
+        z = lambda *shape: ref.new_zeros(*shape)
+        pad_rows = lambda t, n: F.pad(t, (0, 0, 0, n - t.shape[0])) if t.dim() == 2 else F.pad(t, (0, n - t.shape[0]))
+        pad_cols = lambda t, n: F.pad(t, (0, n - t.shape[1]))
+        out = []
+        for i in range(SUPPORTED["D"]):
+            if i < D:
+                w, b = self.pts_linears[i].weight, self.pts_linears[i].bias
+                if i == 0:
+                    w = pad_rows(w, KW)
+                elif i == SUPPORTED["skips"][0] + 1:      # [encoding | hidden] columns
+                    w = pad_rows(torch.cat([w[:, :cin], pad_cols(w[:, cin:], KW)], 1), KW)
+                else:
+                    w = pad_rows(pad_cols(w, KW), KW)
+                out += [w, pad_rows(b, KW)]
+            else:
+                out += [torch.eye(KW, device=ref.device, dtype=ref.dtype), z(KW)]
+        HV, vch = KW // 2, self.hip_view_ch
+        if self.use_viewdirs:
+            vw = self.views_linears[0].weight                                  # [W/2, W + view_ch]: [feature | direction]
+            out += [pad_rows(torch.cat([pad_cols(vw[:, :W], KW), vw[:, W:]], 1), HV), pad_rows(self.views_linears[0].bias, HV),
+                    pad_rows(pad_cols(self.feature_linear.weight, KW), KW), pad_rows(self.feature_linear.bias, KW),
+                    pad_cols(self.alpha_linear.weight, KW), self.alpha_linear.bias,
+                    pad_cols(self.rgb_linear.weight, HV), self.rgb_linear.bias]
+            return out
         Wo, bo = self.output_linear.weight, self.output_linear.bias
         if Wo.shape[0] < 4:
             raise NotImplementedError("plnerf_amd: output_linear needs at least 4 outputs (rgb, sigma)")
-        key = (str(Wo.device), Wo.dtype)
-        if getattr(self, "_head_consts", None) is None or self._head_consts[0] != key:
-            views_w = torch.zeros(W // 2, W + self.hip_view_ch, device=Wo.device, dtype=Wo.dtype)
-            rgb_w = torch.zeros(3, W // 2, device=Wo.device, dtype=Wo.dtype)
-            for c in range(6):
-                views_w[c, c] = 1.0
-            for c in range(3):
-                rgb_w[c, c], rgb_w[c, 3 + c] = 1.0, -1.0
-            self._head_consts = (key, views_w, Wo.new_zeros(W // 2), rgb_w, Wo.new_zeros(W - 6, W), Wo.new_zeros(W))
-        _, views_w, views_b, rgb_w, pad, feat_b = self._head_consts
-        trunk = [t for l in self.pts_linears for t in (l.weight, l.bias)]
-        return trunk + [views_w, views_b, torch.cat([Wo[0:3], -Wo[0:3], pad], 0), feat_b, Wo[3:4], bo[3:4], rgb_w, bo[0:3]]
+        views_w, rgb_w = z(HV, KW + vch), z(3, HV)
+        for c in range(6):
+            views_w[c, c] = 1.0
+        for c in range(3):
+            rgb_w[c, c], rgb_w[c, 3 + c] = 1.0, -1.0
+        Wp = pad_cols(Wo, KW)
+        out += [views_w, z(HV), torch.cat([Wp[0:3], -Wp[0:3], z(KW - 6, KW)], 0), z(KW), Wp[3:4], bo[3:4], rgb_w, bo[0:3]]
+        return out
 
     @property
     def hip_view_ch(self):

@@ -527,6 +527,71 @@ def test_network_without_view_directions(P, precision, tmp_path):
     assert torch.isfinite(rgb).all() and 0.0 < moved <= 5.5e-4
 
 
+@pytest.mark.parametrize("shape", [(8, 128, True), (6, 256, True), (7, 64, False), (6, 32, True)])
+def test_narrower_and_shallower_networks(P, shape):
+    """netwidth < 256 and netdepth 6 / 7 are zero-padded / identity-extended into the compiled 8 x 256 network
+    (NeRF.param_list) -- exactly: fp32 mode against the same network in fp64 torch, forward and every real parameter's
+    gradient, fused entry and embedded entry."""
+    D, Wd, use_viewdirs = shape
+    F = torch.nn.functional
+    torch.manual_seed(41)
+    net = P.NeRF(D=D, W=Wd, input_ch=63, input_ch_views=27 if use_viewdirs else 0, output_ch=5, skips=[4],
+                 use_viewdirs=use_viewdirs, precision="fp32").to(dev())
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in net.state_dict().items()}
+    gen = torch.Generator().manual_seed(43)
+    pts = (torch.rand(5, 37, 3, generator=gen) * 2 - 1) * 1.5
+    vd = torch.nn.functional.normalize(torch.randn(5, 3, generator=gen), dim=-1)
+    cot = torch.randn(5, 37, 4, generator=gen)
+    emb_fn, _ = P.get_embedder(10, 0)
+    embd_fn, _ = P.get_embedder(4, 0)
+    x = emb_fn(pts.reshape(-1, 3)).double()
+    v = embd_fn(vd[:, None].expand(5, 37, 3).reshape(-1, 3)).double()
+    h = x
+    for i in range(D):
+        h = F.relu(F.linear(h, sd[f"pts_linears.{i}.weight"], sd[f"pts_linears.{i}.bias"]))
+        if i == 4:
+            h = torch.cat([x, h], -1)
+    if use_viewdirs:
+        sigma = F.linear(h, sd["alpha_linear.weight"], sd["alpha_linear.bias"])
+        feat = F.linear(h, sd["feature_linear.weight"], sd["feature_linear.bias"])
+        hv = F.relu(F.linear(torch.cat([feat, v], -1), sd["views_linears.0.weight"], sd["views_linears.0.bias"]))
+        ref = torch.cat([F.linear(hv, sd["rgb_linear.weight"], sd["rgb_linear.bias"]), sigma], -1)
+    else:
+        ref = F.linear(h, sd["output_linear.weight"], sd["output_linear.bias"])[:, :4]
+    (ref * cot.reshape(-1, 4).double()).sum().backward()
+    out = net.query(g(pts), g(vd) if use_viewdirs else None)[..., :4]
+    err = maxdiff(out.reshape(-1, 4), ref.detach().float())
+    emb_in = torch.cat([x, v], -1) if use_viewdirs else x
+    err_e = maxdiff(net(g(emb_in.float()))[..., :4], ref.detach().float())
+    (out * g(cot)).sum().backward()
+    worst = 0.0
+    for name, prm in net.named_parameters():
+        r = sd[name].grad
+        if r is None:
+            continue
+        r = r.float()
+        got = prm.grad.cpu()
+        if name.startswith("output_linear"):
+            r, got = r[:4], got[:4]
+        worst = max(worst, float((got - r).abs().max()) / max(float(r.abs().max()), 1e-6))
+    print(f"D={D} W={Wd} viewdirs={use_viewdirs}: forward {err:.2e} (embedded entry {err_e:.2e}), worst gradient error / max|g| {worst:.2e}")
+    assert err <= 1e-5 and err_e <= 1e-5 and worst <= 2e-4
+    # the reference's route with these arguments: create_nerf, render, backward, both Adams (f16x3, the default mode)
+    args = _args(_ckdir(), "f16x3", netdepth=D, netwidth=Wd, netdepth_fine=D, netwidth_fine=Wd, use_viewdirs=use_viewdirs)
+    kw, _, _, grad_vars, opt, opt_c = P.create_nerf(args, device=dev())
+    batch, target = orc.synthetic_blender_rays(64, seed=4)
+    K = [[1111.111, 0, 400], [0, 1111.111, 400], [0, 0, 1]]
+    before = [p.detach().clone() for p in kw["network_fine"].parameters()]
+    rgb, disp, acc, extras = P.render(800, 800, K, chunk=32768, rays=(g(batch[:, 0:3]), g(batch[:, 3:6])), near=2.0,
+                                      far=6.0, retraw=True, **kw)
+    loss = P.img2mse(rgb, g(target)) + P.img2mse(extras["rgb0"], g(target))
+    opt.zero_grad(); opt_c.zero_grad()
+    loss.backward()
+    opt.step(); opt_c.step()
+    moved = max(float((a - b.detach()).abs().max()) for a, b in zip(before, kw["network_fine"].parameters()))
+    assert torch.isfinite(rgb).all() and 0.0 < moved <= 5.5e-4
+
+
 # ----------------------------------------------------------------------------- range of the half modes
 def test_half_modes_flag_range_overflow_and_withhold_the_step(P):
     """`f16x3` / `f16` clamp at the IEEE-half maximum (65,504).  A forward that gets there must not pass silently: the
