@@ -98,6 +98,46 @@ def test_network_without_view_directions_maps_onto_the_kernels_head(built):
     assert net.output_linear.weight.grad is not None and float(net.output_linear.weight.grad[:4].abs().max()) > 0
 
 
+@pytest.mark.parametrize("shape", [(8, 128, True), (6, 256, True), (7, 64, False), (6, 32, True)])
+def test_other_network_shapes_map_exactly_onto_the_compiled_network(built, shape):
+    """NeRF.param_list() for netwidth < 256 / netdepth 6, 7 / no view directions: the 24 tensors of the compiled
+    8 x 256 network, evaluated here in plain fp64 torch, reproduce the real module's function exactly."""
+    import torch
+    import plnerf_amd as P
+    D, Wd, use_viewdirs = shape
+    F = torch.nn.functional
+    torch.manual_seed(5)
+    net = P.NeRF(D=D, W=Wd, input_ch=63, input_ch_views=27 if use_viewdirs else 0, output_ch=5, skips=[4],
+                 use_viewdirs=use_viewdirs).double()
+    assert net.is_supported()
+    x, v = torch.randn(40, 63, dtype=torch.float64), torch.randn(40, 27, dtype=torch.float64)
+    sd = net.state_dict()
+    h = x
+    for i in range(D):
+        h = F.relu(F.linear(h, sd[f"pts_linears.{i}.weight"], sd[f"pts_linears.{i}.bias"]))
+        if i == 4:
+            h = torch.cat([x, h], -1)
+    if use_viewdirs:
+        sigma = F.linear(h, sd["alpha_linear.weight"], sd["alpha_linear.bias"])
+        feat = F.linear(h, sd["feature_linear.weight"], sd["feature_linear.bias"])
+        hv = F.relu(F.linear(torch.cat([feat, v], -1), sd["views_linears.0.weight"], sd["views_linears.0.bias"]))
+        want = torch.cat([F.linear(hv, sd["rgb_linear.weight"], sd["rgb_linear.bias"]), sigma], -1)
+    else:
+        want = F.linear(h, sd["output_linear.weight"], sd["output_linear.bias"])[:, :4]
+    p = net.param_list()
+    ref = P.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+    assert [tuple(t.shape) for t in p] == [tuple(t.shape) for t in ref.parameters()]
+    h = x
+    for i in range(8):
+        h = F.relu(F.linear(h, p[2 * i], p[2 * i + 1]))
+        if i == 4:
+            h = torch.cat([x, h], -1)
+    views_w, views_b, feat_w, feat_b, alpha_w, alpha_b, rgb_w, rgb_b = p[16:]
+    hv = F.relu(F.linear(torch.cat([F.linear(h, feat_w, feat_b), v], -1), views_w, views_b))
+    got = torch.cat([F.linear(hv, rgb_w, rgb_b), F.linear(h, alpha_w, alpha_b)], -1)
+    assert float((got - want).abs().max()) <= 1e-12 * max(1.0, float(want.abs().max()))
+
+
 def test_no_cpu_fallback(built):
     net = built.NeRF(input_ch=63, input_ch_views=27, use_viewdirs=True)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
