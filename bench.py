@@ -8,7 +8,8 @@ backward through both MLPs -> per-network gradient all-reduce across ranks (over
 both networks.  N_rand = 4096 rays PER GPU (BASELINE.json configs[1]; configs[2] is the same per-GPU load at 8 GPUs
 => weak scaling).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without torchrun's environment: this script spawns
+                                                            its own N ranks, one per GPU, and rank 0 prints the line)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Other BASELINE configurations run with --workload {blender_128_64, llff_ndc, depth_128_64}; the default
@@ -23,6 +24,9 @@ measured GPU path.
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import tempfile
 import time
@@ -36,6 +40,7 @@ if ROOT not in sys.path:
 
 FWD_FLOP_PER_ROW = 1186816      # 2 x 593,408 MAC per network evaluation
 TRAIN_FLOP_PER_ROW = 3489024    # forward + wgrad + dgrad
+TRAFFIC_FILE = "r02_traffic.json"   # refreshed per round by tools/pmc_traffic.sh
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s HBM3E
 # training forward, algorithmic bytes per row: saved state written + xyz read (12) + raw written (16)
 FWD_TRAIN_BYTES_PER_ROW = {"fp32": 2596 * 4 + 28, "h16": 2528 * 2 + 272 + 28}   # fp32 planes | half planes + relu masks
@@ -64,7 +69,7 @@ WORKLOADS = {
 }
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -84,10 +89,19 @@ def parse():
     ap.add_argument("--no-strict-fp32", action="store_true", help="skip the exact-fp32 leg")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-no-grid", action="store_true", help="cpu_baseline: only the workload's own cell")
     ap.add_argument("--views", type=int, default=4, help="synthetic views resident on the device")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gradient all-reduce even with one rank (path check)")
-    return ap.parse_args()
+    ap.add_argument("--stub-cpu", action="store_true",
+                    help="launcher self-test (tests/test_host_cpu.py): ranks on the CPU over gloo, the step is a stand-in "
+                         "with NeRF-sized flat gradients through dp.GradientBucket; the line it prints is NOT a "
+                         "measurement of the hot path and says so")
+    ap.add_argument("--stub-fail-rank", type=int, default=-1,
+                    help="launcher self-test: this rank raises before the first step (the launcher must stop the others "
+                         "and exit non-zero)")
+    ap.add_argument("--launch-timeout", type=float, default=1800.0, help="seconds the self-spawned ranks may run")
+    return ap.parse_args(argv)
 
 
 def make_args(a, ckpt_dir, precision):
@@ -110,43 +124,67 @@ def depth_args(a, precision):
 
 
 def cpu_info():
-    model = None
+    """Host description for the cpu_baseline object: model, logical CPUs, physical cores (sockets x cores per socket)."""
+    model, sockets, per_socket = None, set(), None
     try:
         for line in open("/proc/cpuinfo"):
-            if line.lower().startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
+            key, _, val = line.partition(":")
+            key = key.strip().lower()
+            if key == "model name" and model is None:
+                model = val.strip()
+            elif key == "physical id":
+                sockets.add(val.strip())
+            elif key == "cpu cores" and per_socket is None:
+                per_socket = int(val)
+    except (OSError, ValueError):
         pass
-    return {"cpu_count": os.cpu_count(), "cpu_model": model}
+    phys = (len(sockets) or 1) * per_socket if per_socket else None
+    return {"cpu_count": os.cpu_count(), "physical_cores": phys, "sockets": len(sockets) or None, "cpu_model": model}
+
+
+def cpu_cell(orc, n, ns, ni, reps):
+    """One cell of BASELINE.md section 4's grid: the oracle's full training step, 1 warm-up + `reps` timed steps."""
+    batch, target = orc.synthetic_blender_rays(n, seed=0)
+    sd_c, sd_f = orc.closed_form_state_dict(0), orc.closed_form_state_dict(1)
+    kw = dict(N_samples=ns, N_importance=ni, mode="linear", color_mode="midpoint", perturb=1.0, white_bkgd=True,
+              raw_noise_std=0.0)
+    state = {}
+    orc.train_step(sd_c, sd_f, batch, target, kw, adam_state=state)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orc.train_step(sd_c, sd_f, batch, target, kw, adam_state=state)
+    return (time.perf_counter() - t0) / reps
 
 
 def cpu_baseline(a):
-    """The oracle's training step on the host cores, bounded sample (1 warm-up + 3 steps)."""
+    """The oracle's training step on the host cores, bounded sample: the workload's own sampling at `--cpu-rays` rays
+    is `value`; the other cells of BASELINE.md section 4's grid (R in {256, 1024} x {(64,128), (128,64)}) ride along in
+    `grid`, 1 warm-up + 2 steps each (about 35 s of host time in total)."""
     from oracle import plnerf_oracle as orc
-    n = a.cpu_rays
     # 16 threads is the fastest setting on the GPU box's 256-thread host for this workload
     # (profiles/r01_cpu_oracle_thread_sweep.txt: 8 -> 314, 16 -> 339, 32 -> 289, 64 -> 161,
     # 128 -> 71 rays/s; more threads only add oversubscription on these small GEMMs)
     threads = min(a.cpu_threads, os.cpu_count() or 1)
     torch.set_num_threads(threads)
-    batch, target = orc.synthetic_blender_rays(n, seed=0)
-    sd_c, sd_f = orc.closed_form_state_dict(0), orc.closed_form_state_dict(1)
-    kw = dict(N_samples=a.n_samples, N_importance=a.n_importance, mode="linear", color_mode="midpoint",
-              perturb=1.0, white_bkgd=True, raw_noise_std=0.0)
-    state = {}
-    orc.train_step(sd_c, sd_f, batch, target, kw, adam_state=state)
-    t0 = time.perf_counter()
-    reps = 3
-    for _ in range(reps):
-        orc.train_step(sd_c, sd_f, batch, target, kw, adam_state=state)
-    dt = (time.perf_counter() - t0) / reps
-    out = {"value": n / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "threads": torch.get_num_threads(),
-           "kind": "port",
-           "sample": f"{n} rays x ({a.n_samples}+{a.n_samples + a.n_importance}) samples, full train step "
+    reps = 2
+    cells = [(a.cpu_rays, a.n_samples, a.n_importance)]
+    if not a.cpu_no_grid:
+        for n in (256, 1024):
+            for ns, ni in ((64, 128), (128, 64)):
+                if (n, ns, ni) not in cells:
+                    cells.append((n, ns, ni))
+    grid = []
+    for n, ns, ni in cells:
+        dt = cpu_cell(orc, n, ns, ni, reps)
+        grid.append({"rays": n, "N_samples": ns, "N_importance": ni, "s_per_step": dt, "rays_per_s": n / dt})
+    head = grid[0]
+    used = torch.get_num_threads()
+    out = {"value": head["rays_per_s"], "unit": "rays/s", "cores": used, "threads": used, "kind": "port",
+           "sample": f"{head['rays']} rays x ({a.n_samples}+{a.n_samples + a.n_importance}) samples, full train step "
                      f"(fwd+bwd+2xAdam), fp32 PyTorch CPU oracle, 1 warm-up + mean of {reps} steps, "
-                     f"{dt:.2f} s/step; {torch.get_num_threads()} threads = the fastest setting on this host "
-                     f"(profiles/r01_cpu_oracle_thread_sweep.txt)"}
+                     f"{head['s_per_step']:.2f} s/step; `cores` = the {used} torch threads actually used, the fastest "
+                     f"setting on this host (profiles/r01_cpu_oracle_thread_sweep.txt); the host has `physical_cores`",
+           "grid": grid}
     out.update(cpu_info())
     return out
 
@@ -224,22 +262,118 @@ def build_step(P, a, precision, scene, dev, rank, world, force_dist):
     return step, nets
 
 
-def main():
-    a = parse()
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(a, argv):
+    """`bench.py --gpus N` without torchrun's environment: spawn the N ranks here (one process per GPU, LOCAL_RANK ->
+    device, a free rendezvous port on 127.0.0.1), let rank 0 print the one JSON line on this process's stdout, and
+    exit non-zero if any rank fails (the others are then terminated by PID)."""
+    n = a.gpus
+    if not a.stub_cpu:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} needs {n} visible devices, this host has {have} "
+                  f"(nothing was launched)", file=sys.stderr)
+            return 2
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PLNERF_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rank 0 inherits stdout (the JSON line); whatever the other ranks print goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    deadline = time.monotonic() + a.launch_timeout
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in live:
+                    procs[q].terminate()
+        if live and time.monotonic() > deadline:
+            print(f"bench.py: ranks {sorted(live)} still running after {a.launch_timeout:.0f} s; stopping them",
+                  file=sys.stderr)
+            for q in live:
+                procs[q].kill()
+            rc = rc or 124
+            deadline = float("inf")
+        if live:
+            time.sleep(0.05)
+    return rc
+
+
+def build_stub_step(rank, world):
+    """Launcher self-test (--stub-cpu): two NeRF-sized flat gradient buffers through dp.GradientBucket on CPU / gloo.
+    Not the hot path; exists so that the spawn + rendezvous + collective + report plumbing runs without GPUs."""
+    from plnerf_amd import dp
+    torch.manual_seed(7 + rank)
+    nets = [torch.nn.Linear(64, 32), torch.nn.Linear(32, 4)]
+    dp.broadcast_parameters(nets)
+    bucket = dp.GradientBucket(nets)
+    x = torch.randn(16, 64)
+
+    def step(i):
+        for n in nets:
+            n.zero_grad()
+        loss = (nets[1](torch.relu(nets[0](x))) ** 2).mean()
+        loss.backward()
+        t0 = time.perf_counter()
+        bucket.allreduce_mean()
+        step.allreduce_s.append(time.perf_counter() - t0)
+        return loss
+    step.allreduce_s = []
+    return step, nets
+
+
+def stats_ms(v):
+    return {"min": min(v), "median": statistics.median(v), "max": max(v)} if v else None
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    a = parse(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a, argv))
     ns, ni, desc = WORKLOADS[a.workload]
     a.n_samples = a.n_samples if a.n_samples is not None else ns
     a.n_importance = a.n_importance if a.n_importance is not None else ni
     import plnerf_amd as P
     from plnerf_amd import dp, functional as Fn
-    rank, world, local = dp.init_from_env(force=a.force_dist)
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    cpu = a.stub_cpu
+    rank, world, local = dp.init_from_env(backend="gloo" if cpu else None, force=a.force_dist)
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but the environment says WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    if not cpu:
+        if torch.cuda.device_count() <= local:
+            print(f"bench.py: rank {rank} wants device {local}, this host has {torch.cuda.device_count()}",
+                  file=sys.stderr)
+            sys.exit(2)
+        torch.cuda.set_device(local)
+    dev = torch.device("cpu") if cpu else torch.device("cuda", local)
     dist_on = world > 1 or a.force_dist
 
-    scene = Scene(P, a.workload, a.views, dev)
-    step, nets = build_step(P, a, a.precision, scene, dev, rank, world, a.force_dist)
-    if a.force_dist and world == 1:     # exercise the RCCL path on one GPU
+    if cpu:
+        if rank == a.stub_fail_rank:
+            raise RuntimeError(f"--stub-fail-rank {rank}: simulated rank failure")
+        step, nets = build_stub_step(rank, world)
+        scene = None
+    else:
+        scene = Scene(P, a.workload, a.views, dev)
+        step, nets = build_step(P, a, a.precision, scene, dev, rank, world, a.force_dist)
+    if a.force_dist and world == 1 and not cpu:     # exercise the RCCL path on one GPU
         _allreduce = dp.GradientBucket.allreduce_mean
         dp.GradientBucket.allreduce_mean = lambda self, group=None, force=False: _allreduce(self, group, True)
     R = a.rays
@@ -247,53 +381,96 @@ def main():
 
     def sync():
         if dist_on:
-            torch.distributed.barrier(device_ids=[local])
-        torch.cuda.synchronize()
+            torch.distributed.barrier(**({} if cpu else {"device_ids": [local]}))
+        if not cpu:
+            torch.cuda.synchronize()
 
     def timed(step_fn, warmup, steps, timer=None):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks.
+        Also returns every rank's own time and, on the GPU, the per-step times from one HIP event per step boundary
+        (recorded on the launch stream: no host synchronisation inside the timed region)."""
         for i in range(warmup):
             step_fn(i)
         Fn.KERNEL_TIMER = timer
+        marks = []
         sync()
         t0 = time.perf_counter()
         for i in range(warmup, warmup + steps):
+            if not cpu:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append(ev)
             loss = step_fn(i)
+        if not cpu:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append(ev)
         sync()
         dt = time.perf_counter() - t0
         Fn.KERNEL_TIMER = None
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        per_rank = [dt]
         if dist_on:
+            every = [torch.zeros_like(t) for _ in range(world)]
+            torch.distributed.all_gather(every, t)
+            per_rank = [float(x.item()) for x in every]
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        return float(t.item()), float(loss.detach())
+        per_step = [marks[k].elapsed_time(marks[k + 1]) for k in range(len(marks) - 1)]
+        return float(t.item()), float(loss.detach()), per_rank, per_step
 
-    timer = Fn.KernelTimer()
-    dt, final_loss = timed(step, a.warmup, a.steps, timer)
+    timer = None if cpu else Fn.KernelTimer()
+    dt, final_loss, per_rank_s, per_step_ms = timed(step, a.warmup, a.steps, timer)
 
     strict = None
-    if a.precision != "fp32" and not a.no_strict_fp32 and world == 1:
+    if a.precision != "fp32" and not a.no_strict_fp32 and world == 1 and not cpu:
         # the strictly reference-equal arithmetic (exact fp32 MFMA forward and backward), same workload, short leg
         step32, nets32 = build_step(P, a, "fp32", scene, dev, rank, world, False)
         s_steps = max(3, min(a.steps, 5))
-        dt32, _ = timed(step32, 2, s_steps)
+        dt32, _, _, _ = timed(step32, 2, s_steps)
         strict = {"precision": "fp32", "ms_per_step": 1e3 * dt32 / s_steps, "rays_per_s": R * s_steps / dt32,
                   "steps": s_steps, "warmup": 2}
         del step32, nets32
         torch.cuda.empty_cache()
 
-    if rank == 0:
+    # the all-reduce as the launch stream sees it: HIP events on that stream either side of GradientBucket.allreduce_mean
+    # (wait for the two collectives enqueued during the backward + the 1/world scaling) = the EXPOSED part of the exchange
+    if cpu:
+        exposed = [1e3 * x for x in step.allreduce_s[a.warmup:]]
+    else:
+        exposed = timer.all_ms("allreduce_exposed")
+    ex_mean = torch.tensor([sum(exposed) / len(exposed) if exposed else 0.0], device=dev, dtype=torch.float64)
+    if dist_on:
+        torch.distributed.all_reduce(ex_mean, op=torch.distributed.ReduceOp.MAX)
+
+    if rank == 0 and cpu:
+        print(json.dumps({
+            "metric": "launcher self-test (stub step on CPU / gloo; NOT a measurement of the hot path)",
+            "value": world * a.steps / dt, "unit": "stub steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "stub", "parallelism": f"dp{world}", "backend": torch.distributed.get_backend()
+                       if torch.distributed.is_initialized() else None,
+                       "rccl_world_size": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                       "self_launched": bool(os.environ.get("PLNERF_BENCH_SELF_LAUNCHED"))},
+            "ranks": {"ms_per_step": stats_ms([1e3 * x / a.steps for x in per_rank_s]),
+                      "allreduce_exposed_ms_max_over_ranks": float(ex_mean.item())}}), flush=True)
+    elif rank == 0:
         ms = 1e3 * dt / a.steps
         fwd_ms = timer.mean_ms(f"mlp_fwd[{rows_fine}]")
         bwd_ms = timer.mean_ms(f"mlp_bwd[{rows_fine}]")
         peak = PEAK_TFLOPS[a.precision]
-        traffic = None
+        traffic, traffic_source = None, None
         fwd_kernel = FWD_KERNEL[a.precision]
         if a.workload == "depth_128_64" and a.precision in ("f16", "bf16"):
             # the caller-embedded 57|3 input of the depth variant: the plain modes have no register-resident variant for it
             fwd_kernel = "mlp_fwd_pp_kernel<1,true>"
-        try:   # measured offline with rocprofv3 --pmc (cannot be collected from inside this process)
-            t = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json"))).get(a.precision)
+        try:   # measured offline with rocprofv3 --pmc (cannot be collected from inside this process): the JSON says so
+            tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
+            t = tj.get(a.precision)
             if t and t["rows_per_launch"] == rows_fine and t.get("kernel", fwd_kernel) == fwd_kernel:
                 traffic = t["bytes"]
+                traffic_source = f"profiles/{TRAFFIC_FILE}@{tj.get('commit', 'unknown')} (offline rocprofv3 --pmc " \
+                                 f"FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.sh; not measured in this run)"
         except Exception:
             traffic = None
         ach = rows_fine * FWD_FLOP_PER_ROW / (fwd_ms * 1e-3) / 1e12 if fwd_ms else None
@@ -311,7 +488,15 @@ def main():
                                    f"choice + ray generation + render + backward + per-network grad all-reduce + Adam",
                        "global_rays": R * world, "precision": a.precision, "parallelism": f"dp{world}",
                        "rccl_world_size": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                       "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+                       "self_launched": bool(os.environ.get("PLNERF_BENCH_SELF_LAUNCHED")),
                        "final_loss": final_loss},
+            # the K timed steps one by one (rank 0's launch stream, one HIP event per step boundary), and the ranks'
+            # own wall-clock times for the K steps: the spread is what diagnoses a slow rank / an exposed collective
+            "step_ms": stats_ms(per_step_ms),
+            "ranks": {"ms_per_step": stats_ms([1e3 * x / a.steps for x in per_rank_s]),
+                      "allreduce_exposed_ms_max_over_ranks": float(ex_mean.item()) if dist_on else None,
+                      "allreduce_exposed_ms_rank0": stats_ms(exposed)},
             # the MLP is priced against the MFMA roofline on its ALGORITHMIC work,
             # 1,186,816 FLOP per network evaluation -- the 3 MFMA issues per product of the split modes are a cost,
             # not work.  The HBM view of the same launch (saved half planes written once) rides along.
@@ -319,7 +504,7 @@ def main():
                 "bound": "mfma",
                 "kernel": fwd_kernel + " (fine network, fused PE+12-layer MLP forward, saves backward state)",
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": (ach / peak) if ach else None,
-                "traffic": traffic, "launch_ms": fwd_ms, "rows_per_launch": rows_fine,
+                "traffic": traffic, "traffic_source": traffic_source, "launch_ms": fwd_ms, "rows_per_launch": rows_fine,
                 "flop_per_row": FWD_FLOP_PER_ROW,
                 "mfma_issued_tflops": (ach * MFMA_PER_PRODUCT[a.precision]) if ach else None,
                 "mfma_issue_frac": (ach * MFMA_PER_PRODUCT[a.precision] / peak) if ach else None,
@@ -345,6 +530,8 @@ def main():
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():
+        if dist_on:
+            torch.distributed.barrier(**({} if cpu else {"device_ids": [local]}))
         torch.distributed.destroy_process_group()
 
 

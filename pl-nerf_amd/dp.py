@@ -130,9 +130,19 @@ class GradientBucket:
             for mi in range(len(self.modules)):
                 self._launch(mi)
         n = len(self._works)
+        # the EXPOSED part of the exchange, as the launch stream sees it: from here (the backward's last kernel is
+        # enqueued) until both collectives have been waited for and scaled.  Events only while bench.py has a timer
+        # installed; they are recorded on the current stream, which work.wait() makes wait for RCCL's stream.
+        from . import functional as Fn
+        ev = None
+        if Fn.KERNEL_TIMER is not None and self._works and self._works[0][1].is_cuda:
+            ev = Fn.KERNEL_TIMER.bracket("allreduce_exposed")
+            ev[0].record()
         for work, flat in self._works:
             work.wait()
             flat.mul_(1.0 / world)
+        if ev is not None:
+            ev[1].record()
         self._works = []
         self._arrived = [0] * len(self.modules)           # (a module with parameters that never receive a gradient never completes)
         rest = [m for mi, m in enumerate(self.modules) if not self._reduced[mi]]

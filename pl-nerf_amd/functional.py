@@ -38,6 +38,10 @@ class KernelTimer:
             return None
         return sum(s.elapsed_time(e) for s, e in ev) / len(ev)
 
+    def all_ms(self, name, skip=0):
+        """Every bracket of `name` in milliseconds (call after a device synchronisation)."""
+        return [s.elapsed_time(e) for s, e in self.events.get(name, [])[skip:]]
+
     def count(self, name):
         return len(self.events.get(name, []))
 

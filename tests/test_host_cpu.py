@@ -486,3 +486,56 @@ def test_depth_variant_host_logic(built):
         lb = orc.compute_space_carving_loss(b, target_h, **kwargs)
         la.backward(); lb.backward()
         assert torch.equal(la, lb) and torch.equal(a.grad, b.grad), kwargs
+
+
+def _run_bench(*flags, env=None, timeout=300):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(flags), env=e, text=True,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+
+
+def test_bench_spawns_its_own_ranks(built):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's command form) must launch the two
+    ranks itself: here on CPU / gloo with the stand-in step, the real rendezvous, dp.GradientBucket and report path.
+    Rank 0 prints ONE JSON line as the last line of stdout; the world size is what torch.distributed reports."""
+    import json
+    r = _run_bench("--gpus", "2", "--stub-cpu", "--steps", "4", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    assert r.stdout.strip().splitlines()[-1] == lines[0]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 1
+    assert out["config"]["rccl_world_size"] == 2 and out["config"]["self_launched"] is True
+    assert out["config"]["backend"] == "gloo"
+    rk = out["ranks"]
+    assert rk["ms_per_step"]["min"] <= rk["ms_per_step"]["max"] and rk["allreduce_exposed_ms_max_over_ranks"] > 0
+    assert "NOT a measurement" in out["metric"]
+
+
+def test_bench_launcher_refuses_without_devices_and_propagates_failures(built):
+    """No GPU here: `--gpus 2` must say so and exit 2 without launching anything; a rank that dies must take the
+    launcher down with a non-zero exit code (the other rank, blocked in the rendezvous, is stopped by PID)."""
+    import torch
+    if not torch.cuda.is_available():
+        r = _run_bench("--gpus", "2")
+        assert r.returncode == 2 and "needs 2 visible devices" in r.stderr, (r.returncode, r.stderr[-500:])
+    r = _run_bench("--gpus", "2", "--stub-cpu", "--stub-fail-rank", "1", "--launch-timeout", "120")
+    assert r.returncode != 0
+    assert "rank 1 exited" in r.stderr and "simulated rank failure" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_under_torchrun_environment(built):
+    """The torchrun contract still works: with RANK / WORLD_SIZE in the environment bench.py is one rank and does
+    not spawn.  (world size 1 here: a lone stub rank over gloo through --force-dist.)"""
+    import json
+    port = 29900 + (os.getpid() % 90)
+    r = _run_bench("--gpus", "1", "--stub-cpu", "--force-dist", "--steps", "2", "--warmup", "1",
+                   env=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["config"]["self_launched"] is False
