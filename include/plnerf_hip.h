@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PLNERF_VERSION 240 /* major*10000 + minor*100 + patch */
+#define PLNERF_VERSION 300 /* major*10000 + minor*100 + patch */
 
 /* error codes */
 #define PLNERF_OK 0
@@ -50,9 +50,14 @@ extern "C" {
  * plnerf_mlp_status_offset(precision) bytes into the packed-weight buffer (sticky: the library only ever ORs into it;
  * the caller zeroes it when it allocates the buffer and after reading it).  Results computed with a bit set are
  * clamped, i.e. wrong: re-run in mode 1 (bf16x3) or 0.  plnerf_adam_step can be handed the word and then leaves the
- * weights untouched while it is non-zero.  Modes 0-2 carry fp32's exponent range and never set it. */
+ * weights untouched while it is non-zero.  Mode 0 never sets it; modes 1-2 (fp32's exponent range in the forward)
+ * only set PLNERF_RANGE_SAVED, and only in a training forward. */
 #define PLNERF_RANGE_ACTIVATION 1u /* an activation beyond +-65,504 was split into halves (forward)  */
 #define PLNERF_RANGE_WEIGHT 2u     /* a weight beyond +-65,504, or not finite, was packed             */
+#define PLNERF_RANGE_SAVED 4u      /* bf16-element modes (1, 2), training forward: an activation beyond +-65,504 was
+                                    * clamped on its way into the IEEE-half SAVED planes.  The forward result of that call
+                                    * is right (bf16 elements carry fp32's exponent range); the gradients of the matching
+                                    * plnerf_mlp_bwd are not -- use mode 0 for such a network. */
 /* Backward of modes 1-4: the saved activations and the pre-activation gradients are IEEE-half
  * planes, the latter under one power-of-two scale per launch (max |g_raw| -> [8,16), saturating
  * conversion); dgrad chain and weight gradients are single half MFMAs with fp32 accumulation.
@@ -259,16 +264,26 @@ size_t plnerf_mlp_bwd_workspace_bytes(int n_rows, int precision);
  * modes have two forward kernels; one stores its 256-wide planes row-major, the other in 32-row tiles of the MFMA
  * accumulator layout, which the weight-gradient stage reads directly.  Rows of the saved state are padded to a
  * multiple of 256: plnerf_mlp_saved_bytes accounts for it.) */
-int plnerf_mlp_saved_layout(int precision, int has_embedded);
+int plnerf_mlp_saved_layout(int precision, int has_embedded, int fwd_kernel);
+
+/* Which forward kernel a 16-bit mode runs on.  AUTO is the product's choice (mlp_api.hip: the register-resident kernel
+ * wherever it is the faster one); RR / PP force the register-resident / the ping-pong kernel wherever that variant
+ * exists, for A/B measurements and for the test suite's passes over both.  An explicit argument of the two calls it
+ * affects -- the library reads no environment variable and keeps no process-wide setting, so the saved layout is a
+ * pure function of (precision, has_embedded, fwd_kernel).  Ignored by PLNERF_PREC_FP32. */
+#define PLNERF_FWD_KERNEL_AUTO 0
+#define PLNERF_FWD_KERNEL_RR 1
+#define PLNERF_FWD_KERNEL_PP 2
 
 /* Forward.  Either (pts [n_rows,3] AND viewdirs [n_rows/samples_per_ray, 3]) with
  * embedded == NULL -- the encoding is computed in the kernel prologue, once per sample
  * for xyz and from the per-ray direction (input_ch 63 / input_ch_views 27 only) -- or
  * embedded [n_rows, input_ch + input_ch_views] (a caller-supplied encoding; NeRF.forward's
- * own signature).  saved == NULL for inference.  raw_out [n_rows,4]. */
+ * own signature).  saved == NULL for inference.  raw_out [n_rows,4].  fwd_kernel: PLNERF_FWD_KERNEL_* (pass the same
+ * value to plnerf_mlp_saved_layout). */
 int plnerf_mlp_fwd(const void* packed, int precision, const float* pts, const float* viewdirs,
                    const float* embedded, int input_ch, int input_ch_views, int n_rows,
-                   int samples_per_ray, float* raw_out, void* saved, plnerf_stream_t stream);
+                   int samples_per_ray, float* raw_out, void* saved, int fwd_kernel, plnerf_stream_t stream);
 
 /* Backward: g_raw [n_rows,4] -> gradients of all 24 parameter tensors, written (not
  * accumulated) to grads[24] (device pointers, same shapes as params).  Needs the `saved`
@@ -283,13 +298,18 @@ int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, int in
 /* ------------------------------------------------------------------------------------
  * Fused Adam step over a flat parameter buffer (torch.optim.Adam semantics as used at
  * run_plnerf.py:446-447, 1302-1303: betas (0.9,0.999), eps 1e-8, no weight decay, no
- * amsgrad).  step >= 1 is the step count AFTER this update. grad_scale multiplies the
- * gradient first (1/world_size after an all-reduce sum).  skip_if_set (nullable): a device uint32 -- the
- * status word of the network's packed buffer -- read by the kernel; while it is non-zero the launch changes
- * nothing (a step whose forward left the half range must not reach the weights). */
+ * amsgrad).  step >= 1 is the step count AFTER this update.  grad_scale multiplies the
+ * gradient first (1/world_size after an all-reduce sum); clip_value > 0 then clamps every entry to
+ * [-clip_value, clip_value] -- torch.nn.utils.clip_grad_value_ as the depth-supervised loop applies it between
+ * backward and step (depth_supervised_exps/run_nerf_sample_based_depth.py:1156; `grad` itself is left as it is);
+ * clip_value <= 0: no clipping.  skip_if_set, skip_if_set2 (nullable): device uint32 words -- the status words of the
+ * networks' packed buffers (one Adam over two networks: both) -- read by the kernel; while either is non-zero the
+ * launch changes nothing (a step whose forward left the half range must not reach the weights) and adds 1 to
+ * *withheld (nullable device uint32), so that the caller can take the steps that did not happen out of its step count. */
 int plnerf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                      int64_t n, float lr, float beta1, float beta2, float eps, int step,
-                     float grad_scale, const uint32_t* skip_if_set, plnerf_stream_t stream);
+                     float grad_scale, float clip_value, const uint32_t* skip_if_set, const uint32_t* skip_if_set2,
+                     uint32_t* withheld, plnerf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -16,8 +16,14 @@ LIB_PATH = os.environ.get("PLNERF_HIP_LIB") or os.path.join(_HERE, "libplnerf_hi
 MODE = {"constant": 0, "linear": 1}
 COLOR = {"midpoint": 0, "left": 1}
 PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3, "f16": 4}
+GUARDED_PRECISIONS = ("f16x3", "f16", "bf16x3", "bf16")      # modes whose kernels can set a bit of the range status word
 N_PARAM_TENSORS = 24
-RANGE_ACTIVATION, RANGE_WEIGHT = 1, 2      # bits of the packed buffer's status word (plnerf_hip.h)
+# plnerf_mlp_fwd's `fwd_kernel` argument (PLNERF_FWD_KERNEL_*).  The library has no setting of its own; this BINDING
+# takes its default from the environment (PLNERF_FWD_KERNEL=rr | pp: the test suite's and tools/' passes over both
+# forward kernels) and hands it to every call.
+FWD_KERNELS = {"auto": 0, "rr": 1, "pp": 2}
+FWD_KERNEL = FWD_KERNELS.get(os.environ.get("PLNERF_FWD_KERNEL") or "auto", 0)
+RANGE_ACTIVATION, RANGE_WEIGHT, RANGE_SAVED = 1, 2, 4      # bits of the packed buffer's status word (plnerf_hip.h)
 
 c_f = ctypes.c_void_p      # device pointer
 c_i = ctypes.c_int
@@ -49,10 +55,11 @@ SIGNATURES = {
     "plnerf_mlp_pack_weights": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_i, c_i, c_i, c_f, c_s]),
     "plnerf_mlp_saved_bytes": (ctypes.c_size_t, [c_i, c_i]),
     "plnerf_mlp_bwd_workspace_bytes": (ctypes.c_size_t, [c_i, c_i]),
-    "plnerf_mlp_fwd": (c_i, [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_s]),
+    "plnerf_mlp_fwd": (c_i, [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_s]),
     "plnerf_mlp_bwd": (c_i, [c_f, c_i, c_f, c_i, c_i, c_i, c_f, c_i, c_f, ctypes.POINTER(ctypes.c_void_p), c_s]),
-    "plnerf_mlp_saved_layout": (c_i, [c_i, c_i]),
-    "plnerf_adam_step": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_int64] + [ctypes.c_float] * 4 + [c_i, ctypes.c_float, c_f, c_s]),
+    "plnerf_mlp_saved_layout": (c_i, [c_i, c_i, c_i]),
+    "plnerf_adam_step": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_int64] + [ctypes.c_float] * 4 + [c_i, ctypes.c_float, ctypes.c_float,
+                                c_f, c_f, c_f, c_s]),
     "plnerf_mlp_status_offset": (ctypes.c_size_t, [c_i]),
 }
 

@@ -1,9 +1,6 @@
 // MLP entry points of the C ABI (include/plnerf_hip.h): argument validation and dispatch on
 // the precision mode.  Kernels live in mlp_f32.hip (exact fp32 MFMA; also the shared
 // weight-gradient stage) and mlp_bf16.hip (bf16 / 3-term bf16 split MFMA).
-#include <cstdlib>
-#include <cstring>
-
 #include "common.h"
 #include "mlp_internal.h"
 #include "mlp_layout.h"
@@ -26,25 +23,18 @@ inline bool geometry_ok(int input_ch, int input_ch_views) {
 // caller-embedded input; its saved planes leave in the tiled layout of mlp_layout.h, which the weight-gradient stage
 // reads as it is.  The plain mode (f16) uses it for inference with the in-kernel encoding (two row tiles per wave:
 // +18 %) and keeps the ping-pong kernel for the training forward (its 5.3 KB of plane stores per row come out of eight
-// waves per CU there, out of four here: 1.22 vs 1.39 ms) and for embedded inputs.  PLNERF_FWD_KERNEL=rr | pp forces
-// one kernel wherever it exists (A/B measurements, and the test suite's other passes).  Read once.
-inline int forced_kernel() {      // 0 = default split, 1 = rr, 2 = pp
-    static const int v = [] {
-        const char* e = std::getenv("PLNERF_FWD_KERNEL");
-        if (e && std::strcmp(e, "rr") == 0) return 1;
-        if (e && std::strcmp(e, "pp") == 0) return 2;
-        return 0;
-    }();
-    return v;
-}
-inline bool use_rr(const void* saved, int ns, bool embedded) {
+// waves per CU there, out of four here: 1.22 vs 1.39 ms) and for embedded inputs.  `fwd_kernel` (an ABI argument:
+// PLNERF_FWD_KERNEL_AUTO / _RR / _PP) forces one kernel wherever it exists (A/B measurements, and the test suite's
+// other passes); the library itself reads no environment.
+inline bool kernel_arg_ok(int k) { return k == PLNERF_FWD_KERNEL_AUTO || k == PLNERF_FWD_KERNEL_RR || k == PLNERF_FWD_KERNEL_PP; }
+inline bool use_rr(bool training, int ns, bool embedded, int forced) {
     if (embedded && !impl::rr_embedded_ok(ns)) return false;      // a caller-embedded input: split mode only
-    return forced_kernel() == 1 || (forced_kernel() == 0 && (ns == 2 || !saved));
+    return forced == PLNERF_FWD_KERNEL_RR || (forced == PLNERF_FWD_KERNEL_AUTO && (ns == 2 || !training));
 }
 // bf16 elements: inference of both modes; the split mode also for the training forward and caller-embedded inputs
-inline bool use_rr_bf16(const void* saved, int ns, bool embedded) {
-    if (forced_kernel() == 2) return false;
-    return ns == 2 || (!saved && !embedded);
+inline bool use_rr_bf16(bool training, int ns, bool embedded, int forced) {
+    if (forced == PLNERF_FWD_KERNEL_PP) return false;
+    return ns == 2 || (!training && !embedded);
 }
 }  // namespace
 
@@ -56,7 +46,7 @@ inline size_t sections_bytes(int precision) {
     return 0;
 }
 inline unsigned* status_word(void* packed, int precision) {
-    return f16_of(precision) ? (unsigned*)((unsigned char*)packed + sections_bytes(precision)) : nullptr;
+    return ns_of(precision) ? (unsigned*)((unsigned char*)packed + sections_bytes(precision)) : nullptr;      // every 16-bit mode
 }
 
 extern "C" size_t plnerf_mlp_packed_bytes(int precision) {
@@ -90,9 +80,11 @@ extern "C" size_t plnerf_mlp_saved_bytes(int n_rows, int precision) {
 
 // layout of the 256-wide saved planes the forward of this configuration writes (lay::SV_LAYOUT_*): the backward is
 // told, so that whichever forward kernel ran, the weight-gradient stage reads its planes as they are
-extern "C" int plnerf_mlp_saved_layout(int precision, int has_embedded) {
-    if (f16_of(precision)) return use_rr((const void*)1, ns_of(precision), has_embedded != 0) ? lay::SV_LAYOUT_TILED : lay::SV_LAYOUT_ROWS;
-    return use_rr_bf16((const void*)1, ns_of(precision), has_embedded != 0) ? lay::SV_LAYOUT_TILED : lay::SV_LAYOUT_ROWS;
+extern "C" int plnerf_mlp_saved_layout(int precision, int has_embedded, int fwd_kernel) {
+    if (!known(precision) || !kernel_arg_ok(fwd_kernel)) return PLNERF_EINVAL;
+    if (!ns_of(precision)) return lay::SV_LAYOUT_ROWS;
+    if (f16_of(precision)) return use_rr(true, ns_of(precision), has_embedded != 0, fwd_kernel) ? lay::SV_LAYOUT_TILED : lay::SV_LAYOUT_ROWS;
+    return use_rr_bf16(true, ns_of(precision), has_embedded != 0, fwd_kernel) ? lay::SV_LAYOUT_TILED : lay::SV_LAYOUT_ROWS;
 }
 
 extern "C" size_t plnerf_mlp_bwd_workspace_bytes(int n_rows, int precision) {
@@ -105,8 +97,10 @@ extern "C" size_t plnerf_mlp_bwd_workspace_bytes(int n_rows, int precision) {
 
 extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pts, const float* viewdirs,
                               const float* embedded, int input_ch, int input_ch_views, int n_rows,
-                              int samples_per_ray, float* raw_out, void* saved, plnerf_stream_t stream) {
+                              int samples_per_ray, float* raw_out, void* saved, int fwd_kernel,
+                              plnerf_stream_t stream) {
     if (!known(precision)) return PLNERF_ENOSYS;
+    if (!kernel_arg_ok(fwd_kernel)) return PLNERF_EINVAL;
     if (n_rows < 0 || !geometry_ok(input_ch, input_ch_views)) return PLNERF_EINVAL;
     // the in-kernel encoding is the reference's default one: 3 + 6*10 and 3 + 6*4 channels
     if (!embedded && (input_ch != lay::XYZ_CH || input_ch_views != lay::DIR_CH)) return PLNERF_EINVAL;
@@ -116,15 +110,15 @@ extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pt
     if (precision == PLNERF_PREC_FP32)
         return impl::f32_fwd(packed, pts, viewdirs, embedded, input_ch, input_ch_views, n_rows, samples_per_ray,
                              raw_out, saved, (hipStream_t)stream);
-    if (f16_of(precision) && use_rr(saved, ns_of(precision), embedded != nullptr))
+    if (f16_of(precision) && use_rr(saved != nullptr, ns_of(precision), embedded != nullptr, fwd_kernel))
         return impl::rr_fwd(packed, (const unsigned char*)packed + impl::bf16_packed_bytes(ns_of(precision)),
                             ns_of(precision), pts, viewdirs, embedded, input_ch, input_ch_views, n_rows, samples_per_ray,
                             raw_out, saved, status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);
     // bf16 elements: the register-resident kernel serves inference with the in-kernel encoding (unless pp is forced)
-    if (!f16_of(precision) && use_rr_bf16(saved, ns_of(precision), embedded != nullptr))
+    if (!f16_of(precision) && use_rr_bf16(saved != nullptr, ns_of(precision), embedded != nullptr, fwd_kernel))
         return impl::rr_fwd_bf16(packed, (const unsigned char*)packed + impl::bf16_packed_bytes(ns_of(precision)),
                                  ns_of(precision), pts, viewdirs, embedded, input_ch, input_ch_views, n_rows, samples_per_ray,
-                                 raw_out, saved, (hipStream_t)stream);
+                                 raw_out, saved, status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);
     return impl::bf16_fwd(packed, ns_of(precision), f16_of(precision), pts, viewdirs, embedded, input_ch,
                           input_ch_views, n_rows, samples_per_ray, raw_out, saved,
                           status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);

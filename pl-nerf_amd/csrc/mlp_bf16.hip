@@ -72,7 +72,7 @@ int bf16_fwd(const void* packed, int ns, int f16, const float* pts, const float*
     return f16 ? plnerf_h16_f16::h16_fwd(packed, ns, pts, viewdirs, embedded, xyz_ch, dir_ch, n_rows, samples_per_ray,
                                          raw_out, saved, status, st)
                : plnerf_h16_bf16::h16_fwd(packed, ns, pts, viewdirs, embedded, xyz_ch, dir_ch, n_rows, samples_per_ray,
-                                          raw_out, saved, nullptr, st);
+                                          raw_out, saved, status, st);      // (bf16 elements: PLNERF_RANGE_SAVED only)
 }
 
 int bf16_dgrad(const void* packed, int ns, const float* g_raw, int n_rows, const void* saved, void* dz,

@@ -59,7 +59,7 @@ int rr_fwd(const void* packed, const void* section, int ns, const float* pts, co
 int rr_pack_bf16(const float* const* params, int xyz_ch, int dir_ch, int ns, void* section, hipStream_t st);
 int rr_fwd_bf16(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs,
                 const float* embedded, int in_ch, int view_ch, int n_rows, int samples_per_ray, float* raw_out, void* saved,
-                hipStream_t st);
+                unsigned* status, hipStream_t st);
 
 }  // namespace impl
 }  // namespace plnerf

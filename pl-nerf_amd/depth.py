@@ -18,6 +18,7 @@ import os
 import numpy as np
 import torch
 
+from . import _lib as L
 from . import functional as Fn
 from . import raybatch as RB
 from .nerf import Embedder, NeRF
@@ -299,8 +300,8 @@ def create_nerf(args, scene_render_params=None, device=None):
         return run_network(inputs, viewdirs, embedded_cam, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
                            bb_center=box[0], bb_scale=box[1], netchunk=getattr(args, "netchunk", 1024 * 64))
     # (optim.FlatAdam on the GPU: one launch per network's gradient buffer)
-    half_range = device.type == "cuda" and getattr(args, "precision", "fp32") in ("f16x3", "f16")
-    extra = {"guards": [n.status_word() for n in (model, model_fine) if n is not None]} if half_range else {}
+    half_range = device.type == "cuda" and getattr(args, "precision", "fp32") in L.GUARDED_PRECISIONS
+    extra = {"guards": [n for n in (model, model_fine) if n is not None]} if half_range else {}
     optimizer = (FlatAdam if device.type == "cuda" else torch.optim.Adam)(params=grad_vars, lr=args.lrate,
                                                                            betas=(0.9, 0.999), **extra)
     start = 0
@@ -321,16 +322,29 @@ class DepthTrainStep:
     loss = mse(rgb) + space_carving_weight * space_carving(pred_hyp, target_h) + mse(rgb0); backward;
     clip_grad_value_(0.1); Adam.  `ray_batch` is the packed [R, 11] batch render_rays takes."""
 
-    def __init__(self, args, render_kwargs_train, optimizer, grad_vars, distributed=None):
+    def __init__(self, args, render_kwargs_train, optimizer, grad_vars, distributed=None, range_check_every=100):
         from . import dp
         self.args, self.kw, self.optimizer, self.grad_vars = args, render_kwargs_train, optimizer, grad_vars
         self.global_step = 0
-        nets = [n for n in (self.kw["network_fn"], self.kw.get("network_fine")) if n is not None]
+        # the 16-bit modes guard their Adam steps with the networks' range status words; the host looks every
+        # `range_check_every` steps, as train.TrainStep does (0: never -- the caller does)
+        self.range_check_every = int(range_check_every)
+        nets = self.nets = [n for n in (self.kw["network_fn"], self.kw.get("network_fine")) if n is not None]
         distributed = torch.distributed.is_initialized() if distributed is None else distributed
         self.bucket = None
         if distributed and torch.distributed.get_world_size() > 1:
             dp.broadcast_parameters(nets)      # replicas start from rank 0's weights (see train.TrainStep)
+            dp.broadcast_optimizer_state([optimizer])
             self.bucket = dp.GradientBucket(nets)
+
+    def check_range(self):
+        """As train.TrainStep.check_range: reconcile withheld steps, raise on a set range status word."""
+        if hasattr(self.optimizer, "withheld_steps"):
+            self.optimizer.withheld_steps()
+        for net in self.nets:
+            if getattr(net, "precision", None) in L.GUARDED_PRECISIONS and net.is_supported() and \
+                    next(net.parameters()).is_cuda:
+                net.check_range()
 
     def __call__(self, ray_batch, target_s, target_h, space_carving_mask=None, cached_u=None, pytest=False):
         a = self.args
@@ -352,7 +366,12 @@ class DepthTrainStep:
         loss.backward()
         if self.bucket is not None:
             self.bucket.allreduce_mean()
-        torch.nn.utils.clip_grad_value_(self.grad_vars, 0.1)
-        self.optimizer.step()
+        if isinstance(self.optimizer, FlatAdam):
+            self.optimizer.step(clip_value=0.1)      # clip_grad_value_(0.1) folded into the step kernel (:1156)
+        else:
+            torch.nn.utils.clip_grad_value_(self.grad_vars, 0.1)
+            self.optimizer.step()
         self.global_step += 1
+        if self.range_check_every and self.global_step % self.range_check_every == 0:
+            self.check_range()
         return loss.detach(), img_loss.detach(), sc.detach(), out

@@ -15,6 +15,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from ._lib import GUARDED_PRECISIONS
+
 
 def init_from_env(backend=None, force=False):
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun's contract).
@@ -91,6 +93,24 @@ class GradientBucket:
         self._works.append((work, flat))
         self._reduced[mi] = True
 
+    def _sync_status(self, group, world):
+        """The range guard is per network AND per rank, the gradient is not: a rank whose forward clamped has
+        contributed a wrong gradient to the average, so EVERY rank must withhold this step -- and every rank must raise
+        at the next check_range(), not just one while the others block in the next collective.  One 8-byte MAX
+        all-reduce of the ranks' status words (bit masks of 1, 2, 4: MAX of the OR-able words keeps "non-zero" and is
+        available on every backend), written back into each network's word before the Adam launches read it."""
+        if world <= 1:
+            return
+        words = [m.status_word() for m in self.modules
+                 if hasattr(m, "status_word") and getattr(m, "precision", None) in GUARDED_PRECISIONS
+                 and next(m.parameters()).is_cuda]
+        if not words:
+            return
+        both = torch.cat(words)
+        dist.all_reduce(both, op=dist.ReduceOp.MAX, group=group)
+        for w, v in zip(words, both.split(1)):
+            w.copy_(v)
+
     def pending(self):
         """Collectives enqueued by the hooks and not yet waited for (for tests / diagnostics)."""
         return len(self._works)
@@ -141,6 +161,7 @@ class GradientBucket:
         for work, flat in self._works:
             work.wait()
             flat.mul_(1.0 / world)
+        self._sync_status(group, world)
         if ev is not None:
             ev[1].record()
         self._works = []
@@ -151,6 +172,38 @@ class GradientBucket:
             self._fallback(rest, world)
             n += 1
         return n
+
+
+def broadcast_optimizer_state(optimizers, src=0, group=None):
+    """Rank `src`'s Adam moments and step counts to every rank (a checkpoint may have been restored on one rank only:
+    replicas that share weights but not moments diverge at the first step)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for opt in optimizers:
+        for g in opt.param_groups:
+            for p in g['params']:
+                st = opt.state.get(p)
+                have = torch.tensor([1 if st else 0], device=p.device)
+                dist.broadcast(have, src=src, group=group)
+                if not int(have.item()):
+                    continue
+                if not st:      # this rank has no state yet: torch.optim.Adam's layout
+                    st = opt.state[p] = {'step': torch.tensor(0.0), 'exp_avg': torch.zeros_like(p),
+                                         'exp_avg_sq': torch.zeros_like(p)}
+                for k in ('exp_avg', 'exp_avg_sq'):
+                    dist.broadcast(st[k], src=src, group=group)
+                step = torch.as_tensor(float(st['step']), device=p.device).reshape(1)
+                dist.broadcast(step, src=src, group=group)
+                st['step'] = torch.tensor(float(step.item()))
+
+
+def broadcast_scalar(value, src=0, group=None, device=None):
+    """Rank `src`'s Python number on every rank (the loop's global_step, hence its learning rate)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return value
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.broadcast(t, src=src, group=group)
+    return type(value)(t.item())
 
 
 def broadcast_parameters(modules, src=0, group=None):

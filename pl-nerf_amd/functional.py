@@ -316,11 +316,11 @@ class MlpFn(torch.autograd.Function):
         L.check(L.lib().plnerf_mlp_fwd(
             L.dptr(packed, "packed"), prec, L.dptr(pts_c, "pts"), L.dptr(vd_c, "viewdirs"),
             L.dptr(emb_c, "embedded"), int(net.input_ch), int(net.hip_view_ch), n_rows, int(spr), L.dptr(raw),
-            L.dptr(saved), L.stream()), "plnerf_mlp_fwd")
+            L.dptr(saved), L.FWD_KERNEL, L.stream()), "plnerf_mlp_fwd")
         if timer is not None:
             ev[1].record()
         ctx.net, ctx.prec, ctx.n_rows = net, prec, n_rows
-        ctx.saved_layout = L.lib().plnerf_mlp_saved_layout(prec, int(emb_c is not None))
+        ctx.saved_layout = L.lib().plnerf_mlp_saved_layout(prec, int(emb_c is not None), L.FWD_KERNEL)
         ctx.saved_acts = saved
         ctx.packed = packed
         ctx.param_shapes = [p.shape for p in params]

@@ -250,7 +250,9 @@ class NeRF(nn.Module):
     def range_status(self, reset=False):
         """Bits set since the word was last cleared (synchronises): _lib.RANGE_ACTIVATION -- a forward met an activation
         beyond the IEEE-half range (the `f16x3` / `f16` modes clamp there: their result is wrong; `bf16x3` carries
-        fp32's exponent range); _lib.RANGE_WEIGHT -- a weight beyond it (or not finite) was packed."""
+        fp32's exponent range in the forward); _lib.RANGE_WEIGHT -- a weight beyond it (or not finite) was packed;
+        _lib.RANGE_SAVED -- a training forward of a bf16-element mode clamped an activation on its way into the IEEE-half
+        saved planes (forward right, gradients wrong)."""
         w = self.status_word()
         bits = int(w.item())
         if reset and bits:
@@ -258,14 +260,22 @@ class NeRF(nn.Module):
         return bits
 
     def check_range(self):
-        """Raise if a forward of this network left the half range since the last check (and clear the word)."""
+        """Raise if a kernel of this network left the half range since the last check (and clear the word)."""
         bits = self.range_status(reset=True)
         if bits:
-            what = [n for b, n in ((L.RANGE_ACTIVATION, "an activation"), (L.RANGE_WEIGHT, "a weight")) if bits & b]
+            what = [n for b, n in ((L.RANGE_ACTIVATION, "an activation"), (L.RANGE_WEIGHT, "a weight"),
+                                   (L.RANGE_SAVED, "an activation saved for the backward")) if bits & b]
+            if bits & (L.RANGE_ACTIVATION | L.RANGE_WEIGHT):
+                advice = ("results since the last check were clamped and the optimizer steps were withheld.  Use "
+                          "precision='bf16x3' (fp32 exponent range in the forward, same speed) for inference, 'fp32' for "
+                          "training this network")
+            else:
+                advice = ("the forward results were right (bf16 elements carry fp32's exponent range) but the IEEE-half "
+                          "planes the backward reads were clamped: the gradients of those steps were wrong and the "
+                          "optimizer steps were withheld.  Train this network in precision='fp32'")
             raise FloatingPointError(
                 f"plnerf_amd: {' and '.join(what)} exceeded the IEEE-half range (65,504) in precision={self.precision!r}: "
-                "results since the last check were clamped and the optimizer steps were withheld.  Use "
-                "precision='bf16x3' (fp32 exponent range, same speed) or 'fp32' for this network.")
+                + advice + ".")
 
     # -- reference interface --------------------------------------------------------
     def forward(self, x):

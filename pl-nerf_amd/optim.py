@@ -55,12 +55,19 @@ def flat_view_of(tensors):
 
 class FlatAdam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, guards=None):
-        """guards: optional list of 1-element int32 device tensors (NeRF.status_word()); while any of them is non-zero
-        the step kernels leave parameters and moments untouched (a step whose forward left the half range must not
-        reach the weights; the host finds out at its next NeRF.check_range())."""
+        """guards: up to two networks (objects with `.status_word()`: nerf.NeRF) or 1-element int32 device tensors;
+        while the range status word of any of them is non-zero the step kernels leave parameters and moments untouched
+        (a step whose forward left the half range must not reach the weights) and count the launch in a device word;
+        `withheld_steps()` -- called by the train steps' check_range() polling -- takes those steps back out of the
+        host-side step counts, so that the bias corrections do not drift.  Networks are resolved to their status word
+        at step time (the packed buffer a word lives in is re-allocated when a network changes device or precision)."""
         super().__init__(params, lr=lr, betas=betas, eps=eps)
         self.guards = list(guards or [])
+        if len(self.guards) > 2:
+            raise ValueError("FlatAdam: at most two guard words per optimizer (plnerf_adam_step takes two)")
         self._flat = []          # per group: dict(param, m, v, grad, step) or None (torch's own step)
+        self._withheld = None    # device counter of guarded launches that changed nothing
+        self._launches_per_step = 1
         for group in self.param_groups:
             ps = group['params']
             ok = len(ps) > 0 and all(p.is_cuda and p.dtype == torch.float32 and p.device == ps[0].device for p in ps)
@@ -69,13 +76,20 @@ class FlatAdam(torch.optim.Adam):
     def _flatten(self, ps):
         sizes = [p.numel() for p in ps]
         dev = ps[0].device
-        flat = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+        # parameters that already are consecutive slices of one buffer (another FlatAdam over the same network: the
+        # reference's single-pass configuration steps TWO Adams over the coarse weights, run_plnerf.py:438-447) stay
+        # where they are -- re-homing them would orphan the other optimizer's buffer
+        flat = flat_view_of([p.data for p in ps])
+        adopt = flat is not None
+        if not adopt:
+            flat = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
         m = torch.zeros_like(flat)
         v = torch.zeros_like(flat)
         for p, fp, fm, fv in zip(ps, flat.split(sizes), m.split(sizes), v.split(sizes)):
-            fp = fp.view(p.shape)
-            fp.copy_(p.data)
-            p.data = fp
+            if not adopt:
+                fp = fp.view(p.shape)
+                fp.copy_(p.data)
+                p.data = fp
             # torch's own state layout, so that state_dict() is the reference's optimizer_state_dict
             self.state[p] = {'step': torch.tensor(0.0), 'exp_avg': fm.view(p.shape), 'exp_avg_sq': fv.view(p.shape)}
         return {'param': flat, 'm': m, 'v': v, 'sizes': sizes}
@@ -96,20 +110,43 @@ class FlatAdam(torch.optim.Adam):
                 st['exp_avg'], st['exp_avg_sq'] = fm.view(p.shape), fv.view(p.shape)
                 st['step'] = torch.as_tensor(float(st['step']), dtype=torch.float32)
 
-    def _guard_ptr(self, first, last):
-        """One status word can guard a launch.  With several guards (one Adam over both networks, the depth variant)
-        they are OR-ed into a scratch word first."""
+    def _guard_ptrs(self):
+        """The (up to two) status words a launch is guarded by, resolved NOW: a network's packed buffer -- and with it
+        the word -- is re-allocated when the network moves or changes precision, a cached view would watch dead memory."""
+        ptrs = []
+        for g in self.guards:
+            word = g.status_word() if hasattr(g, "status_word") else g
+            ptrs.append(L.dptr(word, "guard", torch.int32))
+        return (ptrs + [None, None])[:2]
+
+    def _withheld_ptr(self, dev):
         if not self.guards:
             return None
-        if len(self.guards) == 1:
-            return L.dptr(self.guards[0], "guard", torch.int32)
-        if getattr(self, "_guard_any", None) is None:
-            self._guard_any = torch.zeros(1, device=self.guards[0].device, dtype=torch.int32)
-        self._guard_any.copy_(torch.stack([g.reshape(()) for g in self.guards]).amax().reshape(1))
-        return L.dptr(self._guard_any, "guard", torch.int32)
+        if self._withheld is None or self._withheld.device != dev:
+            self._withheld = torch.zeros(1, device=dev, dtype=torch.int32)
+        return L.dptr(self._withheld, "withheld", torch.int32)
+
+    def withheld_steps(self, reset=True):
+        """Steps the guarded kernels withheld since the last call (synchronises: one 4-byte read).  With `reset` the
+        host-side step counts -- advanced before each launch, because the host cannot know what the device decided --
+        are wound back by that many, so Adam's bias corrections are those of the steps that really happened."""
+        if self._withheld is None:
+            return 0
+        n = int(self._withheld.item()) // max(self._launches_per_step, 1)
+        if n and reset:
+            self._withheld.zero_()
+            for group in self.param_groups:
+                for p in group['params']:
+                    st = self.state.get(p)
+                    if st and 'step' in st:
+                        st['step'].sub_(float(n)).clamp_(min=0.0)
+        return n
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0):
+    def step(self, closure=None, grad_scale=1.0, clip_value=0.0):
+        """clip_value > 0: every gradient entry is clamped to [-clip_value, clip_value] inside the step kernel (what
+        torch.nn.utils.clip_grad_value_ between backward and step does, run_nerf_sample_based_depth.py:1156 -- minus
+        its 48 launches; `.grad` itself keeps the unclipped values)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -117,8 +154,12 @@ class FlatAdam(torch.optim.Adam):
         if any(fl is None for fl in self._flat):
             if grad_scale != 1.0:
                 raise RuntimeError("FlatAdam: grad_scale needs flat (GPU fp32) parameter groups")
+            if clip_value > 0.0:
+                torch.nn.utils.clip_grad_value_([p for g in self.param_groups for p in g['params']], clip_value)
             super().step(closure=None)      # (the closure, if any, was evaluated above)
             return loss
+        guard_a, guard_b = self._guard_ptrs()
+        launches = 0
         for group, fl in zip(self.param_groups, self._flat):
             ps = group['params']
             if all(p.grad is None for p in ps):
@@ -157,7 +198,9 @@ class FlatAdam(torch.optim.Adam):
                     L.check(L.lib().plnerf_adam_step(
                         L.dptr(fl['param'][lo:hi]), L.dptr(gview), L.dptr(fl['m'][lo:hi]), L.dptr(fl['v'][lo:hi]),
                         hi - lo, float(group['lr']), float(b1), float(b2), float(group['eps']),
-                        int(steps[0].item()), float(grad_scale), self._guard_ptr(first, last), L.stream()),
-                        "plnerf_adam_step")
+                        int(steps[0].item()), float(grad_scale), float(clip_value), guard_a, guard_b,
+                        self._withheld_ptr(fl['param'].device), L.stream()), "plnerf_adam_step")
+                    launches += 1
                 k = e
+        self._launches_per_step = max(launches, 1)
         return loss

@@ -8,6 +8,7 @@ switch to this module unchanged.  Everything numerical happens in libplnerf_hip.
 import numpy as np
 import torch
 
+from . import _lib as L
 from . import functional as Fn
 from . import raybatch as RB
 from .nerf import NeRF, Embedder, get_embedder
@@ -128,6 +129,10 @@ def _draw_u(prefix_shape, n, det, pytest, device):
         return Fn.numpy_uniform(list(prefix_shape) + [n], device)
     if det:
         return Fn.cpu_linspace(n, device)
+    if Fn.DRAWS is not None and len(prefix_shape) == 1:
+        # an installed DrawSource supplies EVERY draw of the step (the constant-mode sampler and the `constant_init`
+        # warm-up included): counter-based on the global ray id, so the step does not depend on the sharding
+        return Fn.DRAWS.uniform(int(prefix_shape[0]), n, Fn.DrawSource.U, device)
     return torch.rand(list(prefix_shape) + [n], device=device)
 
 
@@ -156,6 +161,13 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_
     + rgb0, disp0, depth0, acc0, z_std if N_importance > 0)."""
     dev = ray_batch.device
     N_rays = ray_batch.shape[0]
+    if torch.is_grad_enabled() and getattr(ray_batch, "requires_grad", False):
+        # In the reference autograd would carry d(loss)/d(rays) through z_vals, the sample positions AND the MLP's
+        # inputs; the HIP path differentiates with respect to the network parameters only (SURVEY.md section 8d: the
+        # positions carry no gradient on the training path).  Returning a partial gradient would be silently wrong.
+        raise NotImplementedError(
+            "plnerf_amd: render_rays has no gradient with respect to the ray batch (origins / directions / bounds); "
+            "detach the rays -- the path differentiates with respect to the network parameters only")
     if isinstance(ray_batch, RB.RayColumns):
         rays_o, rays_d, near, far, viewdirs = (ray_batch.rays_o, ray_batch.rays_d, ray_batch.near.reshape(-1, 1),
                                                ray_batch.far.reshape(-1, 1), ray_batch.viewdirs)
@@ -167,11 +179,9 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_
         near, far = ray_batch[:, 6:7].contiguous(), ray_batch[:, 7:8].contiguous()
 
     t_vals = Fn.cpu_linspace(N_samples, dev)
-    # The ray batch carries no gradient on this path (the reference never differentiates through the rays and
-    # the kernels downstream give none to positions), so the prologue's element-wise chain runs as ONE kernel
-    # (depths + positions, bit-identical to the torch expressions below) -- which stay for a batch that does require
-    # grad, so that z_vals remains on the caller's tape.
-    fused_glue = ray_batch.is_cuda and N_rays > 0 and not (torch.is_grad_enabled() and ray_batch.requires_grad)
+    # The ray batch carries no gradient on this path (refused above), so the prologue's element-wise chain runs as ONE
+    # kernel (depths + positions, bit-identical to the torch expressions below, which remain for an empty batch).
+    fused_glue = ray_batch.is_cuda and N_rays > 0
     # Random draws: pytest=True replays the reference's numpy draws; otherwise an installed functional.DrawSource
     # supplies counter-based draws (inside the consuming kernels on the fused path), else torch.rand as the
     # reference does.
@@ -311,7 +321,7 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
             rgbs.append(rgb.cpu().numpy())
             disps.append(disp.cpu().numpy())
             for net in (render_kwargs.get('network_fn'), render_kwargs.get('network_fine')):
-                if isinstance(net, NeRF) and net.precision in ("f16x3", "f16") and net.is_supported():
+                if isinstance(net, NeRF) and net.precision in L.GUARDED_PRECISIONS and net.is_supported():
                     net.check_range()       # (the frame was just synchronised) a clamped frame must not pass silently
     return np.stack(rgbs, 0), np.stack(disps, 0)
 
@@ -343,19 +353,20 @@ def create_nerf(args, device=None):
                            netchunk=args.netchunk)
 
     on_gpu = device.type == "cuda"
-    half_range = on_gpu and precision in ("f16x3", "f16")      # modes that clamp at the half maximum: guard the steps
+    # modes whose kernels can clamp at the IEEE-half maximum (forward: f16x3 / f16; saved planes: every 16-bit mode):
+    # the steps are guarded by the network's range status word
+    half_range = on_gpu and precision in L.GUARDED_PRECISIONS
 
     def guard(net):
-        return {"guards": [net.status_word()]} if (half_range and net.is_supported()) else {}
-    optimizer = (FlatAdam if on_gpu else torch.optim.Adam)(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999),
-                                                         **guard(model_fine if model_fine is not None else model))
+        return {"guards": [net]} if (half_range and net.is_supported()) else {}
+    adam = FlatAdam if on_gpu else torch.optim.Adam
+    optimizer = adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999),
+                     **(guard(model_fine if model_fine is not None else model) if on_gpu else {}))
     # Single-pass configuration (N_importance == 0): the reference builds BOTH Adams over the same (coarse)
-    # parameters and steps them one after the other.  A second FlatAdam would re-home the weights into its own flat
-    # buffer and orphan the first one's; torch's Adam steps the same views in place, which is the reference's
-    # behaviour.
-    coarse_adam = FlatAdam if (on_gpu and model_fine is not None) else torch.optim.Adam
-    optimizer_coarse = coarse_adam(params=coarse_vars, lr=args.coarse_lrate, betas=(0.9, 0.999),
-                                   **(guard(model) if coarse_adam is FlatAdam else {}))
+    # parameters and steps them one after the other.  The second FlatAdam adopts the flat buffer the first one
+    # re-homed the weights into (optim.FlatAdam._flatten) and carries the same guard.
+    optimizer_coarse = adam(params=coarse_vars, lr=args.coarse_lrate, betas=(0.9, 0.999),
+                            **(guard(model) if on_gpu else {}))
 
     start = 0
     candidates = RB.checkpoint_candidates(args)

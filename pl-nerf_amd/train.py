@@ -133,6 +133,8 @@ class TrainStep:
             # checkpoint may have been loaded on one rank only): averaged gradients applied to different weights
             # diverge silently
             dp.broadcast_parameters(self.nets)
+            dp.broadcast_optimizer_state([self.optimizer, self.optimizer_coarse])      # (moments, step counts)
+            self.global_step = dp.broadcast_scalar(self.global_step, device=next(self.nets[0].parameters()).device)
             self.bucket = dp.GradientBucket(self.nets)
 
     def learning_rate(self):
@@ -205,8 +207,14 @@ class TrainStep:
         return loss.detach(), psnr
 
     def check_range(self):
+        """Look at the networks' range status words (one 4-byte read each).  Steps the guarded Adam kernels withheld are
+        first taken back out of the optimizers' step counts; a set word raises FloatingPointError -- on every rank of a
+        data-parallel job at the same step (dp.GradientBucket shares the words before each optimizer step)."""
+        for opt in (self.optimizer, self.optimizer_coarse):
+            if hasattr(opt, "withheld_steps"):
+                opt.withheld_steps()
         for net in self.nets:
-            if getattr(net, "precision", None) in ("f16x3", "f16") and net.is_supported() and \
+            if getattr(net, "precision", None) in L.GUARDED_PRECISIONS and net.is_supported() and \
                     next(net.parameters()).is_cuda:
                 net.check_range()
 

@@ -64,12 +64,17 @@ def test_buffer_size_queries(built):
     assert L.plnerf_mlp_saved_bytes(1025, 3) - L.plnerf_mlp_saved_bytes(1024, 3) == 256 * (2528 * 2 + 272)
     # the layout tag a caller hands back to plnerf_mlp_bwd: the split modes write tiled planes (with or without a
     # caller-embedded input); exact fp32 and the plain 16-bit modes row-major
-    assert L.plnerf_mlp_saved_layout(0, 0) == 0 and L.plnerf_mlp_saved_layout(0, 1) == 0
-    if not os.environ.get("PLNERF_FWD_KERNEL"):
-        assert L.plnerf_mlp_saved_layout(3, 0) == 1 and L.plnerf_mlp_saved_layout(3, 1) == 1
-        assert L.plnerf_mlp_saved_layout(1, 0) == 1 and L.plnerf_mlp_saved_layout(1, 1) == 1
-        assert L.plnerf_mlp_saved_layout(4, 0) == 0 and L.plnerf_mlp_saved_layout(4, 1) == 0
-        assert L.plnerf_mlp_saved_layout(2, 0) == 0 and L.plnerf_mlp_saved_layout(2, 1) == 0
+    # the saved layout is a pure function of (precision, embedded input, forward-kernel argument): no environment
+    AUTO, RR, PP = 0, 1, 2
+    for k in (AUTO, RR, PP):
+        assert L.plnerf_mlp_saved_layout(0, 0, k) == 0 and L.plnerf_mlp_saved_layout(0, 1, k) == 0       # fp32: rows
+    assert L.plnerf_mlp_saved_layout(3, 0, AUTO) == 1 and L.plnerf_mlp_saved_layout(3, 1, AUTO) == 1     # f16x3: tiled
+    assert L.plnerf_mlp_saved_layout(1, 0, AUTO) == 1 and L.plnerf_mlp_saved_layout(1, 1, AUTO) == 1     # bf16x3
+    assert L.plnerf_mlp_saved_layout(4, 0, AUTO) == 0 and L.plnerf_mlp_saved_layout(4, 1, AUTO) == 0     # f16: ping-pong
+    assert L.plnerf_mlp_saved_layout(2, 0, AUTO) == 0 and L.plnerf_mlp_saved_layout(2, 1, AUTO) == 0
+    assert L.plnerf_mlp_saved_layout(3, 0, PP) == 0 and L.plnerf_mlp_saved_layout(1, 0, PP) == 0
+    assert L.plnerf_mlp_saved_layout(4, 0, RR) == 1 and L.plnerf_mlp_saved_layout(4, 1, RR) == 0         # no plain embedded rr
+    assert L.plnerf_mlp_saved_layout(3, 0, 7) < 0 and L.plnerf_mlp_saved_layout(9, 0, AUTO) < 0
     assert L.plnerf_mlp_packed_bytes(7) == 0
 
 
