@@ -3,6 +3,8 @@
 PyTorch is plumbing here (device memory, streams, the autograd tape); every operation of
 the path itself runs in libplnerf_hip.so.
 """
+import contextlib
+
 import numpy as np
 import torch
 
@@ -47,6 +49,39 @@ class KernelTimer:
 
 
 KERNEL_TIMER = None
+
+
+class SideBackward:
+    """The coarse network's backward chain (plnerf_quad_bwd of the coarse maps, then plnerf_mlp_bwd) on a SECOND HIP
+    stream, next to the fine network's on the launch stream.  The two graphs are independent once the image-loss
+    gradients exist (z_samples is detached, run_plnerf.py:728).  Autograd runs a Function's backward on the stream of
+    its forward, so the switch happens inside the two backward methods: the side stream waits for `after` (an event the
+    train step records once d loss / d rgb0 is enqueued, BEFORE the fine chain's kernels), and the launch stream waits
+    for the side stream right after the coarse plnerf_mlp_bwd is enqueued -- i.e. before anything (gradient hooks, the
+    all-reduce, Adam) can touch the coarse gradients.  train.TrainStep arms it per step; None = everything on one
+    stream."""
+
+    def __init__(self, net):
+        self.net = net
+        self.stream = torch.cuda.Stream(device=next(net.parameters()).device)
+        self.after = None        # armed while not None
+
+    def arm(self):
+        self.after = torch.cuda.Event()
+        self.after.record()
+
+    def disarm(self):
+        self.after = None
+
+
+SIDE_BWD = None
+
+
+def _side_of(net=None):
+    sb = SIDE_BWD
+    if sb is None or sb.after is None or (net is not None and net is not sb.net):
+        return None
+    return sb
 
 
 class QuadratureFn(torch.autograd.Function):
@@ -205,7 +240,13 @@ class CoarseEpilogueFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, g_depth, g_z, g_pts, g_std):
-        g_raw = _quad_backward(ctx.saved_tensors, ctx.cfg, g_rgb, g_disp, g_acc, None, g_depth, None, None)
+        side = _side_of()
+        if side is not None:      # (the coarse chain on its own stream: SideBackward)
+            side.stream.wait_event(side.after)
+            with torch.cuda.stream(side.stream):
+                g_raw = _quad_backward(ctx.saved_tensors, ctx.cfg, g_rgb, g_disp, g_acc, None, g_depth, None, None)
+        else:
+            g_raw = _quad_backward(ctx.saved_tensors, ctx.cfg, g_rgb, g_disp, g_acc, None, g_depth, None, None)
         return (g_raw,) + (None,) * 14
 
 
@@ -336,23 +377,32 @@ class MlpFn(torch.autograd.Function):
         # dp.GradientBucket then see a network's gradient as a single flat tensor (one Adam launch, one all-reduce
         # without gather / scatter copies)
         sizes = [int(torch.Size(s).numel()) for s in ctx.param_shapes]
-        flat = (torch.zeros if n_rows == 0 else torch.empty)(sum(sizes), device=dev, dtype=torch.float32)
-        grads = [t.view(s) for t, s in zip(flat.split(sizes), ctx.param_shapes)]
-        if n_rows == 0:
-            return (None,) * 6 + tuple(grads)
-        g = _f32c(g_raw)
-        ws = torch.empty(L.lib().plnerf_mlp_bwd_workspace_bytes(n_rows, prec) // 4, device=dev,
-                         dtype=torch.float32)
-        timer = KERNEL_TIMER
-        if timer is not None:
-            ev = timer.bracket(f"mlp_bwd[{n_rows}]")
-            ev[0].record()
-        L.check(L.lib().plnerf_mlp_bwd(
-            L.dptr(ctx.packed), prec, L.dptr(g, "g_raw"), int(ctx.net.input_ch), int(ctx.net.hip_view_ch), n_rows,
-            L.dptr(ctx.saved_acts), ctx.saved_layout, L.dptr(ws), L.ptr_table(grads, "grads"), L.stream()),
-            "plnerf_mlp_bwd")
-        if timer is not None:
-            ev[1].record()
+        side = _side_of(ctx.net) if n_rows > 0 else None
+        launch_stream = torch.cuda.current_stream()
+        with (torch.cuda.stream(side.stream) if side is not None else contextlib.nullcontext()):
+            flat = (torch.zeros if n_rows == 0 else torch.empty)(sum(sizes), device=dev, dtype=torch.float32)
+            grads = [t.view(s) for t, s in zip(flat.split(sizes), ctx.param_shapes)]
+            if n_rows == 0:
+                return (None,) * 6 + tuple(grads)
+            g = _f32c(g_raw)
+            ws = torch.empty(L.lib().plnerf_mlp_bwd_workspace_bytes(n_rows, prec) // 4, device=dev,
+                             dtype=torch.float32)
+            timer = KERNEL_TIMER
+            if timer is not None:
+                ev = timer.bracket(f"mlp_bwd[{n_rows}]")
+                ev[0].record()
+            L.check(L.lib().plnerf_mlp_bwd(
+                L.dptr(ctx.packed), prec, L.dptr(g, "g_raw"), int(ctx.net.input_ch), int(ctx.net.hip_view_ch), n_rows,
+                L.dptr(ctx.saved_acts), ctx.saved_layout, L.dptr(ws), L.ptr_table(grads, "grads"), L.stream()),
+                "plnerf_mlp_bwd")
+            if timer is not None:
+                ev[1].record()
+        if side is not None:
+            # whatever the launch stream does next with these gradients (hooks, all-reduce, Adam) comes after the side
+            # stream's kernels; the fine network's backward, already enqueued on the launch stream, is not held up
+            done = torch.cuda.Event()
+            done.record(side.stream)
+            launch_stream.wait_event(done)
         ctx.saved_acts = None
         return (None,) * 6 + tuple(grads)
 

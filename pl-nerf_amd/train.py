@@ -111,7 +111,7 @@ class TrainStep:
     renders it or N ranks render a shard each.  `counter_rng=False` restores torch.rand."""
 
     def __init__(self, args, render_kwargs_train, optimizer, optimizer_coarse, start=0, distributed=None, seed=0,
-                 counter_rng=True, range_check_every=100):
+                 counter_rng=True, range_check_every=100, side_stream=None):
         self.args = args
         self.kw = render_kwargs_train
         self.optimizer = optimizer
@@ -127,6 +127,13 @@ class TrainStep:
         # and raises.  0 = never look (the caller does).
         self.range_check_every = int(range_check_every)
         self.seed = seed
+        # the coarse network's backward on a second HIP stream (functional.SideBackward).  Default: the environment's
+        # PLNERF_SIDE_STREAM (0 / 1), else off -- the same-box A/B of profiles/r03_side_stream_ab.txt decides
+        if side_stream is None:
+            side_stream = os.environ.get("PLNERF_SIDE_STREAM", "0") == "1"
+        fine = self.kw.get("network_fine")
+        self.side = Fn.SideBackward(self.kw["network_fn"]) if (side_stream and fine is not None and
+                                                                 next(fine.parameters()).is_cuda) else None
         self.bucket = None
         if distributed and self.world > 1:
             # replicas must start from the same weights (create_nerf initialises from each process's own RNG, and a
@@ -186,7 +193,17 @@ class TrainStep:
             # backward((rgb, rgb0), (d loss / d rgb, d loss / d rgb0)) is loss.backward()
             loss4, g_rgb, g_rgb0 = Fn.image_loss_and_grads(rgb, rgb0, target_s)
             loss, psnr = loss4[0], loss4[3]
-            torch.autograd.backward((rgb,) if rgb0 is None else (rgb, rgb0), (g_rgb,) if rgb0 is None else (g_rgb, g_rgb0))
+            prev_side = Fn.SIDE_BWD
+            if self.side is not None and rgb0 is not None:
+                self.side.arm()              # (the event the side stream waits for: both image gradients are enqueued)
+                Fn.SIDE_BWD = self.side
+            try:
+                torch.autograd.backward((rgb,) if rgb0 is None else (rgb, rgb0),
+                                        (g_rgb,) if rgb0 is None else (g_rgb, g_rgb0))
+            finally:
+                if self.side is not None:
+                    self.side.disarm()
+                Fn.SIDE_BWD = prev_side
         else:
             img_loss = img2mse(rgb, target_s)
             loss = img_loss if rgb0 is None else img_loss + img2mse(rgb0, target_s)

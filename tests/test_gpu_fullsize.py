@@ -8,7 +8,8 @@ Stated tolerances:
   * coarse maps (continuous in the network output): 1e-5 abs+rel on EVERY ray -- the contract;
   * final maps pass through the sampler, which is discontinuous (a fine sample hops a cdf bin when the
     coarse network's output moves by an ulp): the NUMBER of rays beyond 1e-5 is asserted and printed per map --
-    0 on rgb / acc; depth and z_std may have a handful of hopping rays out of 4096 (bounds below);
+    0 on rgb; acc, depth and z_std may have a handful of hopping rays out of 4096 (bounds below; the exact-fp32 kernels
+    show the same handful -- measured: fp32 64+128 depth 5 rays, 128+64 depth 1 / z_std 2; f16x3 64+128 acc 1 / depth 9, 128+64 depth 1 / z_std 2);
   * one full-size training step: loss to 1e-5; every parameter tensor's gradient within the bound of the small-fixture
     tests (fp32: 2e-4 coarse / 2e-3 fine of max|g|; f16x3: 6e-3 / 3e-3, the half-plane backward).
 
@@ -25,9 +26,9 @@ from test_gpu_parity import assert_close, g, make_net, maxdiff
 pytestmark = pytest.mark.gpu
 R_FULL = 4096
 SAMPLINGS = [(64, 128), (128, 64)]
-# rays (of 4096) allowed beyond 1e-5 per final map: rgb and acc are continuous enough to admit none; a hopping fine sample
-# moves depth / disp / z_std of its ray
-MAX_RAYS_BEYOND = {"rgb_map": 0, "acc_map": 0, "depth_map": 8, "z_std": 16}
+# rays (of 4096) allowed beyond 1e-5 per final map: rgb admits none; a hopping fine sample moves acc / depth / z_std of
+# its ray (the kernels are deterministic and the draws fixed, so the counts are reproducible box to box)
+MAX_RAYS_BEYOND = {"rgb_map": 0, "acc_map": 2, "depth_map": 16, "z_std": 8}
 
 
 @pytest.fixture(scope="module")
@@ -72,17 +73,18 @@ def test_render_rays_at_baseline_size_vs_oracle(P, oracle_renders, sampling, pre
     # coarse pass: every ray inside the contract
     for k in ("rgb0", "acc0", "depth0", "disp0"):
         assert_close(got[k], ref[k], what=f"{precision} {ns}+{ni} {k}")
-    report = []
+    report, over = [], []
     for k, allowed in MAX_RAYS_BEYOND.items():
         d = (got[k].cpu() - ref[k]).abs()
         lim = 1e-5 * (1.0 + ref[k].abs())
         bad = d > lim
         n_bad = int((bad.any(-1) if bad.dim() > 1 else bad).sum())
         report.append(f"{k} max {float(d.max()):.2e} beyond {n_bad}")
-        assert n_bad <= allowed, f"{precision} {ns}+{ni} {k}: {n_bad} of {R_FULL} rays beyond 1e-5 (allowed {allowed})"
-    # the fine network's raw output on the rays whose samples did not hop: the sorted depths agree there
+        if n_bad > allowed:
+            over.append(f"{k}: {n_bad} of {R_FULL} rays beyond 1e-5 (allowed {allowed})")
     print(f"{precision} {ns}+{ni} x {R_FULL} rays: coarse rgb0 {maxdiff(got['rgb0'], ref['rgb0']):.2e}, depth0 "
           f"{maxdiff(got['depth0'], ref['depth0']):.2e}; final " + ", ".join(report))
+    assert not over, f"{precision} {ns}+{ni}: " + "; ".join(over)
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "fp32"])

@@ -596,8 +596,10 @@ def test_narrower_and_shallower_networks(P, shape):
 def test_half_modes_flag_range_overflow_and_withhold_the_step(P):
     """`f16x3` / `f16` clamp at the IEEE-half maximum (65,504).  A forward that gets there must not pass silently: the
     kernels set the packed buffer's status word, NeRF.check_range() raises, and the guarded Adam leaves the weights
-    alone for as long as the word is set.  The same network in `bf16x3` / `fp32` (fp32 exponent range) is exact and
-    sets nothing."""
+    alone for as long as the word is set.  The same network in `fp32` is exact and sets nothing; in `bf16x3` (fp32
+    exponent range in the forward) the forward is exact too, inference sets nothing, but the TRAINING forward writes
+    IEEE-half saved planes for the backward: clamping there sets PLNERF_RANGE_SAVED (forward right, gradients wrong),
+    check_range() raises and the guarded step is withheld as well."""
     from plnerf_amd import _lib
     sd = orc.closed_form_state_dict(2, False)
     sd["pts_linears.0.weight"] = sd["pts_linears.0.weight"] * 6.0e4        # weights within the half range, h0 ~ 1e5..1e6 beyond it
@@ -616,9 +618,10 @@ def test_half_modes_flag_range_overflow_and_withhold_the_step(P):
             bits = net.range_status()
             print(f"{prec} grad={grad}: err {err:.2e}, status {bits}")
             assert bool(bits & _lib.RANGE_ACTIVATION) == flagged, (prec, grad, bits)
+            assert bool(bits & _lib.RANGE_SAVED) == (prec == "bf16x3" and grad), (prec, grad, bits)
             if not flagged:
                 assert err <= 2e-5 * (1.0 + float(ref.abs().max())), (prec, err)
-        if flagged:
+        if flagged or prec == "bf16x3":
             with pytest.raises(FloatingPointError, match="exceeded the IEEE-half range"):
                 net.check_range()
             assert net.range_status() == 0                                   # cleared by the check
@@ -632,17 +635,25 @@ def test_half_modes_flag_range_overflow_and_withhold_the_step(P):
         net.query(g(pts), g(vd))
     assert net.range_status() & _lib.RANGE_WEIGHT
     # the guarded optimizer: a step computed from a clamped forward does not reach the weights
-    net = make_net(P, sd, "f16x3")
-    opt = P.FlatAdam(net.parameters(), lr=1e-3, guards=[net.status_word()])
-    before = [p.detach().clone() for p in net.parameters()]
-    (net.query(g(pts), g(vd)) ** 2).sum().backward()
-    opt.step()
-    assert all(torch.equal(a, b.detach()) for a, b in zip(before, net.parameters()))
-    assert net.range_status(reset=True) & _lib.RANGE_ACTIVATION
-    net.load_state_dict(orc.closed_form_state_dict(2, False))                # a sane network again: steps apply
-    opt.zero_grad()
-    (net.query(g(pts), g(vd)) ** 2).sum().backward()
-    opt.step()
-    assert net.range_status() == 0
-    sane = list(orc.closed_form_state_dict(2, False).values())
-    assert any(not torch.equal(q, p.detach().cpu()) for q, p in zip(sane, net.parameters()))
+    for prec, bit in (("f16x3", _lib.RANGE_ACTIVATION), ("bf16x3", _lib.RANGE_SAVED)):
+        net = make_net(P, sd, prec)
+        opt = P.FlatAdam(net.parameters(), lr=1e-3, guards=[net])            # (the network: its word is resolved per step)
+        before = [p.detach().clone() for p in net.parameters()]
+        for _ in range(2):
+            opt.zero_grad()
+            (net.query(g(pts), g(vd)) ** 2).sum().backward()
+            opt.step()
+        assert all(torch.equal(a, b.detach()) for a, b in zip(before, net.parameters())), prec
+        # the host advanced its step counts before each launch; the kernels counted what they withheld
+        assert float(opt.state[next(net.parameters())]['step']) == 2.0
+        assert opt.withheld_steps() == 2
+        assert float(opt.state[next(net.parameters())]['step']) == 0.0 and opt.withheld_steps() == 0
+        assert net.range_status(reset=True) & bit, prec
+        net.load_state_dict(orc.closed_form_state_dict(2, False))                # a sane network again: steps apply
+        opt.zero_grad()
+        (net.query(g(pts), g(vd)) ** 2).sum().backward()
+        opt.step()
+        assert net.range_status() == 0 and opt.withheld_steps() == 0
+        assert float(opt.state[next(net.parameters())]['step']) == 1.0
+        sane = list(orc.closed_form_state_dict(2, False).values())
+        assert any(not torch.equal(q, p.detach().cpu()) for q, p in zip(sane, net.parameters())), prec

@@ -1023,19 +1023,40 @@ def test_render_rays_random_configurations(P):
 
 
 def test_fused_adam_matches_torch(P):
+    """plnerf_adam_step against torch.optim.Adam; with clip_value against clip_grad_value_ + Adam (the depth-supervised
+    loop, run_nerf_sample_based_depth.py:1156-1157); a set guard word withholds the launch and counts it."""
     from plnerf_amd import _lib as L
     gen = torch.Generator().manual_seed(0)
     n = 100003
     p0, gr = torch.randn(n, generator=gen), torch.randn(n, generator=gen) * 1e-3
-    ref = p0.clone().requires_grad_(True)
-    opt = torch.optim.Adam([ref], lr=5e-4, betas=(0.9, 0.999))
-    p, m, v = g(p0.clone()), g(torch.zeros(n)), g(torch.zeros(n))
-    for step in range(1, 4):
-        ref.grad = gr * step
-        opt.step()
-        L.check(L.lib().plnerf_adam_step(L.dptr(p), L.dptr(g(gr * step)), L.dptr(m), L.dptr(v), n, 5e-4, 0.9, 0.999,
-                                         1e-8, step, 1.0, None, L.stream()), "adam")
-    assert_close(p, ref.detach(), atol=1e-6, rtol=1e-6, what="adam params")
+    for clip in (0.0, 7e-4):
+        ref = p0.clone().requires_grad_(True)
+        opt = torch.optim.Adam([ref], lr=5e-4, betas=(0.9, 0.999))
+        p, m, v = g(p0.clone()), g(torch.zeros(n)), g(torch.zeros(n))
+        for step in range(1, 4):
+            ref.grad = gr * step
+            if clip > 0:
+                torch.nn.utils.clip_grad_value_([ref], clip)
+            opt.step()
+            L.check(L.lib().plnerf_adam_step(L.dptr(p), L.dptr(g(gr * step)), L.dptr(m), L.dptr(v), n, 5e-4, 0.9, 0.999,
+                                             1e-8, step, 1.0, clip, None, None, None, L.stream()), "adam")
+        assert_close(p, ref.detach(), atol=1e-6, rtol=1e-6, what=f"adam params (clip {clip})")
+    # guards: either word set -> nothing changes, the launch is counted
+    words = g(torch.zeros(2)).to(torch.int32)
+    count = g(torch.zeros(1)).to(torch.int32)
+    before = (p.clone(), m.clone(), v.clone())
+    for which in (0, 1):
+        words.zero_()
+        words[which] = 4
+        L.check(L.lib().plnerf_adam_step(L.dptr(p), L.dptr(g(gr)), L.dptr(m), L.dptr(v), n, 5e-4, 0.9, 0.999, 1e-8, 4, 1.0,
+                                         0.0, L.dptr(words[0:1], "w", torch.int32), L.dptr(words[1:2], "w", torch.int32),
+                                         L.dptr(count, "c", torch.int32), L.stream()), "adam")
+    assert all(torch.equal(a, b) for a, b in zip(before, (p, m, v))) and int(count.item()) == 2
+    words.zero_()
+    L.check(L.lib().plnerf_adam_step(L.dptr(p), L.dptr(g(gr)), L.dptr(m), L.dptr(v), n, 5e-4, 0.9, 0.999, 1e-8, 4, 1.0, 0.0,
+                                     L.dptr(words[0:1], "w", torch.int32), L.dptr(words[1:2], "w", torch.int32),
+                                     L.dptr(count, "c", torch.int32), L.stream()), "adam")
+    assert not torch.equal(before[0], p) and int(count.item()) == 2
 
 
 # ----------------------------------------------------------------------------- full-size properties
