@@ -235,6 +235,37 @@ int plnerf_coarse_samples(const float* rays_o, const float* rays_d, const float*
 int plnerf_image_loss(const float* rgb, const float* rgb0, const float* target, int R, float* loss3,
                       float* g_rgb, float* g_rgb0, plnerf_stream_t stream);
 
+/* The depth-supervised loop's loss (depth_supervised_exps/run_nerf_sample_based_depth.py:1126-1150):
+ *   total = img2mse(rgb, target) + space_carving_weight * compute_space_carving_loss(pred_hyp, target_h)
+ *           + img2mse(rgb0, target)
+ * with compute_space_carving_loss of depth_supervised_exps/model/run_nerf_helpers.py:52-86 in its per-ray form
+ * (is_joint = False): distances[h, r, p] = mask[r] * |pred_hyp[r, p] - target_h[h, r, p]|, zeroed below `threshold`
+ * (> 0), min over the n_hyp hypotheses, mean over points and rays.
+ * pred_hyp [R, n_points]; target_h [n_hyp, R, target_points] with target_points = 1 or n_points; mask [R] or NULL.
+ * loss5 [5] = {total, image (fine), image (coarse), space carving (unweighted), psnr of the fine image term};
+ * g_rgb, g_rgb0 [R, 3], g_hyp [R, n_points] = d total / d (rgb, rgb0, pred_hyp).  rgb0 and pred_hyp may be NULL
+ * (single-pass configuration; warm-up iterations without the depth term).  workspace: PLNERF_DEPTH_LOSS_WORKSPACE_BYTES
+ * of device memory, 8-byte aligned, ZEROED ONCE by the caller (the kernel leaves it zeroed; one workspace per stream that
+ * may run this call concurrently).  fp64 partial sums added in a fixed order: deterministic. */
+#define PLNERF_DEPTH_LOSS_WORKSPACE_BYTES 4096
+int plnerf_depth_loss(const float* rgb, const float* rgb0, const float* target, const float* pred_hyp,
+                      const float* target_h, const float* mask, int R, int n_points, int n_hyp, int target_points,
+                      float space_carving_weight, float threshold, float* loss5, float* g_rgb, float* g_rgb0,
+                      float* g_hyp, void* workspace, plnerf_stream_t stream);
+
+/* run_network's input assembly for a caller-side encoding (depth_supervised_exps/run_nerf_sample_based_depth.py:52-68
+ * with the Embedder of depth_supervised_exps/model/run_nerf_helpers.py:100-130; input_scale = 1 gives the NVS
+ * script's, run_plnerf.py:78-92 + run_nerf_helpers.py:24-54):
+ *   embedded[row] = [ gamma_fx((pts[row] - bb_center) * bb_scale) | gamma_fd(viewdirs[row / samples_per_ray]) | cam ]
+ *   gamma_L(x) = [x, sin(x s 2^0), cos(x s 2^0), ..., sin(x s 2^(L-1)), cos(x s 2^(L-1))],  s = input_scale,
+ * each argument evaluated as fl(fl(x s) 2^k), the reference's association.  viewdirs NULL: the position block only.
+ * cam [n_cam] (device; the per-image camera code, run_nerf_sample_based_depth.py:1122-1123) is repeated on every row.
+ * bb_center_host: three HOST floats (NULL = 0).  embedded [n_rows, 3 + 6 fx (+ 3 + 6 fd + n_cam)] is what
+ * plnerf_mlp_fwd takes as `embedded`. */
+int plnerf_embed_rows(const float* pts, const float* viewdirs, const float* cam, int n_rows, int samples_per_ray,
+                      int n_freqs_xyz, int n_freqs_dir, int n_cam, float input_scale, const float* bb_center_host,
+                      float bb_scale, float* embedded, plnerf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * The MLP: run_network (run_plnerf.py:78-92) = Embedder (run_nerf_helpers.py:24-54) +
  * NeRF.forward (:105-128), fused: positional encoding -> 8x256 trunk with skip ->

@@ -18,6 +18,7 @@ COLOR = {"midpoint": 0, "left": 1}
 PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3, "f16": 4}
 GUARDED_PRECISIONS = ("f16x3", "f16", "bf16x3", "bf16")      # modes whose kernels can set a bit of the range status word
 N_PARAM_TENSORS = 24
+DEPTH_LOSS_WORKSPACE_BYTES = 4096      # PLNERF_DEPTH_LOSS_WORKSPACE_BYTES
 # plnerf_mlp_fwd's `fwd_kernel` argument (PLNERF_FWD_KERNEL_*).  The library has no setting of its own; this BINDING
 # takes its default from the environment (PLNERF_FWD_KERNEL=rr | pp: the test suite's and tools/' passes over both
 # forward kernels) and hands it to every call.
@@ -51,6 +52,9 @@ SIGNATURES = {
                            [c_s]),
     "plnerf_coarse_samples": (c_i, [c_f] * 6 + [ctypes.c_uint64, ctypes.c_uint32] + [c_i] * 5 + [c_f] * 2 + [c_s]),
     "plnerf_image_loss": (c_i, [c_f] * 3 + [c_i] + [c_f] * 3 + [c_s]),
+    "plnerf_depth_loss": (c_i, [c_f] * 6 + [c_i] * 4 + [ctypes.c_float] * 2 + [c_f] * 5 + [c_s]),
+    "plnerf_embed_rows": (c_i, [c_f] * 3 + [c_i] * 5 + [ctypes.c_float, ctypes.POINTER(ctypes.c_float), ctypes.c_float,
+                                c_f, c_s]),
     "plnerf_mlp_packed_bytes": (ctypes.c_size_t, [c_i]),
     "plnerf_mlp_pack_weights": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_i, c_i, c_i, c_f, c_s]),
     "plnerf_mlp_saved_bytes": (ctypes.c_size_t, [c_i, c_i]),

@@ -8,6 +8,14 @@
 //   plnerf_coarse_samples  run_plnerf.py:683-708: stratified depths (jitter drawn in the kernel or read from a tensor)
 //                          and the sample positions, one launch
 //   plnerf_image_loss      run_plnerf.py:1287-1296: img2mse(rgb, target) + img2mse(rgb0, target) and both gradients
+//   plnerf_depth_loss      depth_supervised_exps/run_nerf_sample_based_depth.py:1126-1150: the same two image terms plus
+//                          space_carving_weight * compute_space_carving_loss(pred_hyp, target_h)
+//                          (model/run_nerf_helpers.py:52-86), and the three gradients, one launch
+//   plnerf_embed_rows      depth_supervised_exps/run_nerf_sample_based_depth.py:52-68: run_network's input assembly for
+//                          a network whose encoding is not the in-kernel one -- bounding-box affine, gamma(x) with an
+//                          optional input scale (model/run_nerf_helpers.py:100-130: sin / cos(x * pi * 2^k)), the ray's
+//                          direction encoding and the per-image camera code repeated over its samples -- one launch
+//                          instead of ~100 element-wise / cat launches per network evaluation
 //
 // Built with -ffp-contract=off like the other per-ray kernels: products and sums are rounded separately, in the
 // reference's order.
@@ -214,6 +222,169 @@ __global__ __launch_bounds__(1024) void image_loss_kernel(const float* __restric
     }
 }
 
+// ---- depth-supervised loss: DL_BLOCKS workgroups over contiguous slices, fp64 partial sums per workgroup in a fixed
+// order, the last workgroup to finish (a ticket counter in the caller's workspace, which it resets) adds the partials in
+// workgroup order: deterministic, and enough loads in flight (one workgroup walking 262,144 hypotheses measured 305 us
+// of serialised memory latency) ----
+struct DepthLossArgs {
+    const float* rgb; const float* rgb0; const float* target;      // [R, 3]
+    const float* hyp;          // pred_hyp [R, P]
+    const float* target_h;     // [H, R, PT] with PT = 1 (one depth per ray and hypothesis) or P
+    const float* mask;         // [R] or nullptr
+    int R, P, H, PT;
+    float weight, threshold;
+    float* loss5;              // {total, img, img0, space carving (unweighted), psnr of img}
+    float* g_rgb; float* g_rgb0; float* g_hyp;
+    double* partial;           // workspace: [DL_BLOCKS][3] partial sums ...
+    unsigned* ticket;          // ... and the ticket counter behind them (zero between launches)
+};
+constexpr int DL_BLOCKS = 128, DL_THREADS = 256;
+
+__global__ __launch_bounds__(DL_THREADS) void depth_loss_kernel(const DepthLossArgs a) {
+    __shared__ double part[3][DL_THREADS / 64];
+    __shared__ unsigned last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const int n = 3 * a.R;
+    const float scale = 2.0f / (float)n;
+    double s1 = 0.0, s0 = 0.0, sc = 0.0;
+    {
+        const int per = (n + DL_BLOCKS - 1) / DL_BLOCKS, lo = b * per, hi = min(n, lo + per);
+        for (int i = lo + tid; i < hi; i += DL_THREADS) {
+            const float t = a.target[i];
+            const float d1 = a.rgb[i] - t;
+            s1 += (double)(d1 * d1);
+            a.g_rgb[i] = d1 * scale;
+            if (a.rgb0) {
+                const float d0 = a.rgb0[i] - t;
+                s0 += (double)(d0 * d0);
+                a.g_rgb0[i] = d0 * scale;
+            }
+        }
+    }
+    if (a.hyp) {
+        // distances[h, r, p] = mask[r] * |pred[r, p] - target[h, r, p]|  (torch.norm over a trailing axis of length 1),
+        // zeroed below the threshold; best = min over h (first minimum on ties, like torch.min); loss = mean over r, p
+        const int np = a.R * a.P;
+        const float gs = a.weight / (float)np;
+        const int per = (np + DL_BLOCKS - 1) / DL_BLOCKS, lo = b * per, hi = min(np, lo + per);
+        for (int i = lo + tid; i < hi; i += DL_THREADS) {
+            const int r = i / a.P, p = i - r * a.P;
+            const float x = a.hyp[i];
+            const float m = a.mask ? a.mask[r] : 1.0f;
+            float best = 0.0f, gbest = 0.0f;
+            for (int h = 0; h < a.H; ++h) {
+                const float t = a.target_h[((size_t)h * a.R + r) * a.PT + (a.PT == 1 ? 0 : p)];
+                const float diff = x - t;
+                float d = fabsf(diff) * m;
+                float gd = diff > 0.0f ? m : (diff < 0.0f ? -m : 0.0f);      // d |x| / dx with 0 at 0 (torch.norm's rule)
+                if (a.threshold > 0.0f && d < a.threshold) { d = 0.0f; gd = 0.0f; }
+                if (h == 0 || d < best) { best = d; gbest = gd; }
+            }
+            sc += (double)best;
+            a.g_hyp[i] = gbest * gs;
+        }
+    }
+    s1 = wave_sum(s1);
+    s0 = wave_sum(s0);
+    sc = wave_sum(sc);
+    if (lane == 0) { part[0][wave] = s1; part[1][wave] = s0; part[2][wave] = sc; }
+    __syncthreads();
+    if (tid == 0) {
+        double v[3] = {0.0, 0.0, 0.0};
+        for (int w = 0; w < DL_THREADS / 64; ++w) { v[0] += part[0][w]; v[1] += part[1][w]; v[2] += part[2][w]; }
+        a.partial[3 * b + 0] = v[0]; a.partial[3 * b + 1] = v[1]; a.partial[3 * b + 2] = v[2];
+        __threadfence();
+        last = atomicAdd(a.ticket, 1u) == (unsigned)(DL_BLOCKS - 1);
+    }
+    __syncthreads();
+    if (last && tid == 0) {
+        __threadfence();
+        double a1 = 0.0, a0 = 0.0, ac = 0.0;
+        for (int w = 0; w < DL_BLOCKS; ++w) {      // workgroup order, whatever order they finished in
+            a1 += __builtin_nontemporal_load(a.partial + 3 * w + 0);
+            a0 += __builtin_nontemporal_load(a.partial + 3 * w + 1);
+            ac += __builtin_nontemporal_load(a.partial + 3 * w + 2);
+        }
+        *a.ticket = 0u;      // ready for the next launch
+        const float fine = (float)(a1 / (double)n), coarse = (float)(a0 / (double)n);
+        const float carve = a.hyp ? (float)(ac / ((double)a.R * (double)a.P)) : 0.0f;
+        // loss = img_loss + weight * sc + img_loss0, in the reference's order (run_nerf_sample_based_depth.py:1131-1150)
+        float total = fine;
+        if (a.hyp) total = total + a.weight * carve;
+        if (a.rgb0) total = total + coarse;
+        a.loss5[0] = total;
+        a.loss5[1] = fine;
+        a.loss5[2] = coarse;
+        a.loss5[3] = carve;
+        a.loss5[4] = -10.0f * log10f(fine);
+    }
+}
+
+// ---- run_network's input assembly: 64 rows per workgroup through LDS, so that the row-major [n_rows, C] matrix leaves
+// as one contiguous, coalesced run per tile ----
+struct EmbedArgs {
+    const float* pts;          // [n_rows, 3]
+    const float* viewdirs;     // [n_rows / spr, 3] or nullptr
+    const float* cam;          // [n_cam] or nullptr
+    int n_rows, spr, fx, fd, n_cam;      // fx, fd: frequency counts of the position / direction encodings
+    float scale;               // the encoder's input scale: 1 (run_nerf_helpers.py:24-54) or pi (depth variant)
+    float cx, cy, cz, bscale;  // bounding-box affine applied to the positions: (x - c) * bscale
+    float* out;                // [n_rows, C], C = 3 + 6 fx (+ 3 + 6 fd + n_cam with view directions)
+};
+constexpr int EMB_ROWS = 64;
+
+__global__ __launch_bounds__(256) void embed_rows_kernel(const EmbedArgs a) {
+    extern __shared__ float tile[];      // [EMB_ROWS][C]
+    const int cx_ = 3 + 6 * a.fx, cd_ = a.viewdirs ? 3 + 6 * a.fd : 0, C = cx_ + cd_ + (a.viewdirs ? a.n_cam : 0);
+    const int tid = threadIdx.x, r = tid & (EMB_ROWS - 1), part = tid >> 6;      // 4 threads per row
+    const int row0 = blockIdx.x * EMB_ROWS, row = row0 + r;
+    const int rows_valid = min(EMB_ROWS, a.n_rows - row0);
+    if (r < rows_valid) {
+        float* o = tile + (size_t)r * C;
+        // position: (x - center) * bb_scale, each rounded (run_nerf_sample_based_depth.py:56)
+        const float c3[3] = {a.cx, a.cy, a.cz};
+        float x[3], xs[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            x[d] = (a.pts[(size_t)row * 3 + d] - c3[d]) * a.bscale;
+            xs[d] = x[d] * a.scale;      // (x * pi) * freq: the reference's association; the power of two is exact
+        }
+        if (part == 0) { o[0] = x[0]; o[1] = x[1]; o[2] = x[2]; }
+        for (int k = part; k < a.fx; k += 4) {
+            const float f = ldexpf(1.0f, k);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                float sv, cv;
+                sincosf(xs[d] * f, &sv, &cv);
+                o[3 + 6 * k + d] = sv;
+                o[3 + 6 * k + 3 + d] = cv;
+            }
+        }
+        if (a.viewdirs) {
+            const float* v = a.viewdirs + (size_t)(row / a.spr) * 3;
+            float* od = o + cx_;
+            float vs[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) vs[d] = v[d] * a.scale;
+            if (part == 1) { od[0] = v[0]; od[1] = v[1]; od[2] = v[2]; }
+            for (int k = part; k < a.fd; k += 4) {
+                const float f = ldexpf(1.0f, k);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    float sv, cv;
+                    sincosf(vs[d] * f, &sv, &cv);
+                    od[3 + 6 * k + d] = sv;
+                    od[3 + 6 * k + 3 + d] = cv;
+                }
+            }
+            for (int c = part; c < a.n_cam; c += 4) od[cd_ + c] = a.cam[c];
+        }
+    }
+    __syncthreads();
+    const size_t base = (size_t)row0 * C;
+    for (int i = tid; i < rows_valid * C; i += 256) a.out[base + i] = tile[i];
+}
+
 }  // namespace
 
 extern "C" int plnerf_uniform(uint64_t seed, uint32_t stream_id, uint32_t step, int ray_id0, int R, int n, float* out,
@@ -284,6 +455,39 @@ extern "C" int plnerf_image_loss(const float* rgb, const float* rgb0, const floa
     if (R < 1 || !rgb || !target || !loss3 || !g_rgb || (rgb0 && !g_rgb0)) return PLNERF_EINVAL;
     hipLaunchKernelGGL(image_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rgb, rgb0, target, 3 * R, loss3,
                        g_rgb, g_rgb0);
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}
+
+extern "C" int plnerf_depth_loss(const float* rgb, const float* rgb0, const float* target, const float* pred_hyp,
+                                 const float* target_h, const float* mask, int R, int n_points, int n_hyp,
+                                 int target_points, float space_carving_weight, float threshold, float* loss5,
+                                 float* g_rgb, float* g_rgb0, float* g_hyp, void* workspace, plnerf_stream_t stream) {
+    static_assert(DL_BLOCKS * 3 * sizeof(double) + sizeof(unsigned) <= PLNERF_DEPTH_LOSS_WORKSPACE_BYTES, "workspace");
+    if (R < 1 || !rgb || !target || !loss5 || !g_rgb || (rgb0 && !g_rgb0) || !workspace) return PLNERF_EINVAL;
+    if (pred_hyp && (!target_h || !g_hyp || n_points < 1 || n_hyp < 1 || (target_points != 1 && target_points != n_points)))
+        return PLNERF_EINVAL;
+    DepthLossArgs a{rgb, rgb0, target, pred_hyp, target_h, mask, R, n_points, n_hyp, target_points, space_carving_weight,
+                    threshold, loss5, g_rgb, g_rgb0, g_hyp, (double*)workspace,
+                    (unsigned*)((double*)workspace + DL_BLOCKS * 3)};
+    hipLaunchKernelGGL(depth_loss_kernel, dim3(DL_BLOCKS), dim3(DL_THREADS), 0, (hipStream_t)stream, a);
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}
+
+extern "C" int plnerf_embed_rows(const float* pts, const float* viewdirs, const float* cam, int n_rows,
+                                 int samples_per_ray, int n_freqs_xyz, int n_freqs_dir, int n_cam, float input_scale,
+                                 const float* bb_center_host, float bb_scale, float* embedded, plnerf_stream_t stream) {
+    if (n_rows < 0 || n_freqs_xyz < 0 || n_freqs_xyz > 16 || n_freqs_dir < 0 || n_freqs_dir > 16 || n_cam < 0 || n_cam > 64)
+        return PLNERF_EINVAL;
+    if (n_rows == 0) return PLNERF_OK;
+    if (!pts || !embedded || (viewdirs && samples_per_ray < 1) || (n_cam > 0 && (!cam || !viewdirs))) return PLNERF_EINVAL;
+    EmbedArgs a{pts, viewdirs, cam, n_rows, samples_per_ray < 1 ? 1 : samples_per_ray, n_freqs_xyz, n_freqs_dir, n_cam,
+                input_scale, bb_center_host ? bb_center_host[0] : 0.0f, bb_center_host ? bb_center_host[1] : 0.0f,
+                bb_center_host ? bb_center_host[2] : 0.0f, bb_scale, embedded};
+    const int C = 3 + 6 * n_freqs_xyz + (viewdirs ? 3 + 6 * n_freqs_dir + n_cam : 0);
+    const size_t lds = (size_t)EMB_ROWS * C * sizeof(float);
+    hipLaunchKernelGGL(embed_rows_kernel, dim3((n_rows + EMB_ROWS - 1) / EMB_ROWS), dim3(256), lds, (hipStream_t)stream, a);
     PLNERF_CHECK_LAUNCH();
     return PLNERF_OK;
 }

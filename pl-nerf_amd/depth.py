@@ -35,20 +35,62 @@ def get_embedder(multires, i=0):
     return emb, emb.out_dim
 
 
+def _kernel_encoding(embed_fn, embeddirs_fn, viewdirs):
+    """(fx, fd, input scale) when plnerf_embed_rows evaluates these two encoders, else None: gamma(x) = [x, sin / cos of
+    x s 2^k, k < L] with s = 1 (run_nerf_helpers.py:24-54) or pi (depth_supervised_exps/model/run_nerf_helpers.py:123)."""
+    def freqs(e):
+        if not isinstance(e, Embedder):
+            return None
+        sc = 1.0 if e.input_scale is None else float(e.input_scale)
+        ok = (e.input_dims == 3 and e.include_input and e.log_sampling and list(e.periodic_fns) == [torch.sin, torch.cos]
+              and e.max_freq_log2 == e.num_freqs - 1 and 0 <= e.num_freqs <= 16)
+        return (e.num_freqs, sc) if ok else None
+    fx = freqs(embed_fn)
+    if fx is None:
+        return None
+    if viewdirs is None:
+        return fx[0], 0, fx[1]
+    fd = freqs(embeddirs_fn)
+    if fd is None:
+        return None
+    scales = {sc for n, sc in (fx, fd) if n > 0}      # (an encoder without frequency bands has no use for its scale)
+    if len(scales) > 1:
+        return None
+    return fx[0], fd[0], (scales.pop() if scales else 1.0)
+
+
 def run_network(inputs, viewdirs, embedded_cam, fn, embed_fn, embeddirs_fn, bb_center, bb_scale, netchunk=1024 * 64):
     """run_nerf_sample_based_depth.py:52-68: bounding-box affine, encodings (positions | per-ray direction | per-image
-    camera code, each repeated over the ray's samples), then the MLP in row chunks.  inputs [R, S, 3]."""
+    camera code, each repeated over the ray's samples), then the MLP in row chunks.  inputs [R, S, 3].
+
+    On the GPU the whole input assembly is ONE launch (plnerf_embed_rows) instead of ~100 element-wise / cat launches
+    per network evaluation (1.2 ms of a 10.8 ms depth-supervised step, profiles/r03_depth_kernel_stats_before.csv).  A
+    camera code that requires grad (trained through the network input, :1091-1093, 1122-1123; optimised alone,
+    :311-345) is handed to the MLP as `cam` and gets its gradient there (functional.MlpFn)."""
     R, S = inputs.shape[0], inputs.shape[1]
+    on_hip = isinstance(fn, NeRF) and fn.is_supported() and inputs.is_cuda
+    # `netchunk` "does not affect final results" (rows are independent): on the HIP MLP the rows go in launches as large
+    # as the saved-activation buffer allows instead of the reference's 65,536-row chunks (a training step would
+    # otherwise pay one forward, one backward and one weight-gradient reduction PER CHUNK)
+    if on_hip:
+        netchunk = max(int(netchunk), MAX_ROWS_PER_LAUNCH)
+    enc = _kernel_encoding(embed_fn, embeddirs_fn, viewdirs) if on_hip else None
+    cam = None if (viewdirs is None or embedded_cam is None or embedded_cam.numel() == 0) else embedded_cam
+    if enc is not None and not (torch.is_grad_enabled() and (inputs.requires_grad or
+                                                             (viewdirs is not None and viewdirs.requires_grad))):
+        fx, fd, scale = enc
+        embedded = Fn.embed_rows(inputs, viewdirs, cam, fx, fd, input_scale=scale, bb_center=bb_center,
+                                 bb_scale=bb_scale)
+        cam_grad = cam if (cam is not None and torch.is_grad_enabled() and cam.requires_grad) else None
+        blocks = [fn(block, cam=cam_grad) if cam_grad is not None else fn(block)
+                  for block in torch.split(embedded, netchunk, dim=0)]
+        raw = blocks[0] if len(blocks) == 1 else torch.cat(blocks, 0)
+        return raw.reshape(*inputs.shape[:-1], raw.shape[-1])
     columns = [embed_fn(((inputs.reshape(-1, inputs.shape[-1]) - bb_center) * bb_scale))]
     if viewdirs is not None:
         per_ray = embeddirs_fn(viewdirs)                              # row-wise encoder: encode once per ray ...
         columns.append(per_ray[:, None, :].expand(R, S, per_ray.shape[-1]).reshape(R * S, -1))   # ... then repeat
         columns.append(embedded_cam.reshape(1, -1).expand(R * S, embedded_cam.shape[0]))
-    # `netchunk` "does not affect final results" (rows are independent): on the HIP MLP the rows go in launches as large
-    # as the saved-activation buffer allows instead of the reference's 65,536-row chunks (a training step would
-    # otherwise pay one forward, one backward and one weight-gradient reduction PER CHUNK)
-    if isinstance(fn, NeRF) and fn.is_supported() and inputs.is_cuda:
-        netchunk = max(int(netchunk), MAX_ROWS_PER_LAUNCH)
     raw = batchify(fn, netchunk)(torch.cat(columns, -1))
     return raw.reshape(*inputs.shape[:-1], raw.shape[-1])
 
@@ -96,15 +138,20 @@ def sample_pdf_return_u(bins, weights, N_samples, det=False, pytest=False, load_
     return Fn.sample_const(bins, weights, u), u
 
 
+def _draw_t_rand(n_rays, n_samples, pytest, device):
+    """The stratified jitter of run_nerf_sample_based_depth.py:781-788: np.random.seed(0) draws under pytest, else
+    torch.rand."""
+    if pytest:
+        return Fn.numpy_uniform([n_rays, n_samples], device)
+    return torch.rand(n_rays, n_samples, device=device)
+
+
 def perturb_z_vals(z_vals, pytest):
     """run_nerf_sample_based_depth.py:775-790."""
     mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
     upper = torch.cat([mids, z_vals[..., -1:]], -1)
     lower = torch.cat([z_vals[..., :1], mids], -1)
-    if pytest:
-        t_rand = Fn.numpy_uniform(list(z_vals.shape), z_vals.device)
-    else:
-        t_rand = torch.rand_like(z_vals)
+    t_rand = _draw_t_rand(z_vals.shape[0], z_vals.shape[1], pytest, z_vals.device)
     return lower + (upper - lower) * t_rand
 
 
@@ -121,13 +168,20 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
     viewdirs = ray_batch[:, 8:11].contiguous() if use_viewdirs else None
     near, far = ray_batch[:, 6:7].contiguous(), ray_batch[:, 7:8].contiguous()
     t_vals = Fn.cpu_linspace(N_samples, dev)
-    if not lindisp:
-        z_vals = near * (1. - t_vals) + far * t_vals
+    fused_glue = ray_batch.is_cuda and N_rays > 0 and not (torch.is_grad_enabled() and ray_batch.requires_grad)
+    if fused_glue:
+        # depths, jitter and positions in one launch (plnerf_coarse_samples: bit-identical to the expressions below,
+        # which are :775-790 and run_plnerf.py:683-708 alike); the jitter is drawn here as the reference draws it
+        t_rand = _draw_t_rand(N_rays, N_samples, pytest, dev) if perturb > 0. else None
+        z_vals, pts = Fn.coarse_samples(rays_o, rays_d, near, far, t_vals, t_rand, lindisp, perturb > 0., None)
     else:
-        z_vals = 1. / (1. / near * (1. - t_vals) + 1. / far * t_vals)
-    if perturb > 0.:
-        z_vals = perturb_z_vals(z_vals, pytest)
-    pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+        if not lindisp:
+            z_vals = near * (1. - t_vals) + far * t_vals
+        else:
+            z_vals = 1. / (1. / near * (1. - t_vals) + 1. / far * t_vals)
+        if perturb > 0.:
+            z_vals = perturb_z_vals(z_vals, pytest)
+        pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
     raw = network_query_fn(pts, viewdirs, embedded_cam, network_fn)
     rgb_map, disp_map, acc_map, weights, depth_map, tau, T = raw2outputs(
         raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std, pytest=pytest, white_bkgd=white_bkgd,
@@ -159,7 +213,10 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
             z_samples = sample_pdf(z_mid, weights[..., 1:-1], N_importance, det=(perturb == 0.), pytest=pytest)
         z_samples = z_samples.detach()
         z_vals = Fn.merge_sort(z_vals, z_samples, near, far)          # clamp + cat + sort (:902-906)
-        pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+        if fused_glue:
+            pts = Fn.ray_points(rays_o, rays_d, z_vals)
+        else:
+            pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
         run_fn = network_fn if network_fine is None else network_fine
         raw = network_query_fn(pts, viewdirs, embedded_cam, run_fn)
         rgb_map, disp_map, acc_map, weights, depth_map, tau, T = raw2outputs(
@@ -352,18 +409,33 @@ class DepthTrainStep:
         out = render_rays(ray_batch, retraw=True, is_joint=getattr(a, "is_joint", False), cached_u=cached_u,
                           quad_solution_v2=getattr(a, "quad_solution_v2", False), pytest=pytest, **kw)
         self.optimizer.zero_grad()
-        img_loss = torch.mean((out['rgb_map'] - target_s) ** 2)
-        loss = img_loss
-        sc = torch.zeros((), device=ray_batch.device)
-        if getattr(a, "space_carving_weight", 0.) > 0. and self.global_step + 1 > getattr(a, "warm_start_nerf", 0):
-            sc = compute_space_carving_loss(out["pred_hyp"], target_h, is_joint=getattr(a, "is_joint", False),
-                                            norm_p=getattr(a, "norm_p", 2),
-                                            threshold=getattr(a, "space_carving_threshold", 0.0),
-                                            mask=space_carving_mask)
-            loss = loss + a.space_carving_weight * sc
-        if 'rgb0' in out:
-            loss = loss + torch.mean((out['rgb0'] - target_s) ** 2)
-        loss.backward()
+        carve = getattr(a, "space_carving_weight", 0.) > 0. and self.global_step + 1 > getattr(a, "warm_start_nerf", 0)
+        rgb, rgb0 = out['rgb_map'], out.get('rgb0')
+        fused = (rgb.is_cuda and rgb.dim() == 2 and rgb.shape == target_s.shape and
+                 not (carve and getattr(a, "is_joint", False)))
+        if fused:
+            # both image terms, the space-carving term and the three gradients in one launch (plnerf_depth_loss);
+            # backward((rgb, rgb0, pred_hyp), (their gradients)) is loss.backward()
+            hyp = out["pred_hyp"] if carve else None
+            loss5, g_rgb, g_rgb0, g_hyp = Fn.depth_loss_and_grads(
+                rgb, rgb0, target_s, hyp, target_h if carve else None, getattr(a, "space_carving_weight", 0.),
+                threshold=getattr(a, "space_carving_threshold", 0.0), mask=space_carving_mask if carve else None)
+            loss, img_loss, sc = loss5[0], loss5[1], loss5[3]
+            roots = [(rgb, g_rgb)] + ([(rgb0, g_rgb0)] if rgb0 is not None else []) + ([(hyp, g_hyp)] if carve else [])
+            torch.autograd.backward(tuple(r for r, _ in roots), tuple(gr for _, gr in roots))
+        else:
+            img_loss = torch.mean((rgb - target_s) ** 2)
+            loss = img_loss
+            sc = torch.zeros((), device=ray_batch.device)
+            if carve:
+                sc = compute_space_carving_loss(out["pred_hyp"], target_h, is_joint=getattr(a, "is_joint", False),
+                                                norm_p=getattr(a, "norm_p", 2),
+                                                threshold=getattr(a, "space_carving_threshold", 0.0),
+                                                mask=space_carving_mask)
+                loss = loss + a.space_carving_weight * sc
+            if rgb0 is not None:
+                loss = loss + torch.mean((rgb0 - target_s) ** 2)
+            loss.backward()
         if self.bucket is not None:
             self.bucket.allreduce_mean()
         if isinstance(self.optimizer, FlatAdam):

@@ -320,11 +320,15 @@ def coarse_samples(rays_o, rays_d, near, far, t_vals, t_rand, lindisp, perturb, 
 
 class MlpFn(torch.autograd.Function):
     """Embedder + NeRF.forward (run_nerf_helpers.py:24-54, 105-128) -> plnerf_mlp_fwd /
-    plnerf_mlp_bwd.  Gradients flow to the 24 parameter tensors only (the sample positions
-    do not depend on parameters on this path)."""
+    plnerf_mlp_bwd.  Gradients flow to the 24 parameter tensors (the sample positions do not depend on parameters on
+    this path) and to `cam`: the depth-supervised script's per-image camera code, a vector the caller has repeated into
+    the LAST cam.numel() columns of every row of `embedded` (run_nerf_sample_based_depth.py:60-64, trained through the
+    network input at :1091-1093, 1122-1123 and optimised alone at :311-345).  Because every row carries the same
+    values, its gradient is the view layer's weight columns applied to the row-sum of dz_view -- which is the view
+    layer's bias gradient, already produced by the backward:  g_cam = W_view[:, -n_cam:]^T  g_bias_view."""
 
     @staticmethod
-    def forward(ctx, pts, viewdirs, embedded, spr, net, want_grad, *params):
+    def forward(ctx, pts, viewdirs, embedded, cam, spr, net, want_grad, *params):
         prec = L.PRECISION[net.precision]
         # The kernels produce parameter gradients only (SURVEY.md section 8d: the sample positions carry no gradient
         # on the reference's path).  A gradient requested for an MLP *input* would be dropped silently by returning
@@ -333,7 +337,9 @@ class MlpFn(torch.autograd.Function):
             raise NotImplementedError(
                 "plnerf_amd: the fused MLP has no input gradient (pts / viewdirs / embedded require grad); the HIP "
                 "path differentiates with respect to the network parameters only -- detach the inputs "
-                "(e.g. a trainable camera embedding, input_ch_cam > 0, is not supported)")
+                "(a trainable camera code goes in as `cam`: NeRF.forward(embedded, cam=...))")
+        _expect(cam is None or (embedded is not None and cam.dim() == 1 and 0 < cam.numel() <= embedded.shape[-1]),
+                "cam must be a vector held in the last columns of `embedded`")
         packed = net.packed_weights()
         if embedded is not None:
             emb_c = _f32c(embedded)
@@ -345,7 +351,7 @@ class MlpFn(torch.autograd.Function):
             emb_c = None
         raw = torch.empty(n_rows, 4, device=dev)
         # grad mode is always off inside Function.forward: the caller samples torch.is_grad_enabled()
-        need_grad = bool(want_grad) and any(ctx.needs_input_grad[6:])
+        need_grad = bool(want_grad) and any(ctx.needs_input_grad[3:4] + ctx.needs_input_grad[7:])
         saved = None
         if need_grad and n_rows > 0:
             nbytes = L.lib().plnerf_mlp_saved_bytes(n_rows, prec)
@@ -365,6 +371,9 @@ class MlpFn(torch.autograd.Function):
         ctx.saved_acts = saved
         ctx.packed = packed
         ctx.param_shapes = [p.shape for p in params]
+        ctx.n_cam = 0 if cam is None else int(cam.numel())
+        # (the view layer's weight, for the camera code's gradient: the packed copy is not in [out][in] order)
+        ctx.view_weight = params[16].detach() if (ctx.n_cam and need_grad) else None
         return raw
 
     @staticmethod
@@ -383,7 +392,7 @@ class MlpFn(torch.autograd.Function):
             flat = (torch.zeros if n_rows == 0 else torch.empty)(sum(sizes), device=dev, dtype=torch.float32)
             grads = [t.view(s) for t, s in zip(flat.split(sizes), ctx.param_shapes)]
             if n_rows == 0:
-                return (None,) * 6 + tuple(grads)
+                return (None,) * 3 + (None if not ctx.n_cam else flat.new_zeros(ctx.n_cam),) + (None,) * 3 + tuple(grads)
             g = _f32c(g_raw)
             ws = torch.empty(L.lib().plnerf_mlp_bwd_workspace_bytes(n_rows, prec) // 4, device=dev,
                              dtype=torch.float32)
@@ -403,8 +412,12 @@ class MlpFn(torch.autograd.Function):
             done = torch.cuda.Event()
             done.record(side.stream)
             launch_stream.wait_event(done)
+        g_cam = None
+        if ctx.n_cam and ctx.view_weight is not None:
+            # params: ..., views_linears.0.weight (16) [W/2, W + view_ch], views_linears.0.bias (17) [W/2]
+            g_cam = torch.mv(ctx.view_weight[:, -ctx.n_cam:].t(), grads[17])
         ctx.saved_acts = None
-        return (None,) * 6 + tuple(grads)
+        return (None,) * 3 + (g_cam,) + (None,) * 3 + tuple(grads)
 
 
 class SampleConstFn(torch.autograd.Function):
@@ -580,3 +593,58 @@ def numpy_uniform(shape, device):
     """The reference's pytest=True draw: np.random.seed(0); np.random.rand(*shape) -> fp32."""
     np.random.seed(0)
     return torch.Tensor(np.random.rand(*shape)).to(device)
+
+
+def embed_rows(pts, viewdirs, cam, n_freqs_xyz, n_freqs_dir, input_scale=1.0, bb_center=0.0, bb_scale=1.0):
+    """plnerf_embed_rows: run_network's input assembly in one launch.  pts [R, S, 3]; viewdirs [R, 3] or None; cam
+    [n_cam] or None (needs viewdirs).  Returns embedded [R * S, 3 + 6 fx (+ 3 + 6 fd + n_cam)]; no gradient (the
+    positions carry none on this path; a trainable `cam` gets its gradient through MlpFn)."""
+    import ctypes
+    R, S = pts.shape[0], pts.shape[1]
+    pts_c = _f32c(pts).reshape(-1, 3)
+    vd_c = None if viewdirs is None else _f32c(viewdirs)
+    cam_c = None if (cam is None or cam.numel() == 0) else _f32c(cam).reshape(-1)
+    n_cam = 0 if cam_c is None else cam_c.numel()
+    C = 3 + 6 * n_freqs_xyz + (0 if vd_c is None else 3 + 6 * n_freqs_dir + n_cam)
+    out = torch.empty(R * S, C, device=pts_c.device)
+    c = torch.as_tensor(bb_center, dtype=torch.float32).reshape(-1).cpu()
+    center = (ctypes.c_float * 3)(*[float(c[i if c.numel() == 3 else 0]) for i in range(3)])
+    L.check(L.lib().plnerf_embed_rows(L.dptr(pts_c, "pts"), L.dptr(vd_c, "viewdirs"), L.dptr(cam_c, "cam"), R * S, S,
+                                      int(n_freqs_xyz), int(n_freqs_dir), n_cam, float(input_scale), center,
+                                      float(bb_scale), L.dptr(out), L.stream()), "plnerf_embed_rows")
+    return out
+
+
+_DEPTH_LOSS_WS = {}
+
+
+def depth_loss_and_grads(rgb, rgb0, target, pred_hyp, target_h, weight, threshold=0.0, mask=None):
+    """plnerf_depth_loss: the depth-supervised loop's loss and its three gradients in one launch.
+    Returns (loss5 = [total, img, img0, space carving, psnr], g_rgb, g_rgb0, g_hyp); rgb0 / pred_hyp may be None."""
+    rgb_c, t_c = _f32c(rgb), _f32c(target)
+    rgb0_c = None if rgb0 is None else _f32c(rgb0)
+    _expect(rgb_c.shape == t_c.shape and rgb_c.dim() == 2 and rgb_c.shape[1] == 3, "rgb / target must be [R, 3]")
+    R = rgb_c.shape[0]
+    hyp_c = th_c = mask_c = g_h = None
+    P = H = PT = 1
+    if pred_hyp is not None:
+        hyp_c, th_c = _f32c(pred_hyp), _f32c(target_h)
+        P, H, PT = hyp_c.shape[1], th_c.shape[0], th_c.shape[-1]
+        _expect(hyp_c.shape[0] == R and th_c.dim() == 3 and th_c.shape[1] == R and PT in (1, P),
+                f"pred_hyp [R, P] / target_h [H, R, 1 or P]: got {tuple(hyp_c.shape)} / {tuple(th_c.shape)}")
+        g_h = torch.empty_like(hyp_c)
+        mask_c = None if mask is None else _f32c(mask).reshape(-1)
+        _expect(mask_c is None or mask_c.numel() == R, "mask must hold one value per ray")
+    loss5 = torch.empty(5, device=rgb_c.device)
+    g1 = torch.empty_like(rgb_c)
+    g0 = None if rgb0_c is None else torch.empty_like(rgb_c)
+    # the kernel's partial sums and ticket counter: zeroed once per (device, stream), left zeroed by every launch
+    key = (rgb_c.device, torch.cuda.current_stream().cuda_stream)
+    ws = _DEPTH_LOSS_WS.get(key)
+    if ws is None:
+        ws = _DEPTH_LOSS_WS[key] = torch.zeros(L.DEPTH_LOSS_WORKSPACE_BYTES // 8, device=rgb_c.device, dtype=torch.float64)
+    L.check(L.lib().plnerf_depth_loss(L.dptr(rgb_c, "rgb"), L.dptr(rgb0_c, "rgb0"), L.dptr(t_c, "target"),
+                                      L.dptr(hyp_c, "pred_hyp"), L.dptr(th_c, "target_h"), L.dptr(mask_c, "mask"), R, P, H,
+                                      PT, float(weight), float(threshold), L.dptr(loss5), L.dptr(g1), L.dptr(g0),
+                                      L.dptr(g_h), L.dptr(ws, "workspace", torch.float64), L.stream()), "plnerf_depth_loss")
+    return loss5, g1, g0, g_h

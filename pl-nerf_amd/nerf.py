@@ -278,7 +278,10 @@ class NeRF(nn.Module):
                 + advice + ".")
 
     # -- reference interface --------------------------------------------------------
-    def forward(self, x):
+    def forward(self, x, cam=None):
+        """x [..., input_ch + input_ch_views + input_ch_cam] embedded rows (the reference module's signature).  `cam`
+        (extension): the camera code the caller has repeated into the last input_ch_cam columns of every row, when it
+        is to receive a gradient (functional.MlpFn); x itself carries none."""
         self._require_supported()
         lead = x.shape[:-1]
         flat = x.reshape(-1, x.shape[-1])
@@ -286,7 +289,7 @@ class NeRF(nn.Module):
             raise ValueError(f"NeRF.forward expects {self.input_ch + self.view_ch} embedded channels, got {flat.shape[-1]}")
         if not self.use_viewdirs:      # the kernels' direction channels: zeros (their weights are zero as well)
             flat = torch.cat([flat[:, :self.input_ch], flat.new_zeros(flat.shape[0], self.hip_view_ch)], -1)
-        out = MlpFn.apply(None, None, flat, 1, self, torch.is_grad_enabled(), *self.param_list())
+        out = MlpFn.apply(None, None, flat, cam, 1, self, torch.is_grad_enabled(), *self.param_list())
         return self._outputs(out.reshape(*lead, 4))
 
     def query(self, pts, viewdirs):
@@ -301,5 +304,5 @@ class NeRF(nn.Module):
             if self.use_viewdirs:
                 raise ValueError("this network takes view directions")
             viewdirs = pts.new_zeros(R, 3)
-        out = MlpFn.apply(pts.reshape(-1, 3), viewdirs, None, S, self, torch.is_grad_enabled(), *self.param_list())
+        out = MlpFn.apply(pts.reshape(-1, 3), viewdirs, None, None, S, self, torch.is_grad_enabled(), *self.param_list())
         return self._outputs(out.reshape(R, S, 4))

@@ -1,0 +1,161 @@
+"""Round 3's kernels around the depth-supervised variant of the path, on a real MI355X:
+
+  * plnerf_embed_rows  -- run_network's input assembly (depth_supervised_exps/run_nerf_sample_based_depth.py:52-68 with the
+                          pi-scaled Embedder of model/run_nerf_helpers.py:100-130) against the oracle's torch expressions;
+  * plnerf_depth_loss  -- the loop's loss (:1126-1150, model/run_nerf_helpers.py:52-86) and its three gradients against
+                          torch autograd;
+  * the camera code's gradient (input_ch_cam > 0: :1091-1093, 1122-1123, 311-345) through functional.MlpFn against the
+    oracle network's autograd in fp64.
+
+Tolerances: the encoding 5e-7 absolute (values in [-1, 1]; sin / cos arguments reach 2^8 pi |x|, one ulp of the result
+either side); the loss 1e-6 relative and its gradients 1e-7 absolute + 1e-5 relative (fp64 partial sums in the kernel,
+fp32 in torch); the camera gradient 2e-4 of max|g| in fp32 mode and 6e-3 in f16x3 (the half-plane backward, DESIGN.md
+section 3).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import plnerf_oracle as orc
+from test_gpu_parity import dev, g
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    import plnerf_amd
+    return plnerf_amd
+
+
+@pytest.mark.parametrize("cfg", [(9, 0, np.pi, 0), (9, 0, np.pi, 4), (10, 4, 1.0, 0), (3, 2, np.pi, 2), (0, 0, 1.0, 0)])
+def test_embed_rows_matches_the_reference_expressions(P, cfg):
+    from plnerf_amd import functional as Fn
+    fx, fd, scale, n_cam = cfg
+    gen = torch.Generator().manual_seed(5)
+    R, S = 37, 11                                       # ragged against the kernel's 64-row tiles
+    pts = (torch.rand(R, S, 3, generator=gen) * 2 - 1) * 3.0
+    vd = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
+    cam = torch.randn(n_cam, generator=gen) if n_cam else None
+    center, bscale = torch.tensor([0.3, -0.2, 0.1]), 0.7
+
+    def gamma(x, n):     # model/run_nerf_helpers.py:123: fn(x * pi * freq), in fp32
+        blocks = [x]
+        for k in range(n):
+            xs = x * np.float32(scale) * float(2 ** k)
+            blocks += [torch.sin(xs), torch.cos(xs)]
+        return torch.cat(blocks, -1)
+    flat = (pts.reshape(-1, 3) - center) * bscale
+    cols = [gamma(flat, fx), gamma(vd, fd)[:, None, :].expand(R, S, 3 + 6 * fd).reshape(R * S, -1)]
+    if n_cam:
+        cols.append(cam.reshape(1, -1).expand(R * S, n_cam))
+    want = torch.cat(cols, -1)
+    got = Fn.embed_rows(g(pts), g(vd), None if cam is None else g(cam), fx, fd, input_scale=scale, bb_center=center,
+                        bb_scale=bscale).cpu()
+    assert got.shape == want.shape
+    err = float((got - want).abs().max())
+    print(f"embed_rows fx={fx} fd={fd} scale={scale:.3f} cam={n_cam}: max err {err:.2e}")
+    assert err <= 5e-7
+    assert torch.equal(got[:, :3], want[:, :3])         # the affine and the identity block: bit-equal
+    # positions only (no view directions)
+    got_x = Fn.embed_rows(g(pts), None, None, fx, 0, input_scale=scale, bb_center=center, bb_scale=bscale).cpu()
+    assert got_x.shape[1] == 3 + 6 * fx and float((got_x - want[:, :3 + 6 * fx]).abs().max()) <= 5e-7
+
+
+@pytest.mark.parametrize("case", ["full", "no_coarse", "target_per_point", "mask_threshold", "no_depth_term"])
+def test_depth_loss_and_gradients_match_autograd(P, case):
+    from plnerf_amd import depth as Dp, functional as Fn
+    gen = torch.Generator().manual_seed(9)
+    R, Pn, H = 300, 64, 3
+    rgb = torch.rand(R, 3, generator=gen).requires_grad_(True)
+    rgb0 = torch.rand(R, 3, generator=gen).requires_grad_(True)
+    target = torch.rand(R, 3, generator=gen)
+    hyp = (2.0 + 4.0 * torch.rand(R, Pn, generator=gen)).requires_grad_(True)
+    th = 2.0 + 4.0 * torch.rand(H, R, Pn if case == "target_per_point" else 1, generator=gen)
+    th[1, 5] = hyp.detach()[5, :1] if th.shape[-1] == 1 else hyp.detach()[5]      # an exact hit: |x| at 0
+    mask = (torch.rand(R, generator=gen) > 0.3).float() if case == "mask_threshold" else None
+    thr = 0.25 if case == "mask_threshold" else 0.0
+    w = 0.007
+    use0, use_h = case != "no_coarse", case != "no_depth_term"
+    loss = torch.mean((rgb - target) ** 2)
+    img = loss
+    sc = torch.zeros(())
+    if use_h:
+        sc = Dp.compute_space_carving_loss(hyp, th, is_joint=False, mask=mask, norm_p=2, threshold=thr)
+        loss = loss + w * sc
+    if use0:
+        loss = loss + torch.mean((rgb0 - target) ** 2)
+    loss.backward()
+    loss5, g1, g0, gh = Fn.depth_loss_and_grads(g(rgb.detach()), g(rgb0.detach()) if use0 else None, g(target),
+                                                g(hyp.detach()) if use_h else None, g(th) if use_h else None, w,
+                                                threshold=thr, mask=None if mask is None else g(mask))
+    l5 = loss5.cpu()
+    assert abs(float(l5[0]) - float(loss)) <= 1e-6 * abs(float(loss)) + 1e-8, (float(l5[0]), float(loss))
+    assert abs(float(l5[1]) - float(img)) <= 1e-6 * float(img) + 1e-8
+    assert abs(float(l5[3]) - float(sc)) <= 1e-6 * abs(float(sc)) + 1e-8, (float(l5[3]), float(sc))
+    assert abs(float(l5[4]) - float(-10.0 * torch.log10(img.detach()))) <= 1e-4
+
+    def close(a, b, what):
+        err = float((a.cpu() - b).abs().max())
+        assert err <= 1e-7 + 1e-5 * float(b.abs().max()), f"{case} {what}: {err:.3e}"
+    close(g1, rgb.grad, "g_rgb")
+    if use0:
+        close(g0, rgb0.grad, "g_rgb0")
+    if use_h:
+        close(gh, hyp.grad, "g_hyp")
+        assert float(gh.cpu()[5].abs().max()) >= 0.0      # (finite at the exact hit: torch.norm's sub-gradient 0)
+        assert torch.isfinite(gh).all()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_camera_code_gradient_through_the_mlp(P, precision):
+    """input_ch_cam = 4: the camera code repeated on every row gets d loss / d cam = W_view[:, cam columns]^T applied to
+    the row-sum of dz_view; against fp64 autograd of the oracle's network on the same rows."""
+    from plnerf_amd import depth as Dp, functional as Fn
+    n_cam = 4
+    gen = torch.Generator().manual_seed(21)
+    R, S = 24, 40
+    sd = orc.closed_form_state_dict_depth(3, False)
+    extra = torch.randn(128, n_cam, generator=gen) * 0.05
+    sd["views_linears.0.weight"] = torch.cat([sd["views_linears.0.weight"], extra], 1)       # [128, 256 + 3 + 4]
+    net = P.NeRF(D=8, W=256, input_ch=57, input_ch_views=3, input_ch_cam=n_cam, output_ch=5, skips=[4], use_viewdirs=True,
+                 precision=precision, density_activation="softplus")
+    net.load_state_dict(sd)
+    net = net.to(dev())
+    pts = (torch.rand(R, S, 3, generator=gen) * 2 - 1) * 1.5
+    vd = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
+    cam0 = torch.randn(n_cam, generator=gen) * 0.3
+    cot = torch.randn(R, S, 4, generator=gen)
+    emb_fn, _ = Dp.get_embedder(9, 0)
+    embd_fn, _ = Dp.get_embedder(0, 0)
+    # fp64 oracle
+    cam64 = cam0.double().requires_grad_(True)
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    flat = pts.reshape(-1, 3).double()
+    emb = torch.cat([orc.positional_encoding_pi(flat, 9), vd[:, None, :].expand(R, S, 3).reshape(-1, 3).double(),
+                     cam64.reshape(1, -1).expand(R * S, n_cam)], -1)
+    raw64 = orc.nerf_mlp_depth(sd64, emb).reshape(R, S, 4)
+    (raw64 * cot.double()).sum().backward()
+    # HIP path through the depth script's run_network
+    cam = g(cam0).requires_grad_(True)
+    raw = Dp.run_network(g(pts), g(vd), cam, net, emb_fn, embd_fn, 0.0, 1.0)
+    err_fwd = float((raw.detach().cpu().double() - raw64.detach()).abs().max())
+    (raw * g(cot)).sum().backward()
+    gc, gr = cam.grad.cpu().double(), cam64.grad
+    rel = float((gc - gr).abs().max()) / float(gr.abs().max())
+    gw = net.views_linears[0].weight.grad.cpu().double()
+    relw = float((gw - sd64["views_linears.0.weight"].grad).abs().max()) / float(sd64["views_linears.0.weight"].grad.abs().max())
+    print(f"{precision}: forward err {err_fwd:.2e}, d/d cam rel err {rel:.2e} (grad {gr.tolist()}), view weight grad rel err {relw:.2e}")
+    assert err_fwd <= 2e-5
+    assert rel <= (2e-4 if precision == "fp32" else 6e-3)
+    # test-time optimisation of the code alone (run_nerf_sample_based_depth.py:311-345): frozen network parameters
+    for p_ in net.parameters():
+        p_.requires_grad_(False)
+    cam2 = g(cam0).requires_grad_(True)
+    raw2 = Dp.run_network(g(pts), g(vd), cam2, net, emb_fn, embd_fn, 0.0, 1.0)
+    (raw2 * g(cot)).sum().backward()
+    rel2 = float((cam2.grad.cpu().double() - gr).abs().max()) / float(gr.abs().max())
+    assert rel2 <= (2e-4 if precision == "fp32" else 6e-3)
+    # positions that require grad are still refused, loudly
+    with pytest.raises(NotImplementedError):
+        net(torch.zeros(4, 64, device=dev(), requires_grad=True))

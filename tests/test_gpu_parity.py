@@ -783,18 +783,13 @@ def test_depth_variant_gradients_vs_oracle(P):
     # HIP: same draws injected by patching the two draw helpers for this call
     dmod = sys.modules[Dp.__name__]
     rmod = sys.modules[Dp.__name__.rsplit(".", 1)[0] + ".render"]   # (the package attribute `render` is the function)
-    orig_perturb, orig_draw = dmod.perturb_z_vals, rmod._draw_u
+    orig_jitter, orig_draw = dmod._draw_t_rand, rmod._draw_u
     try:
-        def fixed_perturb(z_vals, pytest):
-            mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
-            upper = torch.cat([mids, z_vals[..., -1:]], -1)
-            lower = torch.cat([z_vals[..., :1], mids], -1)
-            return lower + (upper - lower) * g(t_rand)
-        dmod.perturb_z_vals = fixed_perturb
+        dmod._draw_t_rand = lambda *a, **k: g(t_rand)      # (the stratified jitter, whichever prologue consumes it)
         rmod._draw_u = lambda *a, **k: g(u_fine)
         ret = Dp.render_rays(g(batch), retraw=True, cached_u=g(u_hyp), **kw)
     finally:
-        dmod.perturb_z_vals, rmod._draw_u = orig_perturb, orig_draw
+        dmod._draw_t_rand, rmod._draw_u = orig_jitter, orig_draw
     sc = Dp.compute_space_carving_loss(ret["pred_hyp"], g(target_h))
     loss = P.img2mse(ret["rgb_map"], g(target)) + 0.05 * sc + P.img2mse(ret["rgb0"], g(target))
     loss.backward()
@@ -847,18 +842,13 @@ def test_depth_variant_constant_mode_vs_oracle(P):
     _, _, g_c64, g_f64 = oracle(torch.float64)
     dmod = sys.modules[Dp.__name__]
     rmod = sys.modules[Dp.__name__.rsplit(".", 1)[0] + ".render"]
-    orig_perturb, orig_draw = dmod.perturb_z_vals, rmod._draw_u
+    orig_jitter, orig_draw = dmod._draw_t_rand, rmod._draw_u
     try:
-        def fixed_perturb(z_vals, pytest):
-            mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
-            upper = torch.cat([mids, z_vals[..., -1:]], -1)
-            lower = torch.cat([z_vals[..., :1], mids], -1)
-            return lower + (upper - lower) * g(t_rand)
-        dmod.perturb_z_vals = fixed_perturb
+        dmod._draw_t_rand = lambda *a, **k: g(t_rand)      # (the stratified jitter, whichever prologue consumes it)
         rmod._draw_u = lambda *a, **k: g(u_fine)
         ret = Dp.render_rays(g(batch), retraw=True, cached_u=g(u_hyp), **kw)
     finally:
-        dmod.perturb_z_vals, rmod._draw_u = orig_perturb, orig_draw
+        dmod._draw_t_rand, rmod._draw_u = orig_jitter, orig_draw
     assert ret["pred_hyp"].requires_grad and ret["weights"].shape == (R, Ns + Ni)
     sc = Dp.compute_space_carving_loss(ret["pred_hyp"], g(target_h))
     loss = P.img2mse(ret["rgb_map"], g(target)) + 0.05 * sc + P.img2mse(ret["rgb0"], g(target))
