@@ -36,6 +36,13 @@ for prec in a.precisions.split(","):
             rgb, disp, acc, _ = P.render(H, W, K, chunk=a.chunk, c2w=poses[(f + 1) % 3], near=2.0, far=6.0, **kw_test)
         e.record(); torch.cuda.synchronize()
     ms = s.elapsed_time(e) / a.frames
+    # the frame's algorithmic MLP work (1,186,816 FLOP per network evaluation, 64 + 192 per ray)
+    # against the dense MFMA peak of the operand type: the frame IS the two MLP launches per chunk (everything else --
+    # ray generation, sampling, the fused coarse epilogue, quadrature -- is < 1 % of it)
+    tflops = H * W * (64 + 192) * 1186816 / (ms * 1e-3) / 1e12
+    peak = 157.3 if prec == "fp32" else 2500.0
     print(json.dumps({"what": "render 800x800 frame (64+192 samples, inference)", "precision": prec,
                       "ms_per_frame": ms, "rays_per_s": H * W / (ms * 1e-3), "chunk": a.chunk,
+                      "roofline": {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s",
+                                   "frac": tflops / peak, "note": "whole frame: algorithmic MLP FLOP / frame time"},
                       "finite": bool(torch.isfinite(rgb).all())}), flush=True)

@@ -14,7 +14,7 @@ txt = open("$out/summary.txt").read()
 blk = re.search(r"mlp_fwd_rr_kernel<2, true(?:, false)?>\(pln\S*\s+grid=1572864\n((?:\s+\w+.*\n)+)", txt)
 vals = dict(re.findall(r"(\w+_SIZE)\s+n=\s*\d+\s+mean=([\d.e+]+)", blk.group(1)))
 f, w = float(vals["FETCH_SIZE"]), float(vals["WRITE_SIZE"])
-json.dump({"f16x3": {"kernel": "mlp_fwd_rr_kernel<2,true>", "rows_per_launch": 786432, "fetch_size_kib": f, "write_size_kib": w,
+json.dump({"commit": "${COMMIT:-unknown}", "f16x3": {"kernel": "mlp_fwd_rr_kernel<2,true>", "rows_per_launch": 786432, "fetch_size_kib": f, "write_size_kib": w,
                      "bytes": int((2 * f + w) * 1024), "algorithmic_bytes": 786432 * 5356}}, open("$out/traffic.json", "w"), indent=1)
 print(open("$out/traffic.json").read())
 PY
