@@ -249,6 +249,42 @@ def test_train_step_from_a_view(P):
         assert maxdiff(p, q) <= 3e-4      # (six Adam steps apart: the two routes normalise view directions differently)
 
 
+def test_single_pass_configuration_steps_two_adams_over_one_flat_buffer(P):
+    """N_importance = 0: the reference builds BOTH Adams over the coarse network's parameters and steps them one after the
+    other (run_plnerf.py:438-447, 1302-1303).  Here both are FlatAdam: the second adopts the flat buffer the first one
+    re-homed the weights into (a second re-homing would orphan the first optimizer's buffer), both carry the network's
+    range guard, and two steps of the train loop land where two torch.optim.Adam instances over the same tensors land."""
+    from plnerf_amd.optim import FlatAdam, flat_view_of
+    d = tempfile.mkdtemp()
+    os.makedirs(os.path.join(d, "exp"))
+    args = _args(d, "fp32", N_importance=0)
+    torch.manual_seed(0)
+    kw, _, _, grad_vars, opt, opt_c = P.create_nerf(args, device=dev())
+    assert kw["network_fine"] is None and isinstance(opt, FlatAdam) and isinstance(opt_c, FlatAdam)
+    net = kw["network_fn"]
+    assert flat_view_of([p.data for p in net.parameters()]).data_ptr() == opt._flat[0]["param"].data_ptr() \
+        == opt_c._flat[0]["param"].data_ptr()
+    ref = [p.detach().clone().requires_grad_(True) for p in net.parameters()]
+    ref_opts = [torch.optim.Adam(ref, lr=args.lrate, betas=(0.9, 0.999)), torch.optim.Adam(ref, lr=args.coarse_lrate,
+                                                                                         betas=(0.9, 0.999))]
+    batch, target = orc.synthetic_blender_rays(256, seed=4)
+    ts = P.TrainStep(args, kw, opt, opt_c, distributed=False, seed=0)
+    K = [[1111.111, 0, 400], [0, 1111.111, 400], [0, 0, 1]]
+    for _ in range(2):
+        loss, _ = ts(800, 800, K, (g(batch[:, 0:3]), g(batch[:, 3:6])), g(target), near=2.0, far=6.0)
+        for r, p in zip(ref, net.parameters()):
+            r.grad = p.grad.detach().clone()
+        lr = opt.param_groups[0]["lr"]
+        for o in ref_opts:
+            o.step()
+            for grp in o.param_groups:
+                grp["lr"] = lr
+        assert torch.isfinite(loss)
+    worst = max(float((r.detach() - p.detach()).abs().max()) for r, p in zip(ref, net.parameters()))
+    print(f"single-pass, two Adams, two steps: max parameter difference to torch.optim.Adam x 2 = {worst:.2e}")
+    assert worst <= 2e-6
+
+
 def test_training_step_is_bitwise_reproducible(P):
     """Two runs of the benchmark-sized step (4096 rays x (64 + 128) samples, f16x3) from the same weights and seed end in
     bit-identical parameters, step after step.  Every reduction of the path is ordered (split-K partials summed in a
