@@ -114,10 +114,23 @@ class NeRF(nn.Module):
         self._packed = None
 
     # -- HIP plumbing ---------------------------------------------------------------
+    def _skip_layout(self):
+        """How the reference module's skip list lands on the compiled trunk: "at4" -- the skip after layer 4 is live
+        (needs a sixth layer to consume it: D 6..8); "none" -- no entry of `skips` takes effect (run_nerf_helpers.py:
+        88-89, 109-112: entry k concatenates after layer k and widens layer k + 1, so k >= D does nothing); None --
+        anything else (another skip position; a skip after the LAST layer, which the reference's own head layers
+        cannot consume either)."""
+        live = sorted(set(k for k in self.skips if 0 <= k < self.D))
+        if live == SUPPORTED["skips"] and SUPPORTED["D"] - 2 <= self.D <= SUPPORTED["D"]:
+            return "at4"
+        if not live and 1 <= self.D <= SUPPORTED["D"]:
+            return "none"
+        return None
+
     def is_supported(self):
-        # (narrower and slightly shallower trunks are padded into the compiled one: param_list)
-        trunk = (SUPPORTED["D"] - 2 <= self.D <= SUPPORTED["D"] and 8 <= self.W <= SUPPORTED["W"] and self.W % 2 == 0 and
-                 1 <= self.input_ch <= MAX_INPUT_CH and list(self.skips) == SUPPORTED["skips"])
+        # (narrower and shallower trunks, and trunks without a live skip, are padded into the compiled one: param_list)
+        trunk = (self._skip_layout() is not None and 8 <= self.W <= SUPPORTED["W"] and self.W % 2 == 0 and
+                 1 <= self.input_ch <= MAX_INPUT_CH)
         if not self.use_viewdirs:      # (see param_list; the reference ignores the view columns of x, if any)
             return trunk
         return trunk and 1 <= self.view_ch <= MAX_VIEW_CH
@@ -134,7 +147,8 @@ class NeRF(nn.Module):
             raise NotImplementedError(
                 "plnerf_amd's HIP MLP is compiled for the reference's trunk "
                 f"(D={SUPPORTED['D']}, W={SUPPORTED['W']}, skips={SUPPORTED['skips']}) and runs what can be expressed exactly "
-                f"in it: netdepth {SUPPORTED['D'] - 2}..{SUPPORTED['D']}, even netwidth 8..{SUPPORTED['W']}, input_ch <= "
+                f"in it: netdepth {SUPPORTED['D'] - 2}..{SUPPORTED['D']} with skips=[4], netdepth 1..{SUPPORTED['D']} without a live "
+                f"skip, even netwidth 8..{SUPPORTED['W']}, input_ch <= "
                 f"{MAX_INPUT_CH}, input_ch_views + input_ch_cam <= {MAX_VIEW_CH}, with or without view directions; got "
                 f"D={self.D}, W={self.W}, "
                 f"input_ch={self.input_ch}, input_ch_views={self.input_ch_views}, input_ch_cam={self.input_ch_cam}, "
@@ -162,10 +176,14 @@ class NeRF(nn.Module):
 
           * netwidth < 256: weights and biases zero-padded (the extra units compute relu(0) = 0 and feed nothing);
           * netdepth 6 or 7: the missing trunk layers as identities (their inputs are post-ReLU, so relu(I h) = h);
+          * no live skip (skips=[], or every entry >= netdepth, e.g. netdepth 4 with the default skips=[4]), netdepth
+            1..8: the compiled skip layer's encoding columns are zero -- [0 | W_5], or [0 | I] when layer 5 itself is
+            one of the identities;
           * use_viewdirs=False (run_nerf_helpers.py:102-103, 125-126: `output_linear` on the trunk): feature rows
             0..2 = W_out[rgb], rows 3..5 = -W_out[rgb]; the view layer copies those six features (identity weights, zero
             direction columns); rgb = relu(F) - relu(-F) + b = F + b; sigma = the alpha row = W_out[3]."""
-        if self.use_viewdirs and self.D == SUPPORTED["D"] and self.W == SUPPORTED["W"]:
+        layout = self._skip_layout()
+        if self.use_viewdirs and self.D == SUPPORTED["D"] and self.W == SUPPORTED["W"] and layout == "at4":
             return list(self.parameters())
         import torch.nn.functional as F
         KW, W, D, cin = SUPPORTED["W"], self.W, self.D, self.input_ch
@@ -179,13 +197,16 @@ class NeRF(nn.Module):
                 w, b = self.pts_linears[i].weight, self.pts_linears[i].bias
                 if i == 0:
                     w = pad_rows(w, KW)
-                elif i == SUPPORTED["skips"][0] + 1:      # [encoding | hidden] columns
+                elif i == SUPPORTED["skips"][0] + 1 and layout == "at4":      # [encoding | hidden] columns
                     w = pad_rows(torch.cat([w[:, :cin], pad_cols(w[:, cin:], KW)], 1), KW)
+                elif i == SUPPORTED["skips"][0] + 1:      # no live skip: the compiled layer's encoding columns are zero
+                    w = pad_rows(torch.cat([z(w.shape[0], cin), pad_cols(w, KW)], 1), KW)
                 else:
                     w = pad_rows(pad_cols(w, KW), KW)
                 out += [w, pad_rows(b, KW)]
             else:
-                out += [torch.eye(KW, device=ref.device, dtype=ref.dtype), z(KW)]
+                eye = torch.eye(KW, device=ref.device, dtype=ref.dtype)
+                out += [torch.cat([z(KW, cin), eye], 1) if i == SUPPORTED["skips"][0] + 1 else eye, z(KW)]
         HV, vch = KW // 2, self.hip_view_ch
         if self.use_viewdirs:
             vw = self.views_linears[0].weight                                  # [W/2, W + view_ch]: [feature | direction]

@@ -527,7 +527,8 @@ def test_network_without_view_directions(P, precision, tmp_path):
     assert torch.isfinite(rgb).all() and 0.0 < moved <= 5.5e-4
 
 
-@pytest.mark.parametrize("shape", [(8, 128, True), (6, 256, True), (7, 64, False), (6, 32, True)])
+@pytest.mark.parametrize("shape", [(8, 128, True), (6, 256, True), (7, 64, False), (6, 32, True), (4, 128, True),
+                                   (2, 256, False)])
 def test_narrower_and_shallower_networks(P, shape):
     """netwidth < 256 and netdepth 6 / 7 are zero-padded / identity-extended into the compiled 8 x 256 network
     (NeRF.param_list) -- exactly: fp32 mode against the same network in fp64 torch, forward and every real parameter's
@@ -549,7 +550,7 @@ def test_narrower_and_shallower_networks(P, shape):
     h = x
     for i in range(D):
         h = F.relu(F.linear(h, sd[f"pts_linears.{i}.weight"], sd[f"pts_linears.{i}.bias"]))
-        if i == 4:
+        if i == 4:      # (netdepth <= 4: the default skips=[4] never takes effect, run_nerf_helpers.py:109-112)
             h = torch.cat([x, h], -1)
     if use_viewdirs:
         sigma = F.linear(h, sd["alpha_linear.weight"], sd["alpha_linear.bias"])

@@ -361,6 +361,29 @@ if rank == 0:
                 for p, q in zip(n.parameters(), m.parameters()))
     print("max |param(2 ranks) - param(1 rank, global batch)| =", worst)
     assert worst <= 2e-4, worst          # three Adam steps (lr 5e-4) apart at most through rounding-level gradient differences
+# The range guard is global: ONE rank's forward leaves the half range (simulated: its fine network's status word is set
+# as the clamping kernel would set it) -> the bucket shares the words before Adam, BOTH ranks withhold the step, BOTH
+# raise at the next check, and the step counts are wound back on both.
+before = [p.detach().clone() for n in ts.nets for p in n.parameters()]
+steps_before = float(ts.optimizer.state[next(ts.nets[1].parameters())]['step'])
+if rank == 1:
+    ts.nets[1].status_word().fill_(1)
+ts.step_view(H, W, K, c2w, image, near=2.0, far=6.0, n_rand=128)
+fine_before = before[len(list(ts.nets[0].parameters())):]
+assert all(torch.equal(a, p.detach()) for a, p in zip(fine_before, ts.nets[1].parameters())), "a guarded step reached the weights"
+assert int(ts.nets[1].status_word().item()) == 1, f"rank {rank}: the status word was not shared"
+raised = False
+try:
+    ts.check_range()
+except FloatingPointError:
+    raised = True
+assert raised, f"rank {rank} did not raise"
+assert float(ts.optimizer.state[next(ts.nets[1].parameters())]['step']) == steps_before       # wound back
+# (the coarse network's word was clear on both ranks: its step went through, identically)
+digest = [float(p.detach().double().sum()) for p in ts.nets[0].parameters()]
+gathered = [None] * world
+dist.all_gather_object(gathered, digest)
+assert gathered[0] == gathered[1]
 print(f"rank {rank} ok")
 dist.destroy_process_group()
 '''

@@ -39,6 +39,26 @@ def test_library_exports_every_declared_symbol(built):
     assert _lib.lib().plnerf_error_string(-3).decode().startswith("size outside")
 
 
+def test_header_is_plain_c_and_links(built, tmp_path):
+    """include/plnerf_hip.h compiled as C99 by gcc, every entry point referenced with its declared prototype, linked
+    against the built library, and the GPU-free calls executed (tests/abi_check.c): the boundary a cgo / JNI / ctypes
+    binding would bind."""
+    import re
+    from plnerf_amd import _lib
+    header = open(os.path.join(ROOT, "include", "plnerf_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|size_t|const char\*)\s+(plnerf_\w+)\s*\(", header, flags=re.M))
+    listed = set(re.findall(r"\(any_fn\)(plnerf_\w+)", open(os.path.join(ROOT, "tests", "abi_check.c")).read()))
+    assert declared == listed == set(_lib.SIGNATURES), (declared ^ listed, declared ^ set(_lib.SIGNATURES))
+    exe = str(tmp_path / "abi_check")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "abi_check.c"), "-o", exe, "-L", libdir, "-lplnerf_hip",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert f"{len(declared)} entry points" in out.stdout
+
+
 def test_pe_sincos_reduction_on_host(tmp_path):
     """pl-nerf_amd/csrc/pe_sincos.h (the encoding's shared argument reduction) is plain C++: compile it for the
     host and compare with double-precision sin / cos over scene-scale, large and near-k*pi/2 arguments (the
@@ -103,16 +123,19 @@ def test_network_without_view_directions_maps_onto_the_kernels_head(built):
     assert net.output_linear.weight.grad is not None and float(net.output_linear.weight.grad[:4].abs().max()) > 0
 
 
-@pytest.mark.parametrize("shape", [(8, 128, True), (6, 256, True), (7, 64, False), (6, 32, True)])
+@pytest.mark.parametrize("shape", [(8, 128, True, [4]), (6, 256, True, [4]), (7, 64, False, [4]), (6, 32, True, [4]),
+                                   (8, 256, True, []), (4, 256, True, [4]), (3, 64, False, []), (1, 128, True, [4]),
+                                   (5, 96, True, [7])])
 def test_other_network_shapes_map_exactly_onto_the_compiled_network(built, shape):
-    """NeRF.param_list() for netwidth < 256 / netdepth 6, 7 / no view directions: the 24 tensors of the compiled
-    8 x 256 network, evaluated here in plain fp64 torch, reproduce the real module's function exactly."""
+    """NeRF.param_list() for netwidth < 256 / netdepth 6, 7 / no view directions / no live skip with netdepth 1..8: the
+    24 tensors of the compiled 8 x 256 network, evaluated here in plain fp64 torch, reproduce the real module's
+    function exactly (the module's own forward, run_nerf_helpers.py:105-128, restated)."""
     import torch
     import plnerf_amd as P
-    D, Wd, use_viewdirs = shape
+    D, Wd, use_viewdirs, skips = shape
     F = torch.nn.functional
     torch.manual_seed(5)
-    net = P.NeRF(D=D, W=Wd, input_ch=63, input_ch_views=27 if use_viewdirs else 0, output_ch=5, skips=[4],
+    net = P.NeRF(D=D, W=Wd, input_ch=63, input_ch_views=27 if use_viewdirs else 0, output_ch=5, skips=skips,
                  use_viewdirs=use_viewdirs).double()
     assert net.is_supported()
     x, v = torch.randn(40, 63, dtype=torch.float64), torch.randn(40, 27, dtype=torch.float64)
@@ -120,7 +143,7 @@ def test_other_network_shapes_map_exactly_onto_the_compiled_network(built, shape
     h = x
     for i in range(D):
         h = F.relu(F.linear(h, sd[f"pts_linears.{i}.weight"], sd[f"pts_linears.{i}.bias"]))
-        if i == 4:
+        if i in skips:
             h = torch.cat([x, h], -1)
     if use_viewdirs:
         sigma = F.linear(h, sd["alpha_linear.weight"], sd["alpha_linear.bias"])
@@ -141,6 +164,19 @@ def test_other_network_shapes_map_exactly_onto_the_compiled_network(built, shape
     hv = F.relu(F.linear(torch.cat([F.linear(h, feat_w, feat_b), v], -1), views_w, views_b))
     got = torch.cat([F.linear(hv, rgb_w, rgb_b), F.linear(h, alpha_w, alpha_b)], -1)
     assert float((got - want).abs().max()) <= 1e-12 * max(1.0, float(want.abs().max()))
+
+
+def test_unsupported_network_shapes_are_refused(built):
+    """What the compiled trunk cannot express is constructible (same state_dict as the reference) and refuses to run:
+    another skip position, a skip after the last layer (the reference's own head cannot consume that one either),
+    more than 8 layers, more than 256 units."""
+    import plnerf_amd as P
+    for kw in (dict(D=8, skips=[2]), dict(D=5, skips=[4]), dict(D=9, skips=[4]), dict(D=8, W=512, skips=[4]),
+               dict(D=8, skips=[4, 6])):
+        net = P.NeRF(input_ch=63, input_ch_views=27, output_ch=5, use_viewdirs=True, **kw)
+        assert not net.is_supported(), kw
+        with pytest.raises(NotImplementedError):
+            net.param_list() if False else net._require_supported()
 
 
 def test_no_cpu_fallback(built):
@@ -253,6 +289,19 @@ for r, n in zip(ref, nets):
 for n, r in zip(nets, ref):
     for p, q in zip(n.parameters(), r.parameters()):
         assert torch.allclose(p.grad, q.grad, atol=1e-6), (rank, (p.grad - q.grad).abs().max())
+# optimizer state and the loop's step count travel with the weights: rank 0 "restored a checkpoint" (has moments and a
+# step count), rank 1 starts empty -- after the broadcast both hold rank 0's
+opt = torch.optim.Adam([p for n in nets for p in n.parameters()], lr=1e-3)
+if rank == 0:
+    for k in range(3):
+        opt.step()
+dp.broadcast_optimizer_state([opt])
+start = dp.broadcast_scalar(1234 if rank == 0 else 0)
+assert start == 1234 and isinstance(start, int)
+state = [[float(opt.state[p]['step']), opt.state[p]['exp_avg'].tolist(), opt.state[p]['exp_avg_sq'].tolist()]
+         for n in nets for p in n.parameters()]
+dist.all_gather_object(gathered, state)
+assert gathered[0] == gathered[1] and gathered[0][0][0] == 3.0, "optimizer state differs after the broadcast"
 print(f"rank {rank} ok")
 '''
 
