@@ -307,14 +307,17 @@ int plnerf_mlp_saved_layout(int precision, int has_embedded, int fwd_kernel);
 #define PLNERF_FWD_KERNEL_PP 2
 
 /* Forward.  Either (pts [n_rows,3] AND viewdirs [n_rows/samples_per_ray, 3]) with
- * embedded == NULL -- the encoding is computed in the kernel prologue, once per sample
- * for xyz and from the per-ray direction (input_ch 63 / input_ch_views 27 only) -- or
+ * embedded == NULL -- the encoding gamma(x) = [x, sin(x s 2^0), cos(x s 2^0), ...] is computed in the kernel prologue,
+ * once per sample for xyz and from the per-ray direction: input_ch = 3 + 6 L (L <= 10), input_ch_views = 3 + 6 M
+ * (M <= 4), s = input_scale (1: run_nerf_helpers.py:24-54; pi: the Embedder of
+ * depth_supervised_exps/model/run_nerf_helpers.py:100-130, arguments evaluated as fl(fl(x pi) 2^k)) -- or
  * embedded [n_rows, input_ch + input_ch_views] (a caller-supplied encoding; NeRF.forward's
  * own signature).  saved == NULL for inference.  raw_out [n_rows,4].  fwd_kernel: PLNERF_FWD_KERNEL_* (pass the same
  * value to plnerf_mlp_saved_layout). */
 int plnerf_mlp_fwd(const void* packed, int precision, const float* pts, const float* viewdirs,
                    const float* embedded, int input_ch, int input_ch_views, int n_rows,
-                   int samples_per_ray, float* raw_out, void* saved, int fwd_kernel, plnerf_stream_t stream);
+                   int samples_per_ray, float input_scale, float* raw_out, void* saved, int fwd_kernel,
+                   plnerf_stream_t stream);
 
 /* Backward: g_raw [n_rows,4] -> gradients of all 24 parameter tensors, written (not
  * accumulated) to grads[24] (device pointers, same shapes as params).  Needs the `saved`

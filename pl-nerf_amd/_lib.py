@@ -59,7 +59,7 @@ SIGNATURES = {
     "plnerf_mlp_pack_weights": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_i, c_i, c_i, c_f, c_s]),
     "plnerf_mlp_saved_bytes": (ctypes.c_size_t, [c_i, c_i]),
     "plnerf_mlp_bwd_workspace_bytes": (ctypes.c_size_t, [c_i, c_i]),
-    "plnerf_mlp_fwd": (c_i, [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_s]),
+    "plnerf_mlp_fwd": (c_i, [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_i, c_s]),
     "plnerf_mlp_bwd": (c_i, [c_f, c_i, c_f, c_i, c_i, c_i, c_f, c_i, c_f, ctypes.POINTER(ctypes.c_void_p), c_s]),
     "plnerf_mlp_saved_layout": (c_i, [c_i, c_i, c_i]),
     "plnerf_adam_step": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_int64] + [ctypes.c_float] * 4 + [c_i, ctypes.c_float, ctypes.c_float,

@@ -97,30 +97,33 @@ extern "C" size_t plnerf_mlp_bwd_workspace_bytes(int n_rows, int precision) {
 
 extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pts, const float* viewdirs,
                               const float* embedded, int input_ch, int input_ch_views, int n_rows,
-                              int samples_per_ray, float* raw_out, void* saved, int fwd_kernel,
-                              plnerf_stream_t stream) {
+                              int samples_per_ray, float input_scale, float* raw_out, void* saved,
+                              int fwd_kernel, plnerf_stream_t stream) {
     if (!known(precision)) return PLNERF_ENOSYS;
     if (!kernel_arg_ok(fwd_kernel)) return PLNERF_EINVAL;
     if (n_rows < 0 || !geometry_ok(input_ch, input_ch_views)) return PLNERF_EINVAL;
-    // the in-kernel encoding is the reference's default one: 3 + 6*10 and 3 + 6*4 channels
-    if (!embedded && (input_ch != lay::XYZ_CH || input_ch_views != lay::DIR_CH)) return PLNERF_EINVAL;
+    // the in-kernel encoding: 3 + 6 L position channels (L <= 10) and 3 + 6 M direction channels (M <= 4) -- a prefix of
+    // the reference default's 63 | 27 (the unused bands meet zero-padded weights) -- with the encoder's input scale
+    if (!embedded && ((input_ch - 3) % 6 != 0 || input_ch < 3 || input_ch > lay::XYZ_CH || (input_ch_views - 3) % 6 != 0 ||
+                      input_ch_views < 3 || input_ch_views > lay::DIR_CH || !(input_scale > 0.0f) || !(input_scale < 1e6f)))
+        return PLNERF_EINVAL;
     if (n_rows == 0) return PLNERF_OK;
     if (!packed || !raw_out) return PLNERF_EINVAL;
     if (!embedded && (!pts || !viewdirs || samples_per_ray < 1)) return PLNERF_EINVAL;
     if (precision == PLNERF_PREC_FP32)
         return impl::f32_fwd(packed, pts, viewdirs, embedded, input_ch, input_ch_views, n_rows, samples_per_ray,
-                             raw_out, saved, (hipStream_t)stream);
+                             input_scale, raw_out, saved, (hipStream_t)stream);
     if (f16_of(precision) && use_rr(saved != nullptr, ns_of(precision), embedded != nullptr, fwd_kernel))
         return impl::rr_fwd(packed, (const unsigned char*)packed + impl::bf16_packed_bytes(ns_of(precision)),
                             ns_of(precision), pts, viewdirs, embedded, input_ch, input_ch_views, n_rows, samples_per_ray,
-                            raw_out, saved, status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);
+                            input_scale, raw_out, saved, status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);
     // bf16 elements: the register-resident kernel serves inference with the in-kernel encoding (unless pp is forced)
     if (!f16_of(precision) && use_rr_bf16(saved != nullptr, ns_of(precision), embedded != nullptr, fwd_kernel))
         return impl::rr_fwd_bf16(packed, (const unsigned char*)packed + impl::bf16_packed_bytes(ns_of(precision)),
                                  ns_of(precision), pts, viewdirs, embedded, input_ch, input_ch_views, n_rows, samples_per_ray,
-                                 raw_out, saved, status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);
+                                 input_scale, raw_out, saved, status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);
     return impl::bf16_fwd(packed, ns_of(precision), f16_of(precision), pts, viewdirs, embedded, input_ch,
-                          input_ch_views, n_rows, samples_per_ray, raw_out, saved,
+                          input_ch_views, n_rows, samples_per_ray, input_scale, raw_out, saved,
                           status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);
 }
 

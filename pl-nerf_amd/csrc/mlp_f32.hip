@@ -162,6 +162,7 @@ struct FwdArgs {
     int n_rows, spr;
     float* raw_out;
     float* saved;
+    float pe_scale;       // the in-kernel encoding's input scale: sin / cos(x * pe_scale * 2^k) (1, or pi: depth variant)
 };
 
 // bias (+relu) epilogue: accumulators -> LDS tile in place (+ saved plane in HBM)
@@ -221,13 +222,16 @@ __global__ __launch_bounds__(256) void mlp_fwd_f32_kernel(FwdArgs a) {
             const float px = a.pts[3 * (size_t)grow + 0], py = a.pts[3 * (size_t)grow + 1],
                         pz = a.pts[3 * (size_t)grow + 2];
             float* prow = pe + row * LDP;
-            const PeTurns tx = pe_turns(px), ty = pe_turns(py), tz = pe_turns(pz);   // one reduction per coordinate
+            // band arguments (x * pe_scale) * 2^k, the reference's association (model/run_nerf_helpers.py:123); pe_scale = 1
+            // is run_nerf_helpers.py:45-48
+            const float sx = px * a.pe_scale, sy = py * a.pe_scale, sz = pz * a.pe_scale;
+            const PeTurns tx = pe_turns(sx), ty = pe_turns(sy), tz = pe_turns(sz);   // one reduction per coordinate
             for (int f = q; f < XYZ_FREQS; f += 4) {
                 const float sc = (float)(1 << f);
                 float s, c;
-                pe_sincos_any(px, tx, sc, &s, &c); prow[3 + 6 * f + 0] = s; prow[3 + 6 * f + 3] = c;
-                pe_sincos_any(py, ty, sc, &s, &c); prow[3 + 6 * f + 1] = s; prow[3 + 6 * f + 4] = c;
-                pe_sincos_any(pz, tz, sc, &s, &c); prow[3 + 6 * f + 2] = s; prow[3 + 6 * f + 5] = c;
+                pe_sincos_any(sx, tx, sc, &s, &c); prow[3 + 6 * f + 0] = s; prow[3 + 6 * f + 3] = c;
+                pe_sincos_any(sy, ty, sc, &s, &c); prow[3 + 6 * f + 1] = s; prow[3 + 6 * f + 4] = c;
+                pe_sincos_any(sz, tz, sc, &s, &c); prow[3 + 6 * f + 2] = s; prow[3 + 6 * f + 5] = c;
             }
             if (q == 0) { prow[0] = px; prow[1] = py; prow[2] = pz; prow[XYZ_CH] = 0.0f; }
             const int ray = grow / a.spr;
@@ -237,10 +241,11 @@ __global__ __launch_bounds__(256) void mlp_fwd_f32_kernel(FwdArgs a) {
             {
                 const int f = q;  // DIR_FREQS == 4
                 const float sc = (float)(1 << f);
+                const float ux = dx * a.pe_scale, uy = dy * a.pe_scale, uz = dz * a.pe_scale;
                 float s, c;
-                pe_sincos_any(dx, pe_turns(dx), sc, &s, &c); drow[3 + 6 * f + 0] = s; drow[3 + 6 * f + 3] = c;
-                pe_sincos_any(dy, pe_turns(dy), sc, &s, &c); drow[3 + 6 * f + 1] = s; drow[3 + 6 * f + 4] = c;
-                pe_sincos_any(dz, pe_turns(dz), sc, &s, &c); drow[3 + 6 * f + 2] = s; drow[3 + 6 * f + 5] = c;
+                pe_sincos_any(ux, pe_turns(ux), sc, &s, &c); drow[3 + 6 * f + 0] = s; drow[3 + 6 * f + 3] = c;
+                pe_sincos_any(uy, pe_turns(uy), sc, &s, &c); drow[3 + 6 * f + 1] = s; drow[3 + 6 * f + 4] = c;
+                pe_sincos_any(uz, pe_turns(uz), sc, &s, &c); drow[3 + 6 * f + 2] = s; drow[3 + 6 * f + 5] = c;
             }
             if (q == 1) { drow[0] = dx; drow[1] = dy; drow[2] = dz; }
             if (q == 2) {
@@ -1116,10 +1121,10 @@ int f32_pack(const float* const* params, int xyz_ch, int dir_ch, void* packed, h
 }
 
 int f32_fwd(const void* packed, const float* pts, const float* viewdirs, const float* embedded, int xyz_ch,
-            int dir_ch, int n_rows, int samples_per_ray, float* raw_out, void* saved, hipStream_t st) {
+            int dir_ch, int n_rows, int samples_per_ray, float pe_scale, float* raw_out, void* saved, hipStream_t st) {
     constexpr int NI = 2, TM = 32 * NI;
     FwdArgs a{(const float*)packed, pts, viewdirs, embedded, xyz_ch, dir_ch, n_rows,
-              samples_per_ray < 1 ? 1 : samples_per_ray, raw_out, (float*)saved};
+              samples_per_ray < 1 ? 1 : samples_per_ray, raw_out, (float*)saved, pe_scale};
     const size_t lds = (size_t)TM * (LDA + LDP + LDD) * sizeof(float);
     dim3 grid((n_rows + TM - 1) / TM), block(256);
     if (saved) {

@@ -79,6 +79,15 @@ def run_network(inputs, viewdirs, embedded_cam, fn, embed_fn, embeddirs_fn, bb_c
     if enc is not None and not (torch.is_grad_enabled() and (inputs.requires_grad or
                                                              (viewdirs is not None and viewdirs.requires_grad))):
         fx, fd, scale = enc
+        identity_box = float(torch.as_tensor(bb_scale)) == 1.0 and not bool(torch.as_tensor(bb_center).any())
+        if (cam is None and identity_box and fn.has_fused_encoding() and fn.input_ch == 3 + 6 * fx and
+                (not fn.use_viewdirs or fn.input_ch_views == 3 + 6 * fd)):
+            # the encoding in the MLP kernel's own prologue, as on the NVS path: no `embedded` matrix at all
+            rays_per_launch = max(1, MAX_ROWS_PER_LAUNCH // max(S, 1))
+            vd = viewdirs if fn.use_viewdirs else None
+            outs = [fn.query(inputs[i:i + rays_per_launch], None if vd is None else vd[i:i + rays_per_launch],
+                             input_scale=scale) for i in range(0, R, rays_per_launch)]
+            return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
         embedded = Fn.embed_rows(inputs, viewdirs, cam, fx, fd, input_scale=scale, bb_center=bb_center,
                                  bb_scale=bb_scale)
         cam_grad = cam if (cam is not None and torch.is_grad_enabled() and cam.requires_grad) else None

@@ -329,6 +329,7 @@ class MlpFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pts, viewdirs, embedded, cam, spr, net, want_grad, *params):
+        pe_scale = float(getattr(net, "_query_scale", 1.0))      # (set by NeRF.query for the duration of the call)
         prec = L.PRECISION[net.precision]
         # The kernels produce parameter gradients only (the sample positions carry no gradient
         # on the reference's path).  A gradient requested for an MLP *input* would be dropped silently by returning
@@ -362,7 +363,7 @@ class MlpFn(torch.autograd.Function):
             ev[0].record()
         L.check(L.lib().plnerf_mlp_fwd(
             L.dptr(packed, "packed"), prec, L.dptr(pts_c, "pts"), L.dptr(vd_c, "viewdirs"),
-            L.dptr(emb_c, "embedded"), int(net.input_ch), int(net.hip_view_ch), n_rows, int(spr), L.dptr(raw),
+            L.dptr(emb_c, "embedded"), int(net.input_ch), int(net.hip_view_ch), n_rows, int(spr), pe_scale, L.dptr(raw),
             L.dptr(saved), L.FWD_KERNEL, L.stream()), "plnerf_mlp_fwd")
         if timer is not None:
             ev[1].record()

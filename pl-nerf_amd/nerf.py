@@ -136,11 +136,16 @@ class NeRF(nn.Module):
         return trunk and 1 <= self.view_ch <= MAX_VIEW_CH
 
     def has_fused_encoding(self):
-        """True when the kernel's own positional encoding (3 + 6*10 | 3 + 6*4 channels) is this network's."""
+        """True when the kernel's own positional encoding can be this network's: 3 + 6 L position channels (L <= 10) and
+        3 + 6 M direction channels (M <= 4) -- a prefix of the compiled 63 | 27 (the unused bands meet zero-padded
+        weights) -- and no camera code.  The encoder's input scale (1, or pi for the depth variant) is an argument of
+        the call (query(..., input_scale=...))."""
+        ok_x = self.input_ch >= 3 and (self.input_ch - 3) % 6 == 0 and self.input_ch <= SUPPORTED["input_ch"]
         if not self.use_viewdirs:
-            return self.input_ch == SUPPORTED["input_ch"]
-        return (self.input_ch == SUPPORTED["input_ch"] and self.input_ch_views == SUPPORTED["input_ch_views"] and
-                self.input_ch_cam == 0)
+            return ok_x
+        ok_d = self.input_ch_views >= 3 and (self.input_ch_views - 3) % 6 == 0 and \
+            self.input_ch_views <= SUPPORTED["input_ch_views"]
+        return ok_x and ok_d and self.input_ch_cam == 0
 
     def _require_supported(self):
         if not self.is_supported():
@@ -313,17 +318,21 @@ class NeRF(nn.Module):
         out = MlpFn.apply(None, None, flat, cam, 1, self, torch.is_grad_enabled(), *self.param_list())
         return self._outputs(out.reshape(*lead, 4))
 
-    def query(self, pts, viewdirs):
-        """Fused entry: pts [R,S,3], viewdirs [R,3] -> raw [R,S,4]; the encoding happens in
-        the kernel prologue (what run_network does on the hot path)."""
+    def query(self, pts, viewdirs, input_scale=1.0):
+        """Fused entry: pts [R,S,3], viewdirs [R,3] -> raw [R,S,4]; the encoding gamma(x) = [x, sin / cos(x s 2^k)] with
+        s = input_scale happens in the kernel prologue (what run_network does on the hot path)."""
         self._require_supported()
         if not self.has_fused_encoding():
-            raise NotImplementedError("the in-kernel encoding is the reference default (63 | 27 channels); "
-                                      "embed on the caller side and use forward()")
+            raise NotImplementedError("the in-kernel encoding covers 3 + 6 L | 3 + 6 M channels (L <= 10, M <= 4) without "
+                                      "a camera code; embed on the caller side and use forward()")
         R, S = pts.shape[0], pts.shape[1]
         if viewdirs is None:
             if self.use_viewdirs:
                 raise ValueError("this network takes view directions")
             viewdirs = pts.new_zeros(R, 3)
-        out = MlpFn.apply(pts.reshape(-1, 3), viewdirs, None, None, S, self, torch.is_grad_enabled(), *self.param_list())
+        self._query_scale = float(input_scale)
+        try:
+            out = MlpFn.apply(pts.reshape(-1, 3), viewdirs, None, None, S, self, torch.is_grad_enabled(), *self.param_list())
+        finally:
+            self._query_scale = 1.0
         return self._outputs(out.reshape(R, S, 4))

@@ -27,12 +27,15 @@ def batchify(fn, chunk):
 
 
 def _fusable(fn, embed_fn, embeddirs_fn, viewdirs):
+    # the kernel's own encoding: 3 + 6 L | 3 + 6 M channels (multires L <= 10, multires_views M <= 4), the reference's
+    # Embedder with the matching number of frequencies
     if not (isinstance(fn, NeRF) and fn.is_supported() and fn.has_fused_encoding() and
-            isinstance(embed_fn, Embedder) and embed_fn.is_standard(10)):
+            isinstance(embed_fn, Embedder) and embed_fn.is_standard((fn.input_ch - 3) // 6)):
         return False
     if not fn.use_viewdirs:      # (output_linear on the trunk: the view directions, if any were passed, are not used)
         return True
-    return viewdirs is not None and isinstance(embeddirs_fn, Embedder) and embeddirs_fn.is_standard(4)
+    return viewdirs is not None and isinstance(embeddirs_fn, Embedder) and \
+        embeddirs_fn.is_standard((fn.input_ch_views - 3) // 6)
 
 
 def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64):

@@ -24,7 +24,7 @@ int main(void) {
     if (plnerf_mlp_saved_layout(PLNERF_PREC_F16X3, 0, PLNERF_FWD_KERNEL_AUTO) != 1) return 5;
     if (plnerf_mlp_saved_layout(PLNERF_PREC_F16X3, 0, 99) >= 0) return 6;
     /* argument validation runs before any device work: a null pointer is PLNERF_EINVAL, not a crash */
-    if (plnerf_mlp_fwd(NULL, PLNERF_PREC_FP32, NULL, NULL, NULL, 63, 27, 8, 1, NULL, NULL, PLNERF_FWD_KERNEL_AUTO, NULL) !=
+    if (plnerf_mlp_fwd(NULL, PLNERF_PREC_FP32, NULL, NULL, NULL, 63, 27, 8, 1, 1.0f, NULL, NULL, PLNERF_FWD_KERNEL_AUTO, NULL) !=
         PLNERF_EINVAL)
         return 7;
     if (plnerf_adam_step(NULL, NULL, NULL, NULL, 4, 1e-3f, 0.9f, 0.999f, 1e-8f, 1, 1.0f, 0.0f, NULL, NULL, NULL, NULL) !=

@@ -159,3 +159,57 @@ def test_camera_code_gradient_through_the_mlp(P, precision):
     # positions that require grad are still refused, loudly
     with pytest.raises(NotImplementedError):
         net(torch.zeros(4, 64, device=dev(), requires_grad=True))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_in_kernel_scaled_encoding_matches_the_embedded_route_and_the_oracle(P, precision):
+    """The depth variant's pi-scaled encoding evaluated in the MLP kernel's own prologue (NeRF.query(input_scale=pi), what
+    depth.run_network does when there is no camera code and no bounding-box affine) against (i) the oracle's network on
+    the reference's torch encoding and (ii) the embedded route (plnerf_embed_rows + NeRF.forward) through the same
+    weights, forward and parameter gradients; and the NVS encoder with fewer frequencies (multires 6 / multires_views 2:
+    39 | 15 channels, a prefix of the compiled 63 | 27) through render.run_network."""
+    from plnerf_amd import depth as Dp, functional as Fn
+    gen = torch.Generator().manual_seed(31)
+    R, S = 21, 50
+    sd = orc.closed_form_state_dict_depth(2, True)
+    net = P.NeRF(D=8, W=256, input_ch=57, input_ch_views=3, output_ch=5, skips=[4], use_viewdirs=True, precision=precision,
+                 density_activation="softplus")
+    net.load_state_dict(sd)
+    net = net.to(dev())
+    assert net.has_fused_encoding()
+    pts = (torch.rand(R, S, 3, generator=gen) * 2 - 1) * 1.5
+    vd = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
+    cot = torch.randn(R, S, 4, generator=gen)
+    ref = orc.query_network_depth(sd, pts, vd)
+    emb_fn, _ = Dp.get_embedder(9, 0)
+    embd_fn, _ = Dp.get_embedder(0, 0)
+    raw = Dp.run_network(g(pts), g(vd), torch.tensor((), device=dev()), net, emb_fn, embd_fn, 0.0, 1.0)   # fused route
+    (raw * g(cot)).sum().backward()
+    g_fused = [p.grad.detach().clone() for p in net.parameters()]
+    for p_ in net.parameters():
+        p_.grad = None
+    emb = Fn.embed_rows(g(pts), g(vd), None, 9, 0, input_scale=np.pi)
+    raw_e = net(emb).reshape(R, S, 4)
+    (raw_e * g(cot)).sum().backward()
+    err_o = float((raw.detach().cpu() - ref).abs().max())
+    err_e = float((raw.detach() - raw_e.detach()).abs().max())
+    worst = max(float((a - p_.grad).abs().max()) / max(float(p_.grad.abs().max()), 1e-9) for a, p_ in zip(g_fused, net.parameters()))
+    print(f"{precision}: in-kernel pi encoding vs oracle {err_o:.2e}, vs embedded route {err_e:.2e}, gradients between the routes {worst:.2e}")
+    assert err_o <= 1e-5 * (1.0 + float(ref.abs().max())) and err_e <= 2e-6 * (1.0 + float(ref.abs().max()))
+    assert worst <= (2e-5 if precision == "fp32" else 2e-3)
+    # a bounding-box affine or a camera code keeps the embedded route (same numbers, no refusal)
+    raw_b = Dp.run_network(g(pts), g(vd), torch.tensor((), device=dev()), net, emb_fn, embd_fn, 0.1, 0.9)
+    ref_b = orc.query_network_depth(sd, pts, vd, bb_center=0.1, bb_scale=0.9)
+    assert float((raw_b.detach().cpu() - ref_b).abs().max()) <= 1e-5 * (1.0 + float(ref_b.abs().max()))
+    # the NVS encoder with fewer frequencies
+    net2 = P.NeRF(D=8, W=256, input_ch=39, input_ch_views=15, output_ch=5, skips=[4], use_viewdirs=True,
+                  precision=precision).to(dev())
+    e6, _ = P.get_embedder(6, 0)
+    e2, _ = P.get_embedder(2, 0)
+    with torch.no_grad():
+        fused = P.run_network(g(pts), g(vd), net2, e6, e2)
+        flat = torch.cat([e6(g(pts).reshape(-1, 3)), e2(g(vd)[:, None].expand(R, S, 3).reshape(-1, 3))], -1)
+        generic = net2(flat).reshape(R, S, -1)
+    err2 = float((fused - generic).abs().max())
+    print(f"{precision}: 39|15-channel network, fused vs torch-embedded {err2:.2e}")
+    assert err2 <= 5e-6 * (1.0 + float(generic.abs().max()))

@@ -523,7 +523,12 @@ def test_depth_variant_host_logic(built):
     kw, kw_test, start, grad_vars, opt = Dp.create_nerf(args, device=torch.device("cpu"))
     net = kw["network_fn"]
     assert [tuple(p.shape) for p in net.parameters()] == [s for _, s in orc.param_shapes_depth()]
-    assert net.is_supported() and not net.has_fused_encoding() and net.density_activation == "softplus"
+    # (57 | 3 channels are a prefix of the compiled 63 | 27: since round 3 the kernel's own encoding serves them, with the
+    # encoder's input scale pi as an argument of the call; a camera code still takes the embedded route)
+    assert net.is_supported() and net.has_fused_encoding() and net.density_activation == "softplus"
+    import plnerf_amd as P
+    assert not P.NeRF(input_ch=57, input_ch_views=3, input_ch_cam=4, use_viewdirs=True).has_fused_encoding()
+    assert not P.NeRF(input_ch=58, input_ch_views=3, use_viewdirs=True).has_fused_encoding()
     assert all(float(m.bias.detach().abs().max()) == 0.0 for m in net.modules() if isinstance(m, torch.nn.Linear))
     w = net.pts_linears[1].weight
     bound = (2.0 ** 0.5) * (6.0 / (256 + 256)) ** 0.5                    # xavier-uniform with the relu gain
