@@ -547,13 +547,17 @@ def nerf_mlp_depth(sd, embedded):
 
 
 def query_network_depth(sd, pts, viewdirs, bb_center=0.0, bb_scale=1.0, xyz_freqs=DEPTH_XYZ_FREQS,
-                        dir_freqs=DEPTH_DIR_FREQS, netchunk=65536):
-    """run_nerf_sample_based_depth.py:52-68 (embedded_cam empty, its default)."""
+                        dir_freqs=DEPTH_DIR_FREQS, netchunk=65536, embedded_cam=None):
+    """run_nerf_sample_based_depth.py:52-68.  embedded_cam (a vector, :1122-1123; empty by default): repeated on every
+    row behind the direction encoding (:64); the view layer's weight then has that many more input columns
+    (model/run_nerf_helpers.py:164-170).  Pinned to the reference by fixture G8c."""
     R, S = pts.shape[0], pts.shape[1]
     flat = (pts.reshape(-1, 3) - bb_center) * bb_scale
     emb = positional_encoding_pi(flat, xyz_freqs)
     dirs = viewdirs[:, None, :].expand(R, S, 3).reshape(-1, 3)
     emb = torch.cat([emb, positional_encoding_pi(dirs, dir_freqs)], dim=-1)
+    if embedded_cam is not None and embedded_cam.numel() > 0:
+        emb = torch.cat([emb, embedded_cam.reshape(1, -1).expand(emb.shape[0], embedded_cam.numel())], dim=-1)
     outs = [nerf_mlp_depth(sd, emb[i:i + netchunk]) for i in range(0, emb.shape[0], netchunk)]
     return torch.cat(outs, 0).reshape(R, S, 4)
 

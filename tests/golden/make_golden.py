@@ -7,7 +7,8 @@ _ref_import.py):
 
 Fixtures are data only: inputs and the reference's outputs.  Network weights
 come from oracle.plnerf_oracle.closed_form_state_dict (an RNG-free recipe), so
-they are not stored.  Fixture ids follow SURVEY.md section 8c (G1..G8); G8b = G8's step at configs[4]'s 128+64 sampling, G9 = the
+they are not stored.  Fixture ids follow SURVEY.md section 8c (G1..G8); G8b = G8's step at configs[4]'s 128+64 sampling, G8c = the
+camera code (input_ch_cam = 4) through the reference's network and run_network, G9 = the
 reference's checkpoint file and what the reference computes after re-loading it.
 """
 import os
@@ -357,6 +358,38 @@ def g8b():
     npz("g8b_depth_variant_128_64", **_depth_render_and_step(D, DH, coarse, fine, query, R=16, Ns=128, Ni=64, seed=88))
 
 
+def g8c():
+    """The camera code of the depth-supervised script (input_ch_cam = 4: run_nerf_sample_based_depth.py:52-68, 1091-1093,
+    1122-1123; model/run_nerf_helpers.py:143-205) with a bounding-box affine: the reference's own NeRF and run_network,
+    forward, and what its autograd gives for d / d embedded_cam and for the view layer's weight (whose last four columns
+    multiply the code) under a fixed cotangent.  Weights: the closed-form depth recipe, the four extra view-layer
+    columns from a closed-form sine as well (stored: they are not part of the recipe)."""
+    D, DH = import_depth_reference()
+    n_cam = 4
+    embed_fn, input_ch = DH.get_embedder(9, 0)
+    embeddirs_fn, input_ch_views = DH.get_embedder(0, 0)
+    net = DH.NeRF(D=8, W=256, input_ch=input_ch, output_ch=5, skips=[4], input_ch_views=input_ch_views,
+                  input_ch_cam=n_cam, use_viewdirs=True)
+    sd = orc.closed_form_state_dict_depth(3, sharpen=False)
+    idx = torch.arange(128 * n_cam, dtype=torch.float64).reshape(128, n_cam)
+    extra = (0.05 * torch.sin(0.37 * idx + 1.3)).float()
+    sd["views_linears.0.weight"] = torch.cat([sd["views_linears.0.weight"], extra], 1)
+    net.load_state_dict(sd)
+    gen = torch.Generator().manual_seed(83)
+    R, S = 12, 20
+    pts = (torch.rand(R, S, 3, generator=gen) * 2 - 1) * 1.5
+    vd = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
+    cam = (torch.randn(n_cam, generator=gen) * 0.3).requires_grad_(True)
+    cot = torch.randn(R, S, 4, generator=gen)
+    bb_center, bb_scale = 0.15, 0.8
+    raw = D.run_network(pts, vd, cam, net, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, bb_center=bb_center,
+                        bb_scale=bb_scale, netchunk=65536)
+    (raw * cot).sum().backward()
+    npz("g8c_camera_code", pts=pts, viewdirs=vd, cam=cam.detach(), cotangent=cot, bb_center=bb_center, bb_scale=bb_scale,
+        view_weight_extra=extra, raw=raw.detach(), grad_cam=cam.grad, grad_view_weight=net.views_linears[0].weight.grad,
+        grad_view_bias=net.views_linears[0].bias.grad)
+
+
 # ---------------------------------------------------------------- G9: checkpoint wire format
 def g9():
     """The reference's checkpoint (run_plnerf.py:1324-1332) written after G6 case 0's optimisation step, re-loaded by
@@ -455,6 +488,6 @@ def g8():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g8b", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g8b", "g8c", "g9"]
     for name in which:
         globals()[name]()

@@ -213,3 +213,35 @@ def test_in_kernel_scaled_encoding_matches_the_embedded_route_and_the_oracle(P, 
     err2 = float((fused - generic).abs().max())
     print(f"{precision}: 39|15-channel network, fused vs torch-embedded {err2:.2e}")
     assert err2 <= 5e-6 * (1.0 + float(generic.abs().max()))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_camera_code_against_the_reference_fixture(P, golden, precision):
+    """Fixture G8c -- the reference's own NeRF(input_ch_cam = 4) + run_network with a bounding-box affine: raw, d / d
+    embedded_cam and the view layer's gradients -- through depth.run_network (plnerf_embed_rows + the EMB kernels +
+    MlpFn's camera gradient)."""
+    from plnerf_amd import depth as Dp
+    gd = golden("g8c_camera_code")
+    T = torch.from_numpy
+    sd = orc.closed_form_state_dict_depth(3, False)
+    sd["views_linears.0.weight"] = torch.cat([sd["views_linears.0.weight"], T(gd["view_weight_extra"])], 1)
+    net = P.NeRF(D=8, W=256, input_ch=57, input_ch_views=3, input_ch_cam=4, output_ch=5, skips=[4], use_viewdirs=True,
+                 precision=precision, density_activation="softplus")
+    net.load_state_dict(sd)
+    net = net.to(dev())
+    emb_fn, _ = Dp.get_embedder(9, 0)
+    embd_fn, _ = Dp.get_embedder(0, 0)
+    cam = g(T(gd["cam"])).requires_grad_(True)
+    raw = Dp.run_network(g(T(gd["pts"])), g(T(gd["viewdirs"])), cam, net, emb_fn, embd_fn, float(gd["bb_center"]),
+                         float(gd["bb_scale"]))
+    (raw * g(T(gd["cotangent"]))).sum().backward()
+    err = float((raw.detach().cpu() - T(gd["raw"])).abs().max())
+    tol = 2e-4 if precision == "fp32" else 6e-3
+    rel = {}
+    for got, key in ((cam.grad, "grad_cam"), (net.views_linears[0].weight.grad, "grad_view_weight"),
+                     (net.views_linears[0].bias.grad, "grad_view_bias")):
+        ref = T(gd[key])
+        rel[key] = float((got.cpu() - ref).abs().max()) / float(ref.abs().max())
+    print(f"{precision} G8c: raw {err:.2e}; " + ", ".join(f"{k} {v:.2e}" for k, v in rel.items()))
+    assert err <= 1e-5 * (1.0 + float(T(gd["raw"]).abs().max()))
+    assert all(v <= tol for v in rel.values()), rel

@@ -230,3 +230,27 @@ def test_sampler_h4_is_defined_at_u_equal_one():
     _, _, _, w, _, tau, Tr = orc.raw2outputs(raw, z, near, far, d, "linear", "midpoint")
     s = orc.sample_pdf_reformulation(z, w, tau, Tr, near, far, 8, det=True)[0]
     assert torch.isfinite(s).all() and (s >= 2.0).all() and (s <= 6.0).all()
+
+
+def test_g8c_camera_code_through_the_depth_network(golden):
+    """The oracle's run_network with a camera code and a bounding-box affine against the reference's own NeRF(input_ch_cam
+    = 4) + run_network (fixture G8c): forward, and autograd's d / d embedded_cam and view-layer gradients."""
+    gd = golden("g8c_camera_code")
+    T = torch.from_numpy
+    sd = orc.closed_form_state_dict_depth(3, False)
+    sd["views_linears.0.weight"] = torch.cat([sd["views_linears.0.weight"], T(gd["view_weight_extra"])], 1)
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    cam = T(gd["cam"]).clone().requires_grad_(True)
+    raw = orc.query_network_depth(sd, T(gd["pts"]), T(gd["viewdirs"]), bb_center=float(gd["bb_center"]),
+                                  bb_scale=float(gd["bb_scale"]), embedded_cam=cam)
+    (raw * T(gd["cotangent"])).sum().backward()
+    assert float((raw.detach() - T(gd["raw"])).abs().max()) <= 2e-6
+    for got, key in ((cam.grad, "grad_cam"), (sd["views_linears.0.weight"].grad, "grad_view_weight"),
+                     (sd["views_linears.0.bias"].grad, "grad_view_bias")):
+        ref = T(gd[key])
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-7, key
+    # the identity the HIP path uses: every row carries the same code, so its gradient is the view layer's weight
+    # columns applied to the row-sum of dz_view, i.e. to the view layer's bias gradient
+    wv = sd["views_linears.0.weight"].detach()
+    via_bias = wv[:, -cam.numel():].t() @ T(gd["grad_view_bias"])
+    assert float((via_bias - T(gd["grad_cam"])).abs().max()) <= 2e-5 * float(T(gd["grad_cam"]).abs().max())
