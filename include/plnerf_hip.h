@@ -205,6 +205,12 @@ int plnerf_coarse_epilogue(const float* raw, const float* z, const float* near, 
  * Stream ids: 0 = t_rand (stratified jitter, :700-705), 1 = u (importance samples). */
 int plnerf_uniform(uint64_t seed, uint32_t stream_id, uint32_t step, int ray_id0, int R, int n,
                    float* out /* [R,n] */, plnerf_stream_t stream);
+/* The same counters through Box-Muller: standard normal draws [R, n] keyed on (seed, step, stream_id, ray_id0 + row,
+ * column) -- the density noise of raw2outputs (run_plnerf.py:568-570: torch.randn(...) * raw_noise_std), invariant
+ * to how a batch is sharded over ranks.  (The reference's own stream is torch's generator; only the distribution is
+ * the reference's.) */
+int plnerf_normal(uint64_t seed, uint32_t stream_id, uint32_t step, int ray_id0, int R, int n, float* out,
+                  plnerf_stream_t stream);
 
 /* Training rays of one view (run_plnerf.py:1259-1281 + run_nerf_helpers.py:162-171 + the ray
  * packing of render, run_plnerf.py:146-164): ray i (global id ray_id0 + i) looks through pixel

@@ -47,6 +47,7 @@ SIGNATURES = {
     "plnerf_coarse_epilogue": (c_i, [c_f] * 8 + [c_i, ctypes.c_uint64, ctypes.c_uint32] + [c_i] * 7 +
                                [ctypes.c_float] * 2 + [c_f] * 10 + [c_s]),
     "plnerf_uniform": (c_i, [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_i, c_i, c_i, c_f, c_s]),
+    "plnerf_normal": (c_i, [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_i, c_i, c_i, c_f, c_s]),
     "plnerf_select_rays": (c_i, [c_i, c_i] + [ctypes.c_float] * 4 + [ctypes.POINTER(ctypes.c_float), c_f] + [c_i] * 4 +
                            [ctypes.c_uint64, ctypes.c_uint32, c_i, c_i, ctypes.c_float, ctypes.c_float] + [c_f] * 7 +
                            [c_s]),

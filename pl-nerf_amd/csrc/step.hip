@@ -2,6 +2,7 @@
 // render() with a dozen host / element-wise torch operations per step.
 //
 //   plnerf_uniform         counter-based uniform draws (philox.h): the t_rand / u tensors, world-size invariant
+//   plnerf_normal          the same counters through Box-Muller: the density noise of raw2outputs (run_plnerf.py:568-570)
 //   plnerf_select_rays     run_plnerf.py:1259-1281: N_rand distinct random pixels of one view -> their rays
 //                          (get_rays, run_nerf_helpers.py:162-171), unit view directions (run_plnerf.py:148-150),
 //                          near / far columns and the target colours -- without building the H x W ray grid
@@ -39,6 +40,33 @@ __global__ __launch_bounds__(256) void uniform_kernel(const RngArgs g, const int
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (4 * b + k < n) row[k] = u01(c[k]);
+}
+
+// standard normal draws from the same counters (Box-Muller on the block's two uniform pairs): the density noise of
+// raw2outputs (run_plnerf.py:568-570: randn * raw_noise_std) keyed on the GLOBAL ray id, so that a sharded batch sees the
+// noise one rank would see -- the LLFF configurations train with raw_noise_std = 1
+__global__ __launch_bounds__(256) void normal_kernel(const RngArgs g, const int R, const int n, float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int blocks_per_row = (n + 3) >> 2;
+    if (idx >= (size_t)R * blocks_per_row) return;
+    const int r = (int)(idx / blocks_per_row), b = (int)(idx - (size_t)r * blocks_per_row);
+    uint32_t c[4] = {(uint32_t)(g.ray_id0 + r), (uint32_t)b, g.stream, g.step};
+    philox4x32_10(c, g.seed_lo, g.seed_hi);
+    float z[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u1 = 1.0f - u01(c[2 * h]);          // (0, 1]: the logarithm is finite
+        const float u2 = u01(c[2 * h + 1]);
+        const float rad = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(6.28318530717958647692f * u2, &sn, &cs);
+        z[2 * h] = rad * cs;
+        z[2 * h + 1] = rad * sn;
+    }
+    float* row = out + (size_t)r * n + 4 * b;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (4 * b + k < n) row[k] = z[k];
 }
 
 // ---- pixel choice: a keyed bijection of [0, M) (4-round Feistel network on 2 hb bits, cycle-walked into the
@@ -395,6 +423,19 @@ extern "C" int plnerf_uniform(uint64_t seed, uint32_t stream_id, uint32_t step, 
     const RngArgs g{(uint32_t)seed, (uint32_t)(seed >> 32), stream_id, step, ray_id0, 1};
     const size_t blocks = (size_t)R * ((n + 3) / 4);
     hipLaunchKernelGGL(uniform_kernel, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, R, n,
+                       out);
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}
+
+extern "C" int plnerf_normal(uint64_t seed, uint32_t stream_id, uint32_t step, int ray_id0, int R, int n, float* out,
+                             plnerf_stream_t stream) {
+    if (R < 0 || n < 1) return PLNERF_EINVAL;
+    if (R == 0) return PLNERF_OK;
+    if (!out) return PLNERF_EINVAL;
+    const RngArgs g{(uint32_t)seed, (uint32_t)(seed >> 32), stream_id, step, ray_id0, 1};
+    const size_t blocks = (size_t)R * ((n + 3) / 4);
+    hipLaunchKernelGGL(normal_kernel, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, R, n,
                        out);
     PLNERF_CHECK_LAUNCH();
     return PLNERF_OK;

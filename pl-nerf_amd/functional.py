@@ -173,11 +173,12 @@ class DrawSource:
     ray's GLOBAL id, column) only, so a batch sharded over N ranks (ray_id0 = the rank's first global ray) sees the
     numbers one rank would see.  Install with `set_draw_source`; render_rays then takes its stratified jitter and
     its sampler draws from here (in the consuming kernels themselves on the fused path) instead of torch.rand."""
-    T_RAND, U = 0, 1          # stream ids
+    T_RAND, U, NOISE = 0, 1, 2          # stream ids (the density noise takes NOISE for the coarse pass, NOISE + 1 for the fine one)
 
     def __init__(self, seed=0, ray_id0=0, step=0):
         self.seed, self.ray_id0, self.step = int(seed), int(ray_id0), int(step)
         self.chunk_offset = 0
+        self.noise_calls = 0      # raw2outputs calls of the current render_rays (coarse pass, then fine pass)
 
     def first_ray(self):
         return self.ray_id0 + self.chunk_offset
@@ -188,6 +189,21 @@ class DrawSource:
             L.check(L.lib().plnerf_uniform(self.seed, stream_id, self.step, self.first_ray(), R, n, L.dptr(out),
                                            L.stream()), "plnerf_uniform")
         return out
+
+    def normal(self, R, n, stream_id, device):
+        """Standard normal draws [R, n] from the same counters (plnerf_normal)."""
+        out = torch.empty(R, n, device=device)
+        if R > 0:
+            L.check(L.lib().plnerf_normal(self.seed, stream_id, self.step, self.first_ray(), R, n, L.dptr(out),
+                                          L.stream()), "plnerf_normal")
+        return out
+
+    def next_noise_stream(self):
+        """Stream id of this raw2outputs call's density noise: the coarse and the fine pass of a render_rays call (of a
+        chunk of it) alternate; the ray's global id does the rest."""
+        sid = self.NOISE + (self.noise_calls & 1)
+        self.noise_calls += 1
+        return sid
 
 
 DRAWS = None

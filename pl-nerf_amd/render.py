@@ -97,6 +97,10 @@ def _draw_noise(raw, raw_noise_std, pytest):
     shape = list(raw.shape[:-1])
     if pytest:   # the reference's deterministic draw is UNIFORM (run_plnerf.py:573-576)
         return Fn.numpy_uniform(shape, raw.device) * raw_noise_std
+    if Fn.DRAWS is not None and len(shape) == 2 and raw.is_cuda:
+        # counter-based normal draws keyed on the global ray id: like the jitter and the sampler's u, the density noise of
+        # the LLFF configurations does not depend on how the batch is sharded
+        return Fn.DRAWS.normal(shape[0], shape[1], Fn.DRAWS.next_noise_stream(), raw.device) * raw_noise_std
     return torch.randn(shape, device=raw.device) * raw_noise_std
 
 
@@ -189,6 +193,8 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_
     # supplies counter-based draws (inside the consuming kernels on the fused path), else torch.rand as the
     # reference does.
     draws = None if pytest else Fn.DRAWS
+    if draws is not None:
+        draws.noise_calls = 0      # (this call's coarse pass draws its density noise first, then the fine pass)
     if fused_glue:
         t_rand = None
         if perturb > 0. and (pytest or draws is None):

@@ -12,7 +12,7 @@ int main(void) {
         (any_fn)plnerf_depth_loss, (any_fn)plnerf_embed_rows, (any_fn)plnerf_quad_fwd, (any_fn)plnerf_quad_bwd,
         (any_fn)plnerf_sample_const, (any_fn)plnerf_sample_const_bwd, (any_fn)plnerf_sample_pl, (any_fn)plnerf_sample_pl_bwd,
         (any_fn)plnerf_stratified_z, (any_fn)plnerf_ray_points, (any_fn)plnerf_merge_sort, (any_fn)plnerf_coarse_epilogue,
-        (any_fn)plnerf_uniform, (any_fn)plnerf_select_rays, (any_fn)plnerf_coarse_samples, (any_fn)plnerf_mlp_packed_bytes,
+        (any_fn)plnerf_uniform, (any_fn)plnerf_normal, (any_fn)plnerf_select_rays, (any_fn)plnerf_coarse_samples, (any_fn)plnerf_mlp_packed_bytes,
         (any_fn)plnerf_mlp_status_offset, (any_fn)plnerf_mlp_pack_weights, (any_fn)plnerf_mlp_saved_bytes,
         (any_fn)plnerf_mlp_bwd_workspace_bytes, (any_fn)plnerf_mlp_saved_layout, (any_fn)plnerf_mlp_fwd, (any_fn)plnerf_mlp_bwd,
         (any_fn)plnerf_adam_step};

@@ -57,6 +57,23 @@ def test_philox_known_answers_and_device_draws(P):
                    Fn.DrawSource(seed=3, ray_id0=5, step=2).uniform(3, 64, 0, dev())], 0)
     assert torch.equal(a, b)
     assert not torch.equal(a, Fn.DrawSource(seed=3, ray_id0=0, step=3).uniform(8, 64, 0, dev()))
+    # normal draws (the density noise): Box-Muller on the same Philox block, restated on the host
+    nrm = src.normal(5, 10, 2, dev()).cpu().numpy()
+    for r in range(5):
+        for col in range(10):
+            w = _philox4x32_10([id0 + r, col >> 2, 2, step], [seed & 0xFFFFFFFF, seed >> 32])
+            h = (col & 3) >> 1
+            u1 = 1.0 - np.float64(np.float32((w[2 * h] >> 8) * 2.0 ** -24))
+            u2 = np.float64(np.float32((w[2 * h + 1] >> 8) * 2.0 ** -24))
+            rad, ang = np.sqrt(-2.0 * np.log(u1)), 2.0 * np.pi * u2
+            want = rad * (np.cos(ang) if (col & 1) == 0 else np.sin(ang))
+            assert abs(nrm[r, col] - want) <= 2e-6 * (1.0 + abs(want)), (r, col, nrm[r, col], want)
+    bign = src.normal(4096, 192, 2, dev())
+    assert torch.isfinite(bign).all() and abs(float(bign.mean())) < 5e-3 and abs(float(bign.var()) - 1.0) < 1e-2
+    assert abs(float((bign ** 4).mean()) - 3.0) < 0.1                     # kurtosis of a normal
+    n1 = torch.cat([Fn.DrawSource(seed=3, ray_id0=0, step=2).normal(5, 64, 2, dev()),
+                    Fn.DrawSource(seed=3, ray_id0=5, step=2).normal(3, 64, 2, dev())], 0)
+    assert torch.equal(n1, Fn.DrawSource(seed=3, ray_id0=0, step=2).normal(8, 64, 2, dev()))
 
 
 # ----------------------------------------------------------------------------- fused coarse epilogue
@@ -223,6 +240,16 @@ def test_render_is_invariant_to_sharding_of_the_batch(P):
         assert_close(chunked[k], whole[k].cpu(), atol=2e-5, rtol=2e-5, what=f"chunked {k}")
     other = run(rays, 1)          # the same rays under other global ids: different draws
     assert maxdiff(whole["depth_map"], other["depth_map"]) > 1e-3
+    # the density noise of the LLFF configurations (raw_noise_std = 1: run_plnerf.py:568-570) comes from the same
+    # counters: sharding- and chunking-invariant too, different between the coarse and the fine pass, and it matters
+    rkw = dict(rkw, raw_noise_std=1.0)
+    whole_n = run(rays, 0)
+    a, b = run(rays[:40], 0), run(rays[40:], 40)
+    chunked = run(rays, 0, chunk=36)
+    for k in ("rgb_map", "depth_map", "rgb0", "z_std"):
+        assert_close(torch.cat([a[k], b[k]], 0), whole_n[k].cpu(), atol=2e-5, rtol=2e-5, what=f"noise, two shards {k}")
+        assert_close(chunked[k], whole_n[k].cpu(), atol=2e-5, rtol=2e-5, what=f"noise, chunked {k}")
+    assert maxdiff(whole_n["rgb0"], whole["rgb0"]) > 1e-4
 
 
 def test_train_step_from_a_view(P):
