@@ -189,7 +189,12 @@ class NeRF(nn.Module):
             direction columns); rgb = relu(F) - relu(-F) + b = F + b; sigma = the alpha row = W_out[3]."""
         layout = self._skip_layout()
         if self.use_viewdirs and self.D == SUPPORTED["D"] and self.W == SUPPORTED["W"] and layout == "at4":
-            return list(self.parameters())
+            # (the Parameter objects never change -- .to(), load_state_dict and optim.FlatAdam all work on their .data --
+            # so the walk over the module tree, 24 generators deep, is done once: it was 100 us of every training step)
+            plist = self.__dict__.get("_plist")
+            if plist is None:
+                plist = self.__dict__["_plist"] = tuple(self.parameters())
+            return list(plist)
         import torch.nn.functional as F
         KW, W, D, cin = SUPPORTED["W"], self.W, self.D, self.input_ch
         ref = self.pts_linears[0].weight

@@ -110,6 +110,15 @@ class FlatAdam(torch.optim.Adam):
                 st['exp_avg'], st['exp_avg_sq'] = fm.view(p.shape), fv.view(p.shape)
                 st['step'] = torch.as_tensor(float(st['step']), dtype=torch.float32)
 
+    @staticmethod
+    def _uniform_grads(ps, base, offs):
+        """Every gradient sits at its parameter's offset behind `base` (24 pointer compares: the cheap confirmation of what
+        the first / last check suggests, without contiguous_runs' storage queries)."""
+        for k, p in enumerate(ps):
+            if p.grad.data_ptr() != base + 4 * offs[k]:
+                return False
+        return True
+
     def _guard_ptrs(self):
         """The (up to two) status words a launch is guarded by, resolved NOW: a network's packed buffer -- and with it
         the word -- is re-allocated when the network moves or changes precision, a cached view would watch dead memory."""
@@ -166,8 +175,20 @@ class FlatAdam(torch.optim.Adam):
                 continue
             if group.get('weight_decay', 0) or group.get('amsgrad') or group.get('maximize'):
                 raise RuntimeError("FlatAdam implements the reference's Adam: no weight decay / amsgrad / maximize")
-            view = flat_view_of([p.data for p in ps])
-            if view is None or view.data_ptr() != fl['param'].data_ptr():
+            offs = fl.get('offs')
+            if offs is None:
+                offs = [0]
+                for n in fl['sizes']:
+                    offs.append(offs[-1] + n)
+                fl['offs'] = offs
+            # the parameters must still be the slices of this optimizer's buffer.  First and last slice are checked on every
+            # step (two pointer reads); the full walk over all of them when those do not line up
+            base = fl['param'].data_ptr()
+            in_place = ps[0].data.data_ptr() == base and ps[-1].data.data_ptr() == base + 4 * offs[-2]
+            if not in_place:
+                view = flat_view_of([p.data for p in ps])
+                in_place = view is not None and view.data_ptr() == base
+            if not in_place:
                 # not this optimizer's buffer any more: .to(device) after construction, or a second FlatAdam built over
                 # the same parameters re-homed them into ITS buffer -- stepping fl['param'] would update dead memory
                 raise RuntimeError("FlatAdam: the parameters no longer live in this optimizer's flat buffer (they were "
@@ -176,12 +197,27 @@ class FlatAdam(torch.optim.Adam):
             # parameters without a gradient are skipped, as torch.optim.Adam does; the others are stepped run by
             # run: a run = consecutive parameters whose gradients are consecutive slices of one buffer and whose
             # step counts agree (one network's backward = one run)
-            offs = [0]
-            for n in fl['sizes']:
-                offs.append(offs[-1] + n)
             live = [k for k, p in enumerate(ps) if p.grad is not None]
             b1, b2 = group['betas']
             k = 0
+            # the common case in one look: every parameter has a gradient, the gradients are the slices of ONE buffer in
+            # parameter order (functional.MlpFn.backward's layout) and the step counts agree -> one launch, no walk
+            if len(live) == len(ps) and len(ps) > 1:
+                g0, g1 = ps[0].grad, ps[-1].grad
+                s0, s1 = self.state[ps[0]]['step'], self.state[ps[-1]]['step']
+                if (g0.dtype == torch.float32 and g1.data_ptr() == g0.data_ptr() + 4 * offs[-2] and
+                        g0.untyped_storage().data_ptr() == g1.untyped_storage().data_ptr() and
+                        g0.is_contiguous() and g1.is_contiguous() and float(s0) == float(s1) and
+                        self._uniform_grads(ps, g0.data_ptr(), offs)):
+                    steps = [self.state[p]['step'] for p in ps]
+                    torch._foreach_add_(steps, 1.0)
+                    L.check(L.lib().plnerf_adam_step(
+                        L.dptr(fl['param']), L.dptr(g0.as_strided((offs[-1],), (1,))), L.dptr(fl['m']), L.dptr(fl['v']),
+                        offs[-1], float(group['lr']), float(b1), float(b2), float(group['eps']),
+                        int(float(steps[0])), float(grad_scale), float(clip_value), guard_a, guard_b,
+                        self._withheld_ptr(fl['param'].device), L.stream()), "plnerf_adam_step")
+                    launches += 1
+                    k = len(live)
             while k < len(live):
                 e = k + 1
                 while e < len(live) and live[e] == live[e - 1] + 1 and \
