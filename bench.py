@@ -91,6 +91,11 @@ def parse(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--cpu-no-grid", action="store_true", help="cpu_baseline: only the workload's own cell")
     ap.add_argument("--views", type=int, default=4, help="synthetic views resident on the device")
+    ap.add_argument("--pipeline", type=int, default=2, choices=[0, 1, 2],
+                    help="train.TrainStep's schedule of the step's two independent chains: 0 = one stream, the reference's "
+                         "order; 1 = the coarse network's loss / backward / Adam on a second HIP stream next to the fine "
+                         "pass; 2 (default) = additionally the next step's coarse pass next to this step's fine backward. "
+                         "Every step computes the same values in all three (tests/test_gpu_step.py)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gradient all-reduce even with one rank (path check)")
     ap.add_argument("--stub-cpu", action="store_true",
@@ -249,7 +254,7 @@ def build_step(P, a, precision, scene, dev, rank, world, force_dist):
     finally:
         sys.stdout = _stdout
     nets = [kw["network_fn"], kw["network_fine"]]
-    ts = P.TrainStep(args, kw, opt, opt_c, distributed=world > 1, seed=0)
+    ts = P.TrainStep(args, kw, opt, opt_c, distributed=world > 1, seed=0, pipeline=a.pipeline)
     if force_dist and world == 1:
         ts.bucket = dp.GradientBucket(nets)
     torch.manual_seed(1000 + rank)         # torch.randn density noise (llff): decorrelate the ranks
@@ -487,6 +492,7 @@ def main(argv=None):
                                    f"N_importance={a.n_importance}, mode=linear/midpoint; full step = device-side pixel "
                                    f"choice + ray generation + render + backward + per-network grad all-reduce + Adam",
                        "global_rays": R * world, "precision": a.precision, "parallelism": f"dp{world}",
+                       "pipeline": a.pipeline if a.workload != "depth_128_64" else 0,
                        "rccl_world_size": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
                        "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
                        "self_launched": bool(os.environ.get("PLNERF_BENCH_SELF_LAUNCHED")),

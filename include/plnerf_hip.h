@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PLNERF_VERSION 300 /* major*10000 + minor*100 + patch */
+#define PLNERF_VERSION 400 /* major*10000 + minor*100 + patch */
 
 /* error codes */
 #define PLNERF_OK 0
@@ -237,9 +237,15 @@ int plnerf_coarse_samples(const float* rays_o, const float* rays_d, const float*
 /* img2mse(rgb, target) + img2mse(rgb0, target) (run_plnerf.py:1287-1296; run_nerf_helpers.py:17):
  * loss3 [4] = {total, fine, coarse, psnr = -10 log10(fine)}; g_rgb, g_rgb0 [R,3] = d total / d rgb,
  * d total / d rgb0.
- * rgb0 may be NULL (single-pass configuration).  Deterministic (one workgroup, fp64 partial sums). */
+ * rgb0 may be NULL (single-pass configuration).  coarse_loss (NULL, or the loss3 of an earlier call on the coarse
+ * image alone; needs rgb0 == NULL): its [1] is taken as the coarse term -- a caller that runs the coarse network's
+ * loss and backward ahead of the fine pass (the two sums of :1296 are independent) still gets the reference's total.
+ * workspace: PLNERF_IMAGE_LOSS_WORKSPACE_BYTES, zeroed by the caller ONCE (each launch leaves it zeroed; one per
+ * stream that launches concurrently).  Deterministic (fp64 partial sums added in workgroup order). */
+#define PLNERF_IMAGE_LOSS_WORKSPACE_BYTES 4096
 int plnerf_image_loss(const float* rgb, const float* rgb0, const float* target, int R, float* loss3,
-                      float* g_rgb, float* g_rgb0, plnerf_stream_t stream);
+                      float* g_rgb, float* g_rgb0, const float* coarse_loss, void* workspace,
+                      plnerf_stream_t stream);
 
 /* The depth-supervised loop's loss (depth_supervised_exps/run_nerf_sample_based_depth.py:1126-1150):
  *   total = img2mse(rgb, target) + space_carving_weight * compute_space_carving_loss(pred_hyp, target_h)
@@ -330,10 +336,13 @@ int plnerf_mlp_fwd(const void* packed, int precision, const float* pts, const fl
  * buffer of the matching forward call and a workspace of
  * plnerf_mlp_bwd_workspace_bytes().  Inputs (pts / viewdirs) receive no gradient, as on
  * the reference path (they do not depend on parameters; z_samples is detached,
- * run_plnerf.py:728). */
+ * run_plnerf.py:728).  status_out (may be NULL): one float, set to 1 if the network's range status word
+ * (plnerf_mlp_status_offset) is non-zero when the gradients are complete, else 0 -- a data-parallel caller puts it
+ * behind the gradients in the buffer it all-reduces (SUM), so "some rank's forward left the half range" reaches
+ * every rank with the gradient itself and can guard plnerf_adam_step there. */
 int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, int input_ch,
                    int input_ch_views, int n_rows, const void* saved, int saved_layout, void* workspace,
-                   float* const* grads, plnerf_stream_t stream);
+                   float* const* grads, float* status_out, plnerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused Adam step over a flat parameter buffer (torch.optim.Adam semantics as used at

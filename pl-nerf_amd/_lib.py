@@ -19,6 +19,7 @@ PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3, "f16": 4}
 GUARDED_PRECISIONS = ("f16x3", "f16", "bf16x3", "bf16")      # modes whose kernels can set a bit of the range status word
 N_PARAM_TENSORS = 24
 DEPTH_LOSS_WORKSPACE_BYTES = 4096      # PLNERF_DEPTH_LOSS_WORKSPACE_BYTES
+IMAGE_LOSS_WORKSPACE_BYTES = 4096      # PLNERF_IMAGE_LOSS_WORKSPACE_BYTES
 # plnerf_mlp_fwd's `fwd_kernel` argument (PLNERF_FWD_KERNEL_*).  The library has no setting of its own; this BINDING
 # takes its default from the environment (PLNERF_FWD_KERNEL=rr | pp: the test suite's and tools/' passes over both
 # forward kernels) and hands it to every call.
@@ -52,7 +53,7 @@ SIGNATURES = {
                            [ctypes.c_uint64, ctypes.c_uint32, c_i, c_i, ctypes.c_float, ctypes.c_float] + [c_f] * 7 +
                            [c_s]),
     "plnerf_coarse_samples": (c_i, [c_f] * 6 + [ctypes.c_uint64, ctypes.c_uint32] + [c_i] * 5 + [c_f] * 2 + [c_s]),
-    "plnerf_image_loss": (c_i, [c_f] * 3 + [c_i] + [c_f] * 3 + [c_s]),
+    "plnerf_image_loss": (c_i, [c_f] * 3 + [c_i] + [c_f] * 5 + [c_s]),
     "plnerf_depth_loss": (c_i, [c_f] * 6 + [c_i] * 4 + [ctypes.c_float] * 2 + [c_f] * 5 + [c_s]),
     "plnerf_embed_rows": (c_i, [c_f] * 3 + [c_i] * 5 + [ctypes.c_float, ctypes.POINTER(ctypes.c_float), ctypes.c_float,
                                 c_f, c_s]),
@@ -61,7 +62,7 @@ SIGNATURES = {
     "plnerf_mlp_saved_bytes": (ctypes.c_size_t, [c_i, c_i]),
     "plnerf_mlp_bwd_workspace_bytes": (ctypes.c_size_t, [c_i, c_i]),
     "plnerf_mlp_fwd": (c_i, [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_i, c_s]),
-    "plnerf_mlp_bwd": (c_i, [c_f, c_i, c_f, c_i, c_i, c_i, c_f, c_i, c_f, ctypes.POINTER(ctypes.c_void_p), c_s]),
+    "plnerf_mlp_bwd": (c_i, [c_f, c_i, c_f, c_i, c_i, c_i, c_f, c_i, c_f, ctypes.POINTER(ctypes.c_void_p), c_f, c_s]),
     "plnerf_mlp_saved_layout": (c_i, [c_i, c_i, c_i]),
     "plnerf_adam_step": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_int64] + [ctypes.c_float] * 4 + [c_i, ctypes.c_float, ctypes.c_float,
                                 c_f, c_f, c_f, c_s]),

@@ -129,7 +129,7 @@ extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pt
 
 extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, int input_ch,
                               int input_ch_views, int n_rows, const void* saved, int saved_layout, void* workspace,
-                              float* const* grads, plnerf_stream_t stream) {
+                              float* const* grads, float* status_out, plnerf_stream_t stream) {
     if (saved_layout != lay::SV_LAYOUT_ROWS && saved_layout != lay::SV_LAYOUT_TILED) return PLNERF_EINVAL;
     if (saved_layout == lay::SV_LAYOUT_TILED && !ns_of(precision)) return PLNERF_EINVAL;
     if (!known(precision)) return PLNERF_ENOSYS;
@@ -143,7 +143,7 @@ extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_
         const int rc = impl::f32_dgrad(packed, g_raw, n_rows, (const float*)saved, dz, st);
         if (rc) return rc;
         return impl::wgrad(g_raw, n_rows, saved, dz, nullptr, dz + (size_t)lay::DZ_PER_ROW * (size_t)n_rows, grads,
-                           input_ch, input_ch_views, false, lay::SV_LAYOUT_ROWS, st);
+                           input_ch, input_ch_views, false, lay::SV_LAYOUT_ROWS, nullptr, status_out, st);
     }
     // 16-bit modes: [dz half planes][max |g_raw|][partials]
     unsigned char* ws = (unsigned char*)workspace;
@@ -153,5 +153,6 @@ extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_
     if (rc) return rc;
     rc = impl::bf16_dgrad(packed, ns_of(precision), g_raw, n_rows, saved, ws, gmax, st);
     if (rc) return rc;
-    return impl::wgrad(g_raw, n_rows, saved, ws, gmax, partials, grads, input_ch, input_ch_views, true, saved_layout, st);
+    return impl::wgrad(g_raw, n_rows, saved, ws, gmax, partials, grads, input_ch, input_ch_views, true, saved_layout,
+                       status_word(const_cast<void*>(packed), precision), status_out, st);
 }

@@ -971,12 +971,17 @@ struct ReduceArgs {
     const float* head_part;
     int splits, splits_thin, n_head;   // row ranges of the 256-wide jobs / of the three thin jobs
     const unsigned* gmax;   // 16-bit modes: the dz planes were scaled by 2^(DZH_TARGET_EXP - exponent(max |g_raw|))
+    const unsigned* status; // the network's range status word (16-bit modes), or nullptr
+    float* status_out;      // nullptr, or where this launch leaves (float)(*status != 0): the tail of the caller's flat gradient
     GradPtrs G;
 };
 
 __global__ void wgrad_reduce_kernel(ReduceArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= PART_PER_SPLIT + HEAD_OUT * 64) return;
+    // the range status travels with the gradient it qualifies (dp.GradientBucket sums this element over the ranks; a
+    // non-zero sum withholds the step everywhere)
+    if (idx == 0 && a.status_out) *a.status_out = (a.status && *a.status) ? 1.0f : 0.0f;
     if (idx >= PART_PER_SPLIT) {
         // head partials: one wavefront per output element (up to 512 partials each; a single thread walking
         // them was the longest thing in this kernel)
@@ -1165,19 +1170,26 @@ int absmax(const float* x, size_t n, unsigned* out, hipStream_t st) {
 }
 
 int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, const unsigned* gmax, float* part,
-          float* const* grads, int xyz_ch, int dir_ch, bool h16, int saved_layout, hipStream_t st) {
+          float* const* grads, int xyz_ch, int dir_ch, bool h16, int saved_layout, const unsigned* status,
+          float* status_out, hipStream_t st) {
     const size_t N = (size_t)n_rows;
     const size_t NS_ = h16 ? sv_rows(N) : N;       // row stride of the saved half state (padded, mlp_layout.h)
     const int tiled = h16 && saved_layout == SV_LAYOUT_TILED;
     const size_t es = h16 ? sizeof(_Float16) : sizeof(float);        // plane element size
     float* head_part = part + (size_t)MAX_SPLITS * PART_PER_SPLIT;
-    const int splits = splits_for(n_rows, h16);
+    int splits = splits_for(n_rows, h16);
     int rps = (n_rows + splits - 1) / splits;
     rps = h16 ? (rps + 63) & ~63 : (rps + 15) & ~15;      // half kernels: whole 64-row stages (two tiles of the tiled layout)
+    // Rounding the range length up can leave the LAST ranges without a row (131,072 rows over 85 ranges of 1,600: ranges
+    // 82..84 start past the end).  A workgroup without rows writes no partial, and the reduction would add whatever the
+    // workspace held there (round 4: found by comparing two schedules of the same step bit for bit) -- so only ranges
+    // that hold a row are launched and summed.
+    splits = (n_rows + rps - 1) / rps;
     int splits_thin = splits;
     if (h16) { splits_thin = (n_rows + 1023) / 1024; splits_thin = splits_thin < 1 ? 1 : (splits_thin > 85 ? 85 : splits_thin); }
     int rps_thin = (n_rows + splits_thin - 1) / splits_thin;
     rps_thin = h16 ? (rps_thin + 63) & ~63 : (rps_thin + 15) & ~15;      // (half: whole tiles of the tiled dz planes)
+    splits_thin = (n_rows + rps_thin - 1) / rps_thin;
     const unsigned char* sv = (const unsigned char*)saved;
     const unsigned char* dz = (const unsigned char*)dzv;
     auto splane = [&](int p) { return (const void*)(sv + (size_t)p * W * NS_ * es); };
@@ -1266,6 +1278,7 @@ int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, co
         ReduceArgs a{};
         a.part = part; a.head_part = head_part; a.splits = splits; a.splits_thin = splits_thin; a.n_head = n_head;
         a.gmax = h16 ? gmax : nullptr;
+        a.status = status; a.status_out = status_out;
         a.G.xyz_ch = xyz_ch; a.G.dir_ch = dir_ch;
         for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i) {
             if (!grads[i]) return PLNERF_EINVAL;

@@ -17,8 +17,11 @@ int f32_fwd(const void* packed, const float* pts, const float* viewdirs, const f
 int f32_dgrad(const void* packed, const float* g_raw, int n_rows, const float* saved, float* dz, hipStream_t st);
 // Weight gradients.  h16 = false: fp32 planes on the fp32 MFMA (fp32 mode); h16 = true: half planes on
 // v_mfma_f32_32x32x16_f16, partial sums divided by the dz scale derived from *gmax (16-bit modes).
+// status / status_out: the network's range status word (nullptr in fp32 mode) and where the reduction leaves
+// (float)(word != 0) for the caller's gradient exchange (nullptr = nowhere)
 int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dz, const unsigned* gmax, float* partials,
-          float* const* grads, int xyz_ch, int dir_ch, bool h16, int saved_layout, hipStream_t st);
+          float* const* grads, int xyz_ch, int dir_ch, bool h16, int saved_layout, const unsigned* status,
+          float* status_out, hipStream_t st);
 // max |x| over n floats as fp32 bits (non-negative floats order like unsigned integers) -> *out
 int absmax(const float* x, size_t n, unsigned* out, hipStream_t st);
 // bytes of the half dz planes of n_rows rows, rounded up to 16

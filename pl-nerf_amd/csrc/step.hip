@@ -214,17 +214,26 @@ __global__ __launch_bounds__(256) void coarse_samples_kernel(const CoarseArgs a)
 }
 
 // ---- loss = mean((rgb - t)^2) + mean((rgb0 - t)^2), and d loss / d rgb, d loss / d rgb0 (for an upstream gradient of
-// one; the caller scales).  One workgroup: n = 3 R elements (12,288 at N_rand 4096), fp64 partial sums in a fixed
-// order -> deterministic.
-__global__ __launch_bounds__(1024) void image_loss_kernel(const float* __restrict__ rgb, const float* __restrict__ rgb0,
-                                                           const float* __restrict__ target, const int n,
-                                                           float* __restrict__ loss3 /* [4] */, float* __restrict__ g_rgb,
-                                                           float* __restrict__ g_rgb0) {
-    __shared__ double part[2][16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// one; the caller scales).  n = 3 R elements (12,288 at N_rand 4096) over IL_BLOCKS workgroups: fp64 partial sums per
+// workgroup, the last one to finish (ticket counter in the caller's zeroed workspace, which it resets) adds them in
+// workgroup order -> deterministic.  (One workgroup walking the batch measured 14 us of serialised load latency.)
+// `coarse_in`: the loss4 of an earlier launch on the coarse image alone (its [1] = mean((rgb0 - t)^2)): the two-stream
+// step (functional.CoarseChain) computes the coarse term first, on its own stream; total = fine + that, as one launch
+// over both images computes it.
+constexpr int IL_BLOCKS = 16, IL_THREADS = 256;
+__global__ __launch_bounds__(IL_THREADS) void image_loss_kernel(const float* __restrict__ rgb, const float* __restrict__ rgb0,
+                                                                 const float* __restrict__ target, const int n,
+                                                                 float* __restrict__ loss3 /* [4] */, float* __restrict__ g_rgb,
+                                                                 float* __restrict__ g_rgb0, const float* __restrict__ coarse_in,
+                                                                 double* __restrict__ partial, unsigned* __restrict__ ticket) {
+    __shared__ double part[2][IL_THREADS / 64];
+    __shared__ unsigned last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
     const float scale = 2.0f / (float)n;
+    const int per = (n + IL_BLOCKS - 1) / IL_BLOCKS;
+    const int lo = b * per, hi = min(n, lo + per);
     double s1 = 0.0, s0 = 0.0;
-    for (int i = tid; i < n; i += 1024) {
+    for (int i = lo + tid; i < hi; i += IL_THREADS) {
         const float t = target[i];
         const float d1 = rgb[i] - t;
         s1 += (double)(d1 * d1);
@@ -241,13 +250,27 @@ __global__ __launch_bounds__(1024) void image_loss_kernel(const float* __restric
     __syncthreads();
     if (tid == 0) {
         double a1 = 0.0, a0 = 0.0;
-        for (int w = 0; w < 16; ++w) { a1 += part[0][w]; a0 += part[1][w]; }
-        const float fine = (float)(a1 / (double)n), coarse = (float)(a0 / (double)n);
-        loss3[0] = fine + coarse;
-        loss3[1] = fine;
-        loss3[2] = coarse;
-        loss3[3] = -10.0f * log10f(fine);      // mse2psnr(img_loss) (run_nerf_helpers.py:18, run_plnerf.py:1290)
+        for (int w = 0; w < IL_THREADS / 64; ++w) { a1 += part[0][w]; a0 += part[1][w]; }
+        partial[2 * b + 0] = a1;
+        partial[2 * b + 1] = a0;
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == IL_BLOCKS - 1 ? 1u : 0u;
     }
+    __syncthreads();
+    if (!last || tid != 0) return;
+    __threadfence();
+    double a1 = 0.0, a0 = 0.0;
+    for (int w = 0; w < IL_BLOCKS; ++w) {
+        a1 += __builtin_nontemporal_load(partial + 2 * w + 0);
+        a0 += __builtin_nontemporal_load(partial + 2 * w + 1);
+    }
+    *ticket = 0u;      // left as the next launch expects it
+    const float fine = (float)(a1 / (double)n);
+    const float coarse = coarse_in ? coarse_in[1] : (float)(a0 / (double)n);
+    loss3[0] = fine + coarse;
+    loss3[1] = fine;
+    loss3[2] = coarse;
+    loss3[3] = -10.0f * log10f(fine);      // mse2psnr(img_loss) (run_nerf_helpers.py:18, run_plnerf.py:1290)
 }
 
 // ---- depth-supervised loss: DL_BLOCKS workgroups over contiguous slices, fp64 partial sums per workgroup in a fixed
@@ -492,10 +515,14 @@ extern "C" int plnerf_coarse_samples(const float* rays_o, const float* rays_d, c
 }
 
 extern "C" int plnerf_image_loss(const float* rgb, const float* rgb0, const float* target, int R, float* loss3,
-                                 float* g_rgb, float* g_rgb0, plnerf_stream_t stream) {
-    if (R < 1 || !rgb || !target || !loss3 || !g_rgb || (rgb0 && !g_rgb0)) return PLNERF_EINVAL;
-    hipLaunchKernelGGL(image_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rgb, rgb0, target, 3 * R, loss3,
-                       g_rgb, g_rgb0);
+                                 float* g_rgb, float* g_rgb0, const float* coarse_loss, void* workspace,
+                                 plnerf_stream_t stream) {
+    static_assert(IL_BLOCKS * 2 * sizeof(double) + sizeof(unsigned) <= PLNERF_IMAGE_LOSS_WORKSPACE_BYTES, "workspace");
+    if (R < 1 || !rgb || !target || !loss3 || !g_rgb || (rgb0 && !g_rgb0) || (rgb0 && coarse_loss) || !workspace)
+        return PLNERF_EINVAL;
+    hipLaunchKernelGGL(image_loss_kernel, dim3(IL_BLOCKS), dim3(IL_THREADS), 0, (hipStream_t)stream, rgb, rgb0, target,
+                       3 * R, loss3, g_rgb, g_rgb0, coarse_loss, (double*)workspace,
+                       (unsigned*)((double*)workspace + IL_BLOCKS * 2));
     PLNERF_CHECK_LAUNCH();
     return PLNERF_OK;
 }

@@ -405,12 +405,15 @@ class DepthTrainStep:
 
     def check_range(self):
         """As train.TrainStep.check_range: reconcile withheld steps, raise on a set range status word."""
-        if hasattr(self.optimizer, "withheld_steps"):
-            self.optimizer.withheld_steps()
+        withheld = self.optimizer.withheld_steps() if hasattr(self.optimizer, "withheld_steps") else 0
         for net in self.nets:
             if getattr(net, "precision", None) in L.GUARDED_PRECISIONS and net.is_supported() and \
                     next(net.parameters()).is_cuda:
                 net.check_range()
+        if withheld and self.bucket is not None:
+            raise FloatingPointError(
+                f"plnerf_amd: {withheld} optimizer step(s) were withheld because another rank's forward left the "
+                "IEEE-half range (that rank's check_range() says which network)")
 
     def __call__(self, ray_batch, target_s, target_h, space_carving_mask=None, cached_u=None, pytest=False):
         a = self.args
@@ -445,10 +448,19 @@ class DepthTrainStep:
             if rgb0 is not None:
                 loss = loss + torch.mean((rgb0 - target_s) ** 2)
             loss.backward()
+        flat_adam = isinstance(self.optimizer, FlatAdam) and all(fl is not None for fl in self.optimizer._flat)
+        scale, tails = 1.0, None
         if self.bucket is not None:
-            self.bucket.allreduce_mean()
-        if isinstance(self.optimizer, FlatAdam):
-            self.optimizer.step(clip_value=0.1)      # clip_grad_value_(0.1) folded into the step kernel (:1156)
+            # one wait for the two collectives; the 1 / world factor and the guard (the ranks' summed range status, which
+            # travelled behind the gradients) go into the step kernel (dp.GradientBucket)
+            scale = self.bucket.finish(defer_scale=flat_adam)
+            tails = self.bucket.tails()
+            tails = tails if len(tails) == len(self.nets) else None
+        if flat_adam:
+            # clip_grad_value_(0.1) folded into the step kernel (:1156), applied to the averaged gradient
+            self.optimizer.step(clip_value=0.1, grad_scale=scale, guards=tails)
+        elif isinstance(self.optimizer, FlatAdam):
+            self.optimizer.step(clip_value=0.1)
         else:
             torch.nn.utils.clip_grad_value_(self.grad_vars, 0.1)
             self.optimizer.step()

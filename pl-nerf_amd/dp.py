@@ -53,11 +53,23 @@ class GradientBucket:
     autograd keeps those views as the `.grad` tensors.  So a network's whole gradient is a single flat tensor that can
     be all-reduced IN PLACE -- no gather into a bucket, no scatter back.  A post-accumulate hook on every parameter
     counts arrivals; when a network is complete its all-reduce is enqueued at once (async: RCCL's stream waits for
-    the gradient, the autograd stream goes on).  The fine network's backward finishes first, so its 2.4 MB travel
-    over xGMI while the coarse network's backward still computes; `allreduce_mean()` -- called where the reference
-    loop would step the optimizers -- waits for both and applies the 1/world factor.
+    the stream the backward runs on, which goes on).  `finish(modules)` -- called where the reference loop would step
+    that network's optimizer -- makes the current stream wait for those collectives.  What is left exposed after a
+    network's last backward kernel is that ONE wait:
 
-    Gradients in any other layout (another module, a CPU test) fall back to one gathered bucket per call."""
+      * the 1 / world factor is not applied here when the caller can take it (`defer_scale`: optim.FlatAdam multiplies
+        inside its step kernel) -- `.grad` then holds the SUM over ranks until the optimizer has stepped;
+      * the networks' range status words (section 5 of DESIGN.md: a rank whose forward clamped has contributed a wrong
+        gradient to the sum, so EVERY rank must withhold the step) travel as a tail element of the same buffer
+        (functional.MlpFn.backward appends it; the weight-gradient reduction kernel writes it): after the SUM a non-zero
+        tail means "some rank's forward left the half range" on every rank alike.  `tails()` hands those words to the
+        optimizer as its guards -- no separate collective, no write-back launch.
+
+    With train.TrainStep's two streams the coarse network's exchange and the fine network's are finished
+    independently, each on its chain's stream.  Gradients in any other layout (another module, a CPU test) fall back
+    to one gathered bucket per call."""
+
+    TAIL = 4      # floats appended to a network's flat gradient by functional.MlpFn.backward ([0] = range status)
 
     def __init__(self, modules, group=None, overlap=True):
         self.modules = list(modules)
@@ -65,9 +77,10 @@ class GradientBucket:
         self.params = [p for m in self.modules for p in m.parameters()]
         self.numel = sum(p.numel() for p in self.params)
         self._owner = {}
+        self._n_params = [sum(1 for _ in m.parameters()) for m in self.modules]
         self._arrived = [0] * len(self.modules)
-        self._works = []         # (work handle, flat tensor) of the collectives in flight
-        self._reduced = [False] * len(self.modules)
+        self._works = {}         # module index -> (work handle, reduced tensor, tail view or None)
+        self._tails = {}         # module index -> tail view of the last finished exchange
         self._hooks = []
         self.flat = None         # fallback bucket, allocated on first use
         if overlap and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -80,40 +93,38 @@ class GradientBucket:
     def _on_grad(self, p):
         mi = self._owner[p]
         self._arrived[mi] += 1
-        if self._arrived[mi] == sum(1 for _ in self.modules[mi].parameters()):
+        if self._arrived[mi] == self._n_params[mi]:
             self._arrived[mi] = 0
             self._launch(mi)
 
     def _launch(self, mi):
         from .optim import flat_view_of
-        flat = flat_view_of([p.grad for p in self.modules[mi].parameters()])
+        m = self.modules[mi]
+        flat = flat_view_of([p.grad for p in m.parameters()])
         if flat is None:
             return                                        # not one buffer: the fallback handles this module
+        tail = None
+        full = getattr(m, "_grad_flat", None)             # (functional.MlpFn.backward: the buffer with its status tail)
+        if full is not None and full.data_ptr() == flat.data_ptr() and full.numel() == flat.numel() + self.TAIL:
+            flat, tail = full, full[-self.TAIL:-self.TAIL + 1]
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._works.append((work, flat))
-        self._reduced[mi] = True
-
-    def _sync_status(self, group, world):
-        """The range guard is per network AND per rank, the gradient is not: a rank whose forward clamped has
-        contributed a wrong gradient to the average, so EVERY rank must withhold this step -- and every rank must raise
-        at the next check_range(), not just one while the others block in the next collective.  One 8-byte MAX
-        all-reduce of the ranks' status words (bit masks of 1, 2, 4: MAX of the OR-able words keeps "non-zero" and is
-        available on every backend), written back into each network's word before the Adam launches read it."""
-        if world <= 1:
-            return
-        words = [m.status_word() for m in self.modules
-                 if hasattr(m, "status_word") and getattr(m, "precision", None) in GUARDED_PRECISIONS
-                 and next(m.parameters()).is_cuda]
-        if not words:
-            return
-        both = torch.cat(words)
-        dist.all_reduce(both, op=dist.ReduceOp.MAX, group=group)
-        for w, v in zip(words, both.split(1)):
-            w.copy_(v)
+        self._works[mi] = (work, flat, tail)
 
     def pending(self):
         """Collectives enqueued by the hooks and not yet waited for (for tests / diagnostics)."""
         return len(self._works)
+
+    def tails(self, modules=None):
+        """The reduced range-status words (1-element float tensors, non-zero = some rank's forward of that network left
+        the half range) of the exchanges `finish` completed last, for the given modules (default: all)."""
+        idx = range(len(self.modules)) if modules is None else [self._index(m) for m in modules]
+        return [self._tails[mi] for mi in idx if self._tails.get(mi) is not None]
+
+    def _index(self, module):
+        for mi, m in enumerate(self.modules):
+            if m is module:
+                return mi
+        raise ValueError("GradientBucket: not one of this bucket's modules")
 
     # -- fallback: one gathered bucket ---------------------------------------------------------------------------
     def _fallback(self, modules, world):
@@ -140,38 +151,54 @@ class GradientBucket:
                 p.grad = torch.empty_like(p)
             p.grad.copy_(v)
 
-    def allreduce_mean(self, group=None, force=False):
-        """Average every gradient over the ranks (in place).  Returns the number of collectives used."""
+    def finish(self, modules=None, defer_scale=False, group=None, force=False):
+        """Complete the exchange of `modules` (default: all of the bucket's): the current stream waits for their
+        collectives.  Returns the factor the caller still owes the gradients: 1 / world if `defer_scale` and every one
+        of them was reduced in place (`.grad` then holds the SUM), else 1.0 (scaled here: `.grad` holds the mean)."""
         group = group if group is not None else self.group
         world = dist.get_world_size(group) if dist.is_initialized() else 1
+        idx = list(range(len(self.modules))) if modules is None else [self._index(m) for m in modules]
+        self.collectives = 0
         if world == 1 and not (force and dist.is_initialized()):
-            return 0
-        if not self._hooks:                               # single rank with force=True, or overlap disabled
-            for mi in range(len(self.modules)):
+            return 1.0
+        for mi in idx:
+            if mi not in self._works and not self._hooks:     # single rank with force=True, or overlap disabled
                 self._launch(mi)
-        n = len(self._works)
-        # the EXPOSED part of the exchange, as the launch stream sees it: from here (the backward's last kernel is
-        # enqueued) until both collectives have been waited for and scaled.  Events only while bench.py has a timer
-        # installed; they are recorded on the current stream, which work.wait() makes wait for RCCL's stream.
+        mine = [mi for mi in idx if mi in self._works]
+        rest = [mi for mi in idx if mi not in self._works]
+        deferred = bool(defer_scale and not rest)
+        # the EXPOSED part of the exchange, as the stream sees it: from here (the backward's last kernel is enqueued)
+        # until the collectives have been waited for.  Events only while bench.py has a timer installed; they are
+        # recorded on the current stream, which work.wait() makes wait for RCCL's stream.
         from . import functional as Fn
         ev = None
-        if Fn.KERNEL_TIMER is not None and self._works and self._works[0][1].is_cuda:
-            ev = Fn.KERNEL_TIMER.bracket("allreduce_exposed")
+        if Fn.KERNEL_TIMER is not None and mine and self._works[mine[0]][1].is_cuda:
+            last = (len(self.modules) - 1) in idx
+            ev = Fn.KERNEL_TIMER.bracket("allreduce_exposed" if last else "allreduce_exposed_coarse")
             ev[0].record()
-        for work, flat in self._works:
+        for mi in mine:
+            work, flat, tail = self._works.pop(mi)
             work.wait()
-            flat.mul_(1.0 / world)
-        self._sync_status(group, world)
+            self._tails[mi] = tail
+            if not deferred:
+                (flat if tail is None else flat[:-self.TAIL]).mul_(1.0 / world)
+            self.collectives += 1
         if ev is not None:
             ev[1].record()
-        self._works = []
-        self._arrived = [0] * len(self.modules)           # (a module with parameters that never receive a gradient never completes)
-        rest = [m for mi, m in enumerate(self.modules) if not self._reduced[mi]]
-        self._reduced = [False] * len(self.modules)
+        for mi in idx:
+            self._arrived[mi] = 0           # (a module with parameters that never receive a gradient never completes)
         if rest:
-            self._fallback(rest, world)
-            n += 1
-        return n
+            for mi in rest:
+                self._tails[mi] = None
+            self._fallback([self.modules[mi] for mi in rest], world)
+            self.collectives += 1
+        return 1.0 / world if deferred else 1.0
+
+    def allreduce_mean(self, group=None, force=False):
+        """Average every gradient over the ranks (in place; `.grad` holds the mean afterwards).  Returns the number of
+        collectives used."""
+        self.finish(None, defer_scale=False, group=group, force=force)
+        return self.collectives
 
 
 def broadcast_optimizer_state(optimizers, src=0, group=None):

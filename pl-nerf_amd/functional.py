@@ -3,7 +3,7 @@
 PyTorch is plumbing here (device memory, streams, the autograd tape); every operation of
 the path itself runs in libplnerf_hip.so.
 """
-import contextlib
+import ctypes
 
 import numpy as np
 import torch
@@ -51,37 +51,64 @@ class KernelTimer:
 KERNEL_TIMER = None
 
 
-class SideBackward:
-    """The coarse network's backward chain (plnerf_quad_bwd of the coarse maps, then plnerf_mlp_bwd) on a SECOND HIP
-    stream, next to the fine network's on the launch stream.  The two graphs are independent once the image-loss
-    gradients exist (z_samples is detached, run_plnerf.py:728).  Autograd runs a Function's backward on the stream of
-    its forward, so the switch happens inside the two backward methods: the side stream waits for `after` (an event the
-    train step records once d loss / d rgb0 is enqueued, BEFORE the fine chain's kernels), and the launch stream waits
-    for the side stream right after the coarse plnerf_mlp_bwd is enqueued -- i.e. before anything (gradient hooks, the
-    all-reduce, Adam) can touch the coarse gradients.  train.TrainStep arms it per step; None = everything on one
-    stream."""
+class CoarseChain:
+    """Two HIP streams for one optimisation step (train.TrainStep arms one per step; None = everything on one stream).
 
-    def __init__(self, net):
-        self.net = net
-        self.stream = torch.cuda.Stream(device=next(net.parameters()).device)
-        self.after = None        # armed while not None
+    The reference's step has two independent sub-graphs once the fine pass's sample positions exist: z_samples is detached
+    (run_plnerf.py:728) and the loss is a sum of two image terms (:1287-1296), so the COARSE network's loss, backward,
+    gradient exchange and Adam step need nothing from the fine network -- and the fine chain needs only the positions.
+    render_rays therefore runs the coarse pass under `coarse()` (the chain's own stream), hands the fine pass its inputs
+    through `coarse_done` (which also launches the rest of the coarse chain: image loss, backward, Adam, on the same
+    stream) and runs the fine pass under `fine()` (the launch stream, which waits for the positions only).  The coarse
+    backward is HBM-bound and the fine forward MFMA-bound, so the two overlap on the chip; and because nothing on the
+    coarse stream waits for the launch stream, the NEXT step's coarse forward overlaps this step's fine backward.
+    Autograd runs a Function's backward on the stream of its forward: no stream switch inside any backward method."""
 
-    def arm(self):
-        self.after = torch.cuda.Event()
-        self.after.record()
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.main = None
+        self.on_coarse_done = None      # callable(rgb0): the rest of the coarse chain (set by the train step)
+        self.positions_ready = torch.cuda.Event()
+        self.calls = 0
 
-    def disarm(self):
-        self.after = None
+    def begin(self, wait_for_main):
+        """Start a step: the launch stream is the current one.  `wait_for_main`: the coarse stream first waits for
+        everything enqueued on the launch stream so far (a caller's own ray batch; the first step)."""
+        self.main = torch.cuda.current_stream()
+        self.calls = 0
+        if wait_for_main:
+            self.stream.wait_stream(self.main)
+
+    def coarse(self):
+        return torch.cuda.stream(self.stream)
+
+    def fine(self):
+        return torch.cuda.stream(self.main)
+
+    def hand_over(self, tensors):
+        """Tensors allocated on the coarse stream that the launch stream will read (the caching allocator must not hand
+        their blocks to the coarse stream's next step while the launch stream still uses them)."""
+        for t in tensors:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(self.main)
+
+    def coarse_done(self, rgb0, for_fine):
+        """Called on the coarse stream when the fine pass's inputs are enqueued."""
+        self.calls += 1
+        if self.calls > 1:
+            raise RuntimeError("plnerf_amd: a pipelined step renders its batch in ONE render_rays call "
+                               "(the batch was split into chunks: raise `chunk` or use pipeline=0)")
+        self.hand_over(for_fine)
+        self.positions_ready.record(self.stream)
+        if self.on_coarse_done is not None:
+            self.on_coarse_done(rgb0)
+
+    def begin_fine(self):
+        self.main.wait_event(self.positions_ready)
 
 
-SIDE_BWD = None
-
-
-def _side_of(net=None):
-    sb = SIDE_BWD
-    if sb is None or sb.after is None or (net is not None and net is not sb.net):
-        return None
-    return sb
+CHAIN = None
+GRAD_TAIL = 4      # floats behind a network's flat gradient (16 bytes: [0] = range status, the rest unused)
 
 
 class QuadratureFn(torch.autograd.Function):
@@ -256,14 +283,36 @@ class CoarseEpilogueFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, g_depth, g_z, g_pts, g_std):
-        side = _side_of()
-        if side is not None:      # (the coarse chain on its own stream: SideBackward)
-            side.stream.wait_event(side.after)
-            with torch.cuda.stream(side.stream):
-                g_raw = _quad_backward(ctx.saved_tensors, ctx.cfg, g_rgb, g_disp, g_acc, None, g_depth, None, None)
-        else:
-            g_raw = _quad_backward(ctx.saved_tensors, ctx.cfg, g_rgb, g_disp, g_acc, None, g_depth, None, None)
+        g_raw = _quad_backward(ctx.saved_tensors, ctx.cfg, g_rgb, g_disp, g_acc, None, g_depth, None, None)
         return (g_raw,) + (None,) * 14
+
+
+_LOSS_WS = {}
+
+
+def _loss_workspace(device, nbytes):
+    """The loss kernels' partial sums and ticket counter: zeroed once per (device, stream), left zeroed by every launch
+    (two streams may run a loss kernel at the same time: one workspace each)."""
+    key = (device, L.stream().value, nbytes)
+    ws = _LOSS_WS.get(key)
+    if ws is None:
+        ws = _LOSS_WS[key] = torch.zeros(nbytes // 8, device=device, dtype=torch.float64)
+    return ws
+
+
+def _image_loss(rgb, rgb0, target, coarse_loss=None):
+    rgb_c, t_c = _f32c(rgb), _f32c(target)
+    rgb0_c = None if rgb0 is None else _f32c(rgb0)
+    _expect(rgb_c.shape == t_c.shape and rgb_c.dim() == 2 and rgb_c.shape[1] == 3, "rgb / target must be [R, 3]")
+    _expect(rgb0_c is None or coarse_loss is None, "coarse_loss replaces rgb0")
+    loss4 = torch.empty(4, device=rgb_c.device)
+    g1 = torch.empty_like(rgb_c)
+    g0 = None if rgb0_c is None else torch.empty_like(rgb_c)
+    ws = _loss_workspace(rgb_c.device, L.IMAGE_LOSS_WORKSPACE_BYTES)
+    L.check(L.lib().plnerf_image_loss(L.dptr(rgb_c, "rgb"), L.dptr(rgb0_c, "rgb0"), L.dptr(t_c, "target"),
+                                      rgb_c.shape[0], L.dptr(loss4), L.dptr(g1), L.dptr(g0), L.dptr(coarse_loss, "coarse_loss"),
+                                      L.dptr(ws, "workspace", torch.float64), L.stream()), "plnerf_image_loss")
+    return loss4, g1, g0
 
 
 class ImageLossFn(torch.autograd.Function):
@@ -272,18 +321,10 @@ class ImageLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rgb, rgb0, target):
-        rgb_c, t_c = _f32c(rgb), _f32c(target)
-        rgb0_c = None if rgb0 is None else _f32c(rgb0)
-        _expect(rgb_c.shape == t_c.shape and rgb_c.dim() == 2 and rgb_c.shape[1] == 3, "rgb / target must be [R, 3]")
-        R = rgb_c.shape[0]
-        loss3 = torch.empty(4, device=rgb_c.device)
-        g1 = torch.empty_like(rgb_c)
-        g0 = None if rgb0_c is None else torch.empty_like(rgb_c)
-        L.check(L.lib().plnerf_image_loss(L.dptr(rgb_c, "rgb"), L.dptr(rgb0_c, "rgb0"), L.dptr(t_c, "target"), R,
-                                          L.dptr(loss3), L.dptr(g1), L.dptr(g0), L.stream()), "plnerf_image_loss")
+        loss4, g1, g0 = _image_loss(rgb, rgb0, target)
         ctx.grads = (g1, g0)
         ctx.set_materialize_grads(False)
-        total, fine, coarse, _ = loss3.unbind(0)
+        total, fine, coarse, _ = loss4.unbind(0)
         return total, fine, coarse
 
     @staticmethod
@@ -299,20 +340,12 @@ class ImageLossFn(torch.autograd.Function):
         return scaled(g1, g_total, g_fine), scaled(g0, g_total, g_coarse), None
 
 
-def image_loss_and_grads(rgb, rgb0, target):
+def image_loss_and_grads(rgb, rgb0, target, coarse_loss=None):
     """plnerf_image_loss without the autograd wrapper, for a caller that back-propagates the two gradients itself
     (train.TrainStep: torch.autograd.backward((rgb, rgb0), (g_rgb, g_rgb0)) is loss.backward() minus three tiny
-    launches).  Returns (loss4 = [total, fine, coarse, psnr], g_rgb, g_rgb0)."""
-    rgb_c, t_c = _f32c(rgb), _f32c(target)
-    rgb0_c = None if rgb0 is None else _f32c(rgb0)
-    _expect(rgb_c.shape == t_c.shape and rgb_c.dim() == 2 and rgb_c.shape[1] == 3, "rgb / target must be [R, 3]")
-    loss4 = torch.empty(4, device=rgb_c.device)
-    g1 = torch.empty_like(rgb_c)
-    g0 = None if rgb0_c is None else torch.empty_like(rgb_c)
-    L.check(L.lib().plnerf_image_loss(L.dptr(rgb_c, "rgb"), L.dptr(rgb0_c, "rgb0"), L.dptr(t_c, "target"),
-                                      rgb_c.shape[0], L.dptr(loss4), L.dptr(g1), L.dptr(g0), L.stream()),
-            "plnerf_image_loss")
-    return loss4, g1, g0
+    launches).  Returns (loss4 = [total, fine, coarse, psnr], g_rgb, g_rgb0).  `coarse_loss` (with rgb0 None): the loss4
+    of an earlier call on the coarse image alone, whose [1] becomes this call's coarse term (functional.CoarseChain)."""
+    return _image_loss(rgb, rgb0, target, coarse_loss)
 
 
 def coarse_samples(rays_o, rays_d, near, far, t_vals, t_rand, lindisp, perturb, draws):
@@ -403,32 +436,27 @@ class MlpFn(torch.autograd.Function):
         # dp.GradientBucket then see a network's gradient as a single flat tensor (one Adam launch, one all-reduce
         # without gather / scatter copies)
         sizes = [int(torch.Size(s).numel()) for s in ctx.param_shapes]
-        side = _side_of(ctx.net) if n_rows > 0 else None
-        launch_stream = torch.cuda.current_stream()
-        with (torch.cuda.stream(side.stream) if side is not None else contextlib.nullcontext()):
-            flat = (torch.zeros if n_rows == 0 else torch.empty)(sum(sizes), device=dev, dtype=torch.float32)
-            grads = [t.view(s) for t, s in zip(flat.split(sizes), ctx.param_shapes)]
-            if n_rows == 0:
-                return (None,) * 3 + (None if not ctx.n_cam else flat.new_zeros(ctx.n_cam),) + (None,) * 3 + tuple(grads)
-            g = _f32c(g_raw)
-            ws = torch.empty(L.lib().plnerf_mlp_bwd_workspace_bytes(n_rows, prec) // 4, device=dev,
-                             dtype=torch.float32)
-            timer = KERNEL_TIMER
-            if timer is not None:
-                ev = timer.bracket(f"mlp_bwd[{n_rows}]")
-                ev[0].record()
-            L.check(L.lib().plnerf_mlp_bwd(
-                L.dptr(ctx.packed), prec, L.dptr(g, "g_raw"), int(ctx.net.input_ch), int(ctx.net.hip_view_ch), n_rows,
-                L.dptr(ctx.saved_acts), ctx.saved_layout, L.dptr(ws), L.ptr_table(grads, "grads"), L.stream()),
-                "plnerf_mlp_bwd")
-            if timer is not None:
-                ev[1].record()
-        if side is not None:
-            # whatever the launch stream does next with these gradients (hooks, all-reduce, Adam) comes after the side
-            # stream's kernels; the fine network's backward, already enqueued on the launch stream, is not held up
-            done = torch.cuda.Event()
-            done.record(side.stream)
-            launch_stream.wait_event(done)
+        n_grad = sum(sizes)
+        # (+ GRAD_TAIL floats behind them: [0] = the network's range status as the reduction kernel leaves it, so that a
+        # data-parallel exchange of this buffer carries it along -- dp.GradientBucket)
+        full = (torch.zeros if n_rows == 0 else torch.empty)(n_grad + GRAD_TAIL, device=dev, dtype=torch.float32)
+        flat = full[:n_grad]
+        ctx.net.__dict__["_grad_flat"] = full
+        grads = [t.view(s) for t, s in zip(flat.split(sizes), ctx.param_shapes)]
+        if n_rows == 0:
+            return (None,) * 3 + (None if not ctx.n_cam else flat.new_zeros(ctx.n_cam),) + (None,) * 3 + tuple(grads)
+        g = _f32c(g_raw)
+        ws = torch.empty(L.lib().plnerf_mlp_bwd_workspace_bytes(n_rows, prec) // 4, device=dev, dtype=torch.float32)
+        timer = KERNEL_TIMER
+        if timer is not None:
+            ev = timer.bracket(f"mlp_bwd[{n_rows}]")
+            ev[0].record()
+        L.check(L.lib().plnerf_mlp_bwd(
+            L.dptr(ctx.packed), prec, L.dptr(g, "g_raw"), int(ctx.net.input_ch), int(ctx.net.hip_view_ch), n_rows,
+            L.dptr(ctx.saved_acts), ctx.saved_layout, L.dptr(ws), L.ptr_table(grads, "grads"),
+            ctypes.c_void_p(full.data_ptr() + 4 * n_grad), L.stream()), "plnerf_mlp_bwd")
+        if timer is not None:
+            ev[1].record()
         g_cam = None
         if ctx.n_cam and ctx.view_weight is not None:
             # params: ..., views_linears.0.weight (16) [W/2, W + view_ch], views_linears.0.bias (17) [W/2]
@@ -616,7 +644,6 @@ def embed_rows(pts, viewdirs, cam, n_freqs_xyz, n_freqs_dir, input_scale=1.0, bb
     """plnerf_embed_rows: run_network's input assembly in one launch.  pts [R, S, 3]; viewdirs [R, 3] or None; cam
     [n_cam] or None (needs viewdirs).  Returns embedded [R * S, 3 + 6 fx (+ 3 + 6 fd + n_cam)]; no gradient (the
     positions carry none on this path; a trainable `cam` gets its gradient through MlpFn)."""
-    import ctypes
     R, S = pts.shape[0], pts.shape[1]
     pts_c = _f32c(pts).reshape(-1, 3)
     vd_c = None if viewdirs is None else _f32c(viewdirs)
@@ -630,9 +657,6 @@ def embed_rows(pts, viewdirs, cam, n_freqs_xyz, n_freqs_dir, input_scale=1.0, bb
                                       int(n_freqs_xyz), int(n_freqs_dir), n_cam, float(input_scale), center,
                                       float(bb_scale), L.dptr(out), L.stream()), "plnerf_embed_rows")
     return out
-
-
-_DEPTH_LOSS_WS = {}
 
 
 def depth_loss_and_grads(rgb, rgb0, target, pred_hyp, target_h, weight, threshold=0.0, mask=None):
@@ -655,11 +679,7 @@ def depth_loss_and_grads(rgb, rgb0, target, pred_hyp, target_h, weight, threshol
     loss5 = torch.empty(5, device=rgb_c.device)
     g1 = torch.empty_like(rgb_c)
     g0 = None if rgb0_c is None else torch.empty_like(rgb_c)
-    # the kernel's partial sums and ticket counter: zeroed once per (device, stream), left zeroed by every launch
-    key = (rgb_c.device, torch.cuda.current_stream().cuda_stream)
-    ws = _DEPTH_LOSS_WS.get(key)
-    if ws is None:
-        ws = _DEPTH_LOSS_WS[key] = torch.zeros(L.DEPTH_LOSS_WORKSPACE_BYTES // 8, device=rgb_c.device, dtype=torch.float64)
+    ws = _loss_workspace(rgb_c.device, L.DEPTH_LOSS_WORKSPACE_BYTES)
     L.check(L.lib().plnerf_depth_loss(L.dptr(rgb_c, "rgb"), L.dptr(rgb0_c, "rgb0"), L.dptr(t_c, "target"),
                                       L.dptr(hyp_c, "pred_hyp"), L.dptr(th_c, "target_h"), L.dptr(mask_c, "mask"), R, P, H,
                                       PT, float(weight), float(threshold), L.dptr(loss5), L.dptr(g1), L.dptr(g0),

@@ -109,6 +109,7 @@ class FlatAdam(torch.optim.Adam):
                 fv.view(p.shape).copy_(st['exp_avg_sq'])
                 st['exp_avg'], st['exp_avg_sq'] = fm.view(p.shape), fv.view(p.shape)
                 st['step'] = torch.as_tensor(float(st['step']), dtype=torch.float32)
+            fl.pop('uniform_step', None)
 
     @staticmethod
     def _uniform_grads(ps, base, offs):
@@ -119,17 +120,29 @@ class FlatAdam(torch.optim.Adam):
                 return False
         return True
 
-    def _guard_ptrs(self):
-        """The (up to two) status words a launch is guarded by, resolved NOW: a network's packed buffer -- and with it
-        the word -- is re-allocated when the network moves or changes precision, a cached view would watch dead memory."""
+    def _uniform_steps(self, fl, ps, s0):
+        """EVERY parameter's step count equals s0 (the one launch uses a single bias correction for all 24 tensors).  The
+        full comparison runs whenever the count is not the one this optimizer itself left behind at its last one-launch
+        step (a partially loaded state_dict, a parameter that skipped steps for lack of a gradient, wound-back counts)."""
+        if fl.get('uniform_step') == s0:
+            return True
+        return all(float(self.state[p]['step']) == s0 for p in ps)
+
+    def _guard_ptrs(self, guards=None):
+        """The (up to two) words a launch is guarded by, resolved NOW: a network's packed buffer -- and with it its status
+        word -- is re-allocated when the network moves or changes precision, a cached view would watch dead memory.  A
+        word is any 4-byte device value whose non-zero BITS mean "withhold": a network's int32 status word, or the float
+        a data-parallel exchange summed over the ranks' words (dp.GradientBucket.tails)."""
         ptrs = []
-        for g in self.guards:
+        for g in (self.guards if guards is None else guards):
             word = g.status_word() if hasattr(g, "status_word") else g
-            ptrs.append(L.dptr(word, "guard", torch.int32))
+            ptrs.append(L.dptr(word, "guard", word.dtype if word.dtype in (torch.int32, torch.float32) else torch.int32))
+        if len(ptrs) > 2:
+            raise ValueError("FlatAdam: at most two guard words per step (plnerf_adam_step takes two)")
         return (ptrs + [None, None])[:2]
 
     def _withheld_ptr(self, dev):
-        if not self.guards:
+        if not (self.guards or getattr(self, "_guarded_now", False)):
             return None
         if self._withheld is None or self._withheld.device != dev:
             self._withheld = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -144,6 +157,9 @@ class FlatAdam(torch.optim.Adam):
         n = int(self._withheld.item()) // max(self._launches_per_step, 1)
         if n and reset:
             self._withheld.zero_()
+            for fl in self._flat:
+                if fl is not None:
+                    fl.pop('uniform_step', None)
             for group in self.param_groups:
                 for p in group['params']:
                     st = self.state.get(p)
@@ -152,8 +168,11 @@ class FlatAdam(torch.optim.Adam):
         return n
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0, clip_value=0.0):
-        """clip_value > 0: every gradient entry is clamped to [-clip_value, clip_value] inside the step kernel (what
+    def step(self, closure=None, grad_scale=1.0, clip_value=0.0, guards=None):
+        """grad_scale: every gradient entry is multiplied by it inside the step kernel (a data-parallel caller passes
+        1 / world for gradients that hold the SUM over the ranks).  guards: this call's guard words instead of the
+        constructor's (a data-parallel step is guarded by the ranks' summed status, dp.GradientBucket.tails).
+        clip_value > 0: every gradient entry is clamped to [-clip_value, clip_value] inside the step kernel (what
         torch.nn.utils.clip_grad_value_ between backward and step does, run_nerf_sample_based_depth.py:1156 -- minus
         its 48 launches; `.grad` itself keeps the unclipped values)."""
         loss = None
@@ -167,7 +186,8 @@ class FlatAdam(torch.optim.Adam):
                 torch.nn.utils.clip_grad_value_([p for g in self.param_groups for p in g['params']], clip_value)
             super().step(closure=None)      # (the closure, if any, was evaluated above)
             return loss
-        guard_a, guard_b = self._guard_ptrs()
+        guard_a, guard_b = self._guard_ptrs(guards)
+        self._guarded_now = bool(self.guards if guards is None else guards)
         launches = 0
         for group, fl in zip(self.param_groups, self._flat):
             ps = group['params']
@@ -208,9 +228,10 @@ class FlatAdam(torch.optim.Adam):
                 if (g0.dtype == torch.float32 and g1.data_ptr() == g0.data_ptr() + 4 * offs[-2] and
                         g0.untyped_storage().data_ptr() == g1.untyped_storage().data_ptr() and
                         g0.is_contiguous() and g1.is_contiguous() and float(s0) == float(s1) and
-                        self._uniform_grads(ps, g0.data_ptr(), offs)):
+                        self._uniform_steps(fl, ps, float(s0)) and self._uniform_grads(ps, g0.data_ptr(), offs)):
                     steps = [self.state[p]['step'] for p in ps]
                     torch._foreach_add_(steps, 1.0)
+                    fl['uniform_step'] = float(s0) + 1.0
                     L.check(L.lib().plnerf_adam_step(
                         L.dptr(fl['param']), L.dptr(g0.as_strided((offs[-1],), (1,))), L.dptr(fl['m']), L.dptr(fl['v']),
                         offs[-1], float(group['lr']), float(b1), float(b2), float(group['eps']),
@@ -231,6 +252,7 @@ class FlatAdam(torch.optim.Adam):
                     lo, hi = offs[first], offs[last + 1]
                     steps = [self.state[ps[q]]['step'] for q in idx[a:b]]
                     torch._foreach_add_(steps, 1.0)
+                    fl.pop('uniform_step', None)
                     L.check(L.lib().plnerf_adam_step(
                         L.dptr(fl['param'][lo:hi]), L.dptr(gview), L.dptr(fl['m'][lo:hi]), L.dptr(fl['v'][lo:hi]),
                         hi - lo, float(group['lr']), float(b1), float(b2), float(group['eps']),

@@ -5,6 +5,8 @@ function), so a caller of the reference's `create_nerf` / `render` / `render_ray
 switch to this module unchanged.  Everything numerical happens in libplnerf_hip.so via
 `functional.py`; torch is used for allocation, the random draws and the autograd tape.
 """
+import contextlib
+
 import numpy as np
 import torch
 
@@ -185,63 +187,74 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_
         viewdirs = ray_batch[:, -3:].contiguous() if ray_batch.shape[-1] > 8 else None
         near, far = ray_batch[:, 6:7].contiguous(), ray_batch[:, 7:8].contiguous()
 
-    t_vals = Fn.cpu_linspace(N_samples, dev)
-    # The ray batch carries no gradient on this path (refused above), so the prologue's element-wise chain runs as ONE
-    # kernel (depths + positions, bit-identical to the torch expressions below, which remain for an empty batch).
-    fused_glue = ray_batch.is_cuda and N_rays > 0
-    # Random draws: pytest=True replays the reference's numpy draws; otherwise an installed functional.DrawSource
-    # supplies counter-based draws (inside the consuming kernels on the fused path), else torch.rand as the
-    # reference does.
-    draws = None if pytest else Fn.DRAWS
-    if draws is not None:
-        draws.noise_calls = 0      # (this call's coarse pass draws its density noise first, then the fine pass)
-    if fused_glue:
-        t_rand = None
-        if perturb > 0. and (pytest or draws is None):
-            shape = [N_rays, N_samples]
-            t_rand = Fn.numpy_uniform(shape, dev) if pytest else torch.rand(shape, device=dev)
-        z_vals, pts = Fn.coarse_samples(rays_o, rays_d, near, far, t_vals, t_rand, lindisp, perturb > 0., draws)
-    else:
-        if not lindisp:
-            z_vals = near * (1. - t_vals) + far * t_vals
+    # Two-stream step (functional.CoarseChain, armed by train.TrainStep): the coarse pass -- and, from `coarse_done` on,
+    # the coarse network's loss, backward and optimizer step -- on the chain's own stream, the fine pass on the launch
+    # stream, which waits for the fine pass's inputs only.  Needs two distinct networks (with one network the fine pass
+    # must see the weights the coarse pass saw).
+    chain = Fn.CHAIN
+    if chain is not None and not (ray_batch.is_cuda and N_rays > 0 and N_importance > 0 and network_fine is not None and
+                                  network_fine is not network_fn):
+        chain = None
+    if chain is not None and torch.cuda.current_stream() != chain.stream:
+        # a ray batch prepared on the caller's stream (slices, NDC warp, ...): the coarse stream starts behind it
+        chain.stream.wait_stream(torch.cuda.current_stream())
+    with (chain.coarse() if chain is not None else contextlib.nullcontext()):
+        t_vals = Fn.cpu_linspace(N_samples, dev)
+        # The ray batch carries no gradient on this path (refused above), so the prologue's element-wise chain runs as
+        # ONE kernel (depths + positions, bit-identical to the torch expressions below, which remain for an empty batch).
+        fused_glue = ray_batch.is_cuda and N_rays > 0
+        # Random draws: pytest=True replays the reference's numpy draws; otherwise an installed functional.DrawSource
+        # supplies counter-based draws (inside the consuming kernels on the fused path), else torch.rand as the
+        # reference does.
+        draws = None if pytest else Fn.DRAWS
+        if draws is not None:
+            draws.noise_calls = 0      # (this call's coarse pass draws its density noise first, then the fine pass)
+        if fused_glue:
+            t_rand = None
+            if perturb > 0. and (pytest or draws is None):
+                shape = [N_rays, N_samples]
+                t_rand = Fn.numpy_uniform(shape, dev) if pytest else torch.rand(shape, device=dev)
+            z_vals, pts = Fn.coarse_samples(rays_o, rays_d, near, far, t_vals, t_rand, lindisp, perturb > 0., draws)
         else:
-            z_vals = 1. / (1. / near * (1. - t_vals) + 1. / far * t_vals)
-        z_vals = z_vals.expand([N_rays, N_samples])
-
-        if perturb > 0.:
-            mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
-            upper = torch.cat([mids, z_vals[..., -1:]], -1)
-            lower = torch.cat([z_vals[..., :1], mids], -1)
-            if pytest:
-                t_rand = Fn.numpy_uniform(list(z_vals.shape), dev)
-            elif draws is not None:
-                t_rand = draws.uniform(N_rays, N_samples, Fn.DrawSource.T_RAND, dev)
+            if not lindisp:
+                z_vals = near * (1. - t_vals) + far * t_vals
             else:
-                t_rand = torch.rand(z_vals.shape, device=dev)
-            z_vals = lower + (upper - lower) * t_rand
+                z_vals = 1. / (1. / near * (1. - t_vals) + 1. / far * t_vals)
+            z_vals = z_vals.expand([N_rays, N_samples])
 
-        pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+            if perturb > 0.:
+                mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+                upper = torch.cat([mids, z_vals[..., -1:]], -1)
+                lower = torch.cat([z_vals[..., :1], mids], -1)
+                if pytest:
+                    t_rand = Fn.numpy_uniform(list(z_vals.shape), dev)
+                elif draws is not None:
+                    t_rand = draws.uniform(N_rays, N_samples, Fn.DrawSource.T_RAND, dev)
+                else:
+                    t_rand = torch.rand(z_vals.shape, device=dev)
+                z_vals = lower + (upper - lower) * t_rand
 
-    if constant_init:   # run_plnerf.py:710-711: overrides the mode for the whole call
-        mode = "constant"
+            pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
 
-    raw = network_query_fn(pts, viewdirs, network_fn)
-    fused_epilogue = fused_glue and N_importance > 0 and mode == "linear" and color_mode in ("midpoint", "left")
-    if fused_epilogue:
-        # coarse raw2outputs + sampler + clamp + sort + fine positions + z_std: one launch (weights, tau, T and the
-        # cdf never reach HBM); identical values to the separate calls below
-        det = perturb == 0.
-        u = _draw_u([N_rays], N_importance, det, pytest, dev) if (pytest or det or draws is None) else None
-        rgb_map_0, disp_map_0, acc_map_0, depth_map_0, z_vals, pts, z_std = Fn.CoarseEpilogueFn.apply(
-            _rgb_sigma(raw), z_vals, near, far, rays_o, rays_d, _draw_noise(raw, raw_noise_std, pytest), u,
-            N_importance, color_mode, white_bkgd, farcolorfix, zero_tol, epsilon, draws)
-    else:
-        rgb_map, disp_map, acc_map, weights, depth_map, tau, T = raw2outputs(
-            raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std, pytest=pytest, white_bkgd=white_bkgd,
-            farcolorfix=farcolorfix)
+        if constant_init:   # run_plnerf.py:710-711: overrides the mode for the whole call
+            mode = "constant"
 
-    if N_importance > 0:
-        if not fused_epilogue:
+        raw = network_query_fn(pts, viewdirs, network_fn)
+        fused_epilogue = fused_glue and N_importance > 0 and mode == "linear" and color_mode in ("midpoint", "left")
+        if fused_epilogue:
+            # coarse raw2outputs + sampler + clamp + sort + fine positions + z_std: one launch (weights, tau, T and the
+            # cdf never reach HBM); identical values to the separate calls below
+            det = perturb == 0.
+            u = _draw_u([N_rays], N_importance, det, pytest, dev) if (pytest or det or draws is None) else None
+            rgb_map_0, disp_map_0, acc_map_0, depth_map_0, z_vals, pts, z_std = Fn.CoarseEpilogueFn.apply(
+                _rgb_sigma(raw), z_vals, near, far, rays_o, rays_d, _draw_noise(raw, raw_noise_std, pytest), u,
+                N_importance, color_mode, white_bkgd, farcolorfix, zero_tol, epsilon, draws)
+        else:
+            rgb_map, disp_map, acc_map, weights, depth_map, tau, T = raw2outputs(
+                raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std, pytest=pytest, white_bkgd=white_bkgd,
+                farcolorfix=farcolorfix)
+
+        if N_importance > 0 and not fused_epilogue:
             rgb_map_0, disp_map_0, acc_map_0, depth_map_0 = rgb_map, disp_map, acc_map, depth_map
             if mode == "linear":
                 z_samples, _, _, _ = sample_pdf_reformulation(
@@ -260,11 +273,21 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_
             else:
                 pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
 
-        run_fn = network_fn if network_fine is None else network_fine
-        raw = network_query_fn(pts, viewdirs, run_fn)
-        rgb_map, disp_map, acc_map, weights, depth_map, tau, T = raw2outputs(
-            raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std, pytest=pytest,
-            white_bkgd=white_bkgd, farcolorfix=farcolorfix)
+        if chain is not None:
+            # the fine pass's inputs are enqueued: the launch stream may go on as soon as THEY exist, while this stream
+            # continues with the coarse network's loss / backward / optimizer step (the callback the train step set)
+            chain.coarse_done(rgb_map_0, (z_vals, pts, rgb_map_0, disp_map_0, acc_map_0, depth_map_0, z_std, rays_o, rays_d,
+                                          near, far, viewdirs))
+
+    if N_importance > 0:
+        with (chain.fine() if chain is not None else contextlib.nullcontext()):
+            if chain is not None:
+                chain.begin_fine()
+            run_fn = network_fn if network_fine is None else network_fine
+            raw = network_query_fn(pts, viewdirs, run_fn)
+            rgb_map, disp_map, acc_map, weights, depth_map, tau, T = raw2outputs(
+                raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std, pytest=pytest,
+                white_bkgd=white_bkgd, farcolorfix=farcolorfix)
 
     ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map, 'depth_map': depth_map}
     if retraw:
@@ -366,16 +389,18 @@ def create_nerf(args, device=None):
     # the steps are guarded by the network's range status word
     half_range = on_gpu and precision in L.GUARDED_PRECISIONS
 
-    def guard(net):
-        return {"guards": [net]} if (half_range and net.is_supported()) else {}
+    def guard(*nets):
+        nets = [n for n in nets if n is not None and n.is_supported()]
+        return {"guards": nets} if (half_range and nets) else {}
     adam = FlatAdam if on_gpu else torch.optim.Adam
+    # (the fine network's step is guarded by BOTH networks: its samples and z_vals come from the coarse pass, and a
+    # clamped coarse forward must withhold the whole step, not let the two networks drift apart until the next poll)
     optimizer = adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999),
-                     **(guard(model_fine if model_fine is not None else model) if on_gpu else {}))
+                     **(guard(model_fine, model) if model_fine is not None else guard(model)))
     # Single-pass configuration (N_importance == 0): the reference builds BOTH Adams over the same (coarse)
     # parameters and steps them one after the other.  The second FlatAdam adopts the flat buffer the first one
     # re-homed the weights into (optim.FlatAdam._flatten) and carries the same guard.
-    optimizer_coarse = adam(params=coarse_vars, lr=args.coarse_lrate, betas=(0.9, 0.999),
-                            **(guard(model) if on_gpu else {}))
+    optimizer_coarse = adam(params=coarse_vars, lr=args.coarse_lrate, betas=(0.9, 0.999), **guard(model))
 
     start = 0
     candidates = RB.checkpoint_candidates(args)

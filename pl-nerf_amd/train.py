@@ -9,6 +9,7 @@ ray shards per rank with one bucketed gradient all-reduce (dp.py).  Ray selectio
 device (only the N_rand selected pixels are turned into rays) instead of rebuilding the full
 H x W ray grid and choosing on the host every step (lines 1259, 1275).
 """
+import contextlib
 import ctypes
 import os
 
@@ -19,6 +20,7 @@ from . import _lib as L
 from . import dp
 from . import functional as Fn
 from . import raybatch as RB
+from .optim import FlatAdam
 from .render import render, render_rays
 
 
@@ -111,7 +113,19 @@ class TrainStep:
     renders it or N ranks render a shard each.  `counter_rng=False` restores torch.rand."""
 
     def __init__(self, args, render_kwargs_train, optimizer, optimizer_coarse, start=0, distributed=None, seed=0,
-                 counter_rng=True, range_check_every=100, side_stream=None):
+                 counter_rng=True, range_check_every=100, pipeline=None):
+        """pipeline: how the step's two independent chains are scheduled (functional.CoarseChain).
+          0  one stream, the reference's order: render, loss, backward, both optimizers.
+          1  the coarse network's loss / backward / gradient exchange / optimizer step on a second HIP stream as soon as
+             the coarse pass is rendered, next to the fine pass on the launch stream (HBM-bound backward next to the
+             MFMA-bound forward); the second stream starts behind whatever the launch stream holds at the step's start.
+             When the step returns, everything it did is ordered before whatever the caller enqueues on the launch stream
+             next.  (Default on the GPU with two networks; PLNERF_PIPELINE in the environment overrides.)
+          2  the same, and in `step_view` -- where the step owns its inputs from the pixel choice on -- the coarse stream
+             never waits for the launch stream: the next step's coarse pass (which needs the coarse weights only)
+             overlaps this step's fine backward.  Every step still computes exactly the reference's step, but the coarse
+             network's weights and optimizer state belong to the coarse stream between steps: read or write them from
+             outside (save / load a checkpoint, evaluate, ...) only after `drain()`.  bench.py runs this mode."""
         self.args = args
         self.kw = render_kwargs_train
         self.optimizer = optimizer
@@ -127,13 +141,15 @@ class TrainStep:
         # and raises.  0 = never look (the caller does).
         self.range_check_every = int(range_check_every)
         self.seed = seed
-        # the coarse network's backward on a second HIP stream (functional.SideBackward).  Default: the environment's
-        # PLNERF_SIDE_STREAM (0 / 1), else off -- the same-box A/B of profiles/r03_side_stream_ab.txt decides
-        if side_stream is None:
-            side_stream = os.environ.get("PLNERF_SIDE_STREAM", "0") == "1"
+        if pipeline is None:
+            pipeline = int(os.environ.get("PLNERF_PIPELINE", "1"))
         fine = self.kw.get("network_fine")
-        self.side = Fn.SideBackward(self.kw["network_fn"]) if (side_stream and fine is not None and
-                                                                 next(fine.parameters()).is_cuda) else None
+        coarse = self.kw["network_fn"]
+        two_nets = fine is not None and fine is not coarse and next(fine.parameters()).is_cuda and \
+            self.kw.get("N_importance", 0) > 0 and optimizer is not optimizer_coarse
+        self.pipeline = int(pipeline) if two_nets else 0
+        self.chain = Fn.CoarseChain(next(coarse.parameters()).device) if self.pipeline else None
+        self._chain_started = False
         self.bucket = None
         if distributed and self.world > 1:
             # replicas must start from the same weights (create_nerf initialises from each process's own RNG, and a
@@ -152,13 +168,35 @@ class TrainStep:
         """The loop body from the view on (run_plnerf.py:1259-1316): choose this rank's n_rand pixels of the view on
         the device, then the optimisation step.  `image` [H, W, 3] lives on the device."""
         n_rand = int(n_rand if n_rand is not None else self.args.N_rand)
-        cols, target, _ = select_view_rays(H, W, K, c2w, image, n_rand, near, far, seed=self.seed,
-                                           step=self.global_step, ray_id0=self.rank * n_rand, precrop=precrop,
-                                           want_viewdirs=bool(self.kw.get("use_viewdirs", True)))
-        return self._step(H, W, K, cols, target, near, far)
+        chain = self._arm_chain(own_inputs=True)
+        with (chain.coarse() if chain is not None else contextlib.nullcontext()):
+            cols, target, _ = select_view_rays(H, W, K, c2w, image, n_rand, near, far, seed=self.seed,
+                                               step=self.global_step, ray_id0=self.rank * n_rand, precrop=precrop,
+                                               want_viewdirs=bool(self.kw.get("use_viewdirs", True)))
+        if chain is not None:
+            chain.hand_over((target,))
+        return self._step(H, W, K, cols, target, near, far, chain)
 
     def __call__(self, H, W, K, batch_rays, target_s, near=0., far=1.):
-        return self._step(H, W, K, batch_rays, target_s, near, far)
+        return self._step(H, W, K, batch_rays, target_s, near, far, self._arm_chain(own_inputs=False))
+
+    def _arm_chain(self, own_inputs):
+        """The step's CoarseChain, or None for the one-stream order (pipeline 0, or the `constant_init` warm-up and
+        other calls that do not take the two-network path: render_rays decides that itself and leaves the chain
+        unused).  The coarse stream waits for the launch stream unless the step owns its inputs (pipeline 2)."""
+        if self.chain is None:
+            return None
+        cross_step = self.pipeline >= 2 and own_inputs and self._chain_started
+        self.chain.begin(wait_for_main=not cross_step)
+        self._chain_started = True
+        return self.chain
+
+    def drain(self):
+        """Both streams wait for each other (host does not block): after this, work enqueued on the launch stream sees
+        every step so far, and the next step starts behind it."""
+        if self.chain is not None and self._chain_started:
+            torch.cuda.current_stream().wait_stream(self.chain.stream)
+            self._chain_started = False
 
     def _render(self, H, W, K, rays, near, far, constant_init):
         chunk = getattr(self.args, "chunk", 1024 * 32)
@@ -174,45 +212,82 @@ class TrainStep:
                                         constant_init=constant_init, **self.kw)
         return rgb, extras
 
-    def _step(self, H, W, K, rays, target_s, near, far):
+    def _coarse_tail(self, chain, target_s, rgb0):
+        """The rest of the coarse chain, on the coarse stream (functional.CoarseChain.coarse_done calls this right after
+        the fine pass's inputs are enqueued): img2mse(rgb0) and its gradient (:1293-1296), the coarse network's
+        backward, its gradient exchange, its Adam step (:1303)."""
+        chain.loss_c, g_rgb0, _ = Fn.image_loss_and_grads(rgb0, None, target_s)
+        chain.hand_over((chain.loss_c,))
+        self.optimizer_coarse.zero_grad()
+        torch.autograd.backward((rgb0,), (g_rgb0,))
+        self._exchange_and_step([self.optimizer_coarse], [self.nets[0]], [[self.nets[0]]])
+        if self.bucket is not None:
+            chain.hand_over(self.bucket.tails([self.nets[0]]))      # (the fine optimizer's guard reads it on the launch stream)
+        chain.coarse_stepped.record(chain.stream)
+
+    def _exchange_and_step(self, opts, exchange, guarded_by):
+        """Finish the gradient exchange of the networks `exchange` (data parallel only) and step the optimizers `opts`,
+        opts[k] guarded by the networks guarded_by[k].  With optim.FlatAdam the 1 / world factor and the guard -- the
+        ranks' summed range status of those networks -- go into the step kernel: between the backward's last kernel and
+        Adam there is one wait and no launch."""
+        if self.bucket is None:
+            for opt in opts:
+                opt.step()
+            return
+        flat_adam = all(isinstance(opt, FlatAdam) and all(fl is not None for fl in opt._flat) for opt in opts)
+        scale = self.bucket.finish(exchange, defer_scale=flat_adam)
+        for opt, nets in zip(opts, guarded_by):
+            if not flat_adam:
+                opt.step()
+                continue
+            tails = self.bucket.tails(nets)
+            opt.step(grad_scale=scale, guards=tails if len(tails) == len(nets) else None)
+
+    def _step(self, H, W, K, rays, target_s, near, far, chain=None):
         i = self.global_step + 1                      # the reference iterates i = start+1 .. N_iters
         n_local = rays.shape[0] if isinstance(rays, RB.RayColumns) else rays[0].reshape(-1, 3).shape[0]
         prev = Fn.DRAWS
         if self.draws is not None:
             self.draws.step, self.draws.ray_id0 = self.global_step, self.rank * n_local
             Fn.set_draw_source(self.draws)
+        if chain is not None:
+            chain.on_coarse_done = lambda rgb0: self._coarse_tail(chain, target_s, rgb0)
+            chain.coarse_stepped = torch.cuda.Event()
+            Fn.CHAIN = chain
         try:
-            rgb, extras = self._render(H, W, K, rays, near, far, i < getattr(self.args, "constant_init", 0))
+            # (chain: the ray batch's preparation -- slices, the NDC warp -- belongs to the coarse stream as well)
+            with (chain.coarse() if chain is not None else contextlib.nullcontext()):
+                rgb, extras = self._render(H, W, K, rays, near, far, i < getattr(self.args, "constant_init", 0))
         finally:
             Fn.set_draw_source(prev)
-        self.optimizer.zero_grad()
-        self.optimizer_coarse.zero_grad()
+            Fn.CHAIN = None
         rgb0 = extras.get('rgb0')
-        if rgb.is_cuda and rgb.dim() == 2 and rgb.shape == target_s.shape:
-            # img2mse(rgb) + img2mse(rgb0), the psnr and both image gradients in one launch (:1287-1300);
-            # backward((rgb, rgb0), (d loss / d rgb, d loss / d rgb0)) is loss.backward()
-            loss4, g_rgb, g_rgb0 = Fn.image_loss_and_grads(rgb, rgb0, target_s)
+        chained = chain is not None and chain.calls == 1
+        self.optimizer.zero_grad()
+        if chained:
+            # the coarse network's part of the step is already enqueued (and maybe done) on the coarse stream; here the
+            # fine network's: img2mse(rgb) (+ the coarse term for the total, :1296), backward, exchange, Adam (:1302)
+            chain.main.wait_event(chain.coarse_stepped)      # (the coarse loss value; and the coarse network's range word: optim guard)
+            loss4, g_rgb, _ = Fn.image_loss_and_grads(rgb, None, target_s, coarse_loss=chain.loss_c)
             loss, psnr = loss4[0], loss4[3]
-            prev_side = Fn.SIDE_BWD
-            if self.side is not None and rgb0 is not None:
-                self.side.arm()              # (the event the side stream waits for: both image gradients are enqueued)
-                Fn.SIDE_BWD = self.side
-            try:
+            torch.autograd.backward((rgb,), (g_rgb,))
+            self._exchange_and_step([self.optimizer], [self.nets[1]], [self.nets])
+        else:
+            self.optimizer_coarse.zero_grad()
+            if rgb.is_cuda and rgb.dim() == 2 and rgb.shape == target_s.shape:
+                # img2mse(rgb) + img2mse(rgb0), the psnr and both image gradients in one launch (:1287-1300);
+                # backward((rgb, rgb0), (d loss / d rgb, d loss / d rgb0)) is loss.backward()
+                loss4, g_rgb, g_rgb0 = Fn.image_loss_and_grads(rgb, rgb0, target_s)
+                loss, psnr = loss4[0], loss4[3]
                 torch.autograd.backward((rgb,) if rgb0 is None else (rgb, rgb0),
                                         (g_rgb,) if rgb0 is None else (g_rgb, g_rgb0))
-            finally:
-                if self.side is not None:
-                    self.side.disarm()
-                Fn.SIDE_BWD = prev_side
-        else:
-            img_loss = img2mse(rgb, target_s)
-            loss = img_loss if rgb0 is None else img_loss + img2mse(rgb0, target_s)
-            psnr = mse2psnr(img_loss.detach())
-            loss.backward()
-        if self.bucket is not None:
-            self.bucket.allreduce_mean()
-        self.optimizer.step()
-        self.optimizer_coarse.step()
+            else:
+                img_loss = img2mse(rgb, target_s)
+                loss = img_loss if rgb0 is None else img_loss + img2mse(rgb0, target_s)
+                psnr = mse2psnr(img_loss.detach())
+                loss.backward()
+            # (fine optimizer first, as the reference does; with ONE network both optimizers step the same weights, :438-447)
+            self._exchange_and_step([self.optimizer, self.optimizer_coarse], self.nets, [self.nets, self.nets[:1]])
         new_lrate = self.learning_rate()
         for group in self.optimizer.param_groups:
             group['lr'] = new_lrate
@@ -226,14 +301,22 @@ class TrainStep:
     def check_range(self):
         """Look at the networks' range status words (one 4-byte read each).  Steps the guarded Adam kernels withheld are
         first taken back out of the optimizers' step counts; a set word raises FloatingPointError -- on every rank of a
-        data-parallel job at the same step (dp.GradientBucket shares the words before each optimizer step)."""
+        data-parallel job at the same step: the ranks' words travel with the gradients (dp.GradientBucket.tails), so a
+        rank whose own words are clear still sees the withheld steps."""
+        if self.chain is not None:
+            torch.cuda.current_stream().wait_stream(self.chain.stream)      # (the coarse stream's steps count as well)
+        withheld = 0
         for opt in (self.optimizer, self.optimizer_coarse):
             if hasattr(opt, "withheld_steps"):
-                opt.withheld_steps()
+                withheld += opt.withheld_steps()
         for net in self.nets:
             if getattr(net, "precision", None) in L.GUARDED_PRECISIONS and net.is_supported() and \
                     next(net.parameters()).is_cuda:
                 net.check_range()
+        if withheld and self.bucket is not None:
+            raise FloatingPointError(
+                f"plnerf_amd: {withheld} optimizer step(s) were withheld because another rank's forward left the "
+                "IEEE-half range (that rank's check_range() says which network); see NeRF.check_range for the remedy")
 
 
 def save_checkpoint(path, global_step, network_fn, network_fine, optimizer):

@@ -340,6 +340,66 @@ def test_training_step_is_bitwise_reproducible(P):
             assert torch.equal(x, y), f"parameters differ after step {step}"
 
 
+def test_two_stream_step_equals_one_stream_step(P):
+    """train.TrainStep's pipelines (functional.CoarseChain): 0 = one stream in the reference's order; 1 = the coarse
+    network's loss / backward / Adam on a second stream next to the fine pass; 2 = additionally the next step's coarse
+    pass next to this step's fine backward.  The three schedule the SAME kernels on the same inputs, so losses and
+    parameters must be bit-identical step after step -- any missing cross-stream dependency (a block handed back to the
+    allocator early, a weight read before its Adam) shows up as a difference.  Also with the `constant_init` warm-up
+    (the non-fused coarse pass) in front, and through __call__ with a caller's own rays."""
+    H = W = 160
+    K = [[220.0, 0, W / 2], [0, 220.0, H / 2], [0, 0, 1]]
+    gen = torch.Generator().manual_seed(5)
+    image = g(torch.rand(H, W, 3, generator=gen))
+    poses = [P.rays.pose_spherical(-180.0 + 72.0 * i, -30.0, 4.0)[:3, :4] for i in range(5)]
+
+    def run(pipeline, own_rays, **over):
+        args, kw, opt, opt_c = _nets(P, **over)
+        ts = P.TrainStep(args, kw, opt, opt_c, distributed=False, seed=17, pipeline=pipeline)
+        assert ts.pipeline == pipeline
+        out = []
+        for step in range(7):
+            if own_rays:
+                cols, target, _ = P.select_view_rays(H, W, K, poses[step % 5], image, 2048, 2.0, 6.0, seed=17, step=step)
+                loss, psnr = ts(H, W, K, cols, target, near=2.0, far=6.0)
+            else:
+                loss, psnr = ts.step_view(H, W, K, poses[step % 5], image, near=2.0, far=6.0, n_rand=2048)
+            out.append((loss, psnr))
+        ts.drain()
+        torch.cuda.synchronize()
+        return [(float(l), float(q)) for l, q in out], [p.detach().clone() for n in ts.nets for p in n.parameters()], ts
+
+    for own_rays, over in ((False, {}), (True, {}), (False, {"constant_init": 3})):
+        base_losses, base_params, _ = run(0, own_rays, **over)
+        for pipeline in (1, 2):
+            losses, params, ts = run(pipeline, own_rays, **over)
+            assert losses == base_losses, (pipeline, own_rays, over, losses, base_losses)
+            for x, y in zip(params, base_params):
+                assert torch.equal(x, y), f"pipeline {pipeline}: parameters differ"
+            assert ts.chain.calls == 1      # (the last step took the two-stream path)
+    assert np.isfinite(base_losses).all()
+
+
+def test_image_loss_takes_the_coarse_term_from_an_earlier_launch(P):
+    """plnerf_image_loss(rgb, NULL, target, coarse_loss = the loss4 of a launch on rgb0 alone) == one launch over both
+    images, bit for bit: what lets the coarse network's loss and backward start before the fine pass exists."""
+    from plnerf_amd import functional as Fn
+    gen = torch.Generator().manual_seed(9)
+    rgb, rgb0, target = (g(torch.rand(4096, 3, generator=gen)) for _ in range(3))
+    both, g1, g0 = Fn.image_loss_and_grads(rgb, rgb0, target)
+    first, gc, _ = Fn.image_loss_and_grads(rgb0, None, target)
+    second, gf, none = Fn.image_loss_and_grads(rgb, None, target, coarse_loss=first)
+    assert none is None and torch.equal(second, both) and torch.equal(gf, g1) and torch.equal(gc, g0)
+    ref = torch.mean((rgb.double() - target.double()) ** 2), torch.mean((rgb0.double() - target.double()) ** 2)
+    assert abs(float(both[1]) - float(ref[0])) <= 1e-7 and abs(float(both[2]) - float(ref[1])) <= 1e-7
+    assert abs(float(both[3]) + 10.0 * np.log10(float(ref[0]))) <= 1e-4
+    for R in (1, 5, 77, 1000):      # fewer elements than workgroups x threads, ragged slices
+        a, b, t = (g(torch.rand(R, 3, generator=gen)) for _ in range(3))
+        l4, ga, gb = Fn.image_loss_and_grads(a, b, t)
+        assert abs(float(l4[0]) - float(torch.mean((a - t) ** 2) + torch.mean((b - t) ** 2))) <= 2e-7
+        assert_close(ga, (2.0 / (3 * R)) * (a - t).cpu(), atol=1e-9, rtol=1e-6, what=f"g_rgb R={R}")
+
+
 # ----------------------------------------------------------------------------- data parallel step, two ranks on one GPU
 _DP_GPU_WORKER = r'''
 import os, sys, tempfile, torch, torch.distributed as dist
@@ -360,7 +420,7 @@ def make(distributed):
     kw, _, _, _, opt, opt_c = P.create_nerf(args, device=dev)
     kw["network_fn"].load_state_dict(orc.closed_form_state_dict(0, False))
     kw["network_fine"].load_state_dict(orc.closed_form_state_dict(1, False))
-    return kw, P.TrainStep(args, kw, opt, opt_c, distributed=distributed, seed=3)
+    return kw, P.TrainStep(args, kw, opt, opt_c, distributed=distributed, seed=3, pipeline=int(sys.argv[2]))
 
 
 H = W = 64
@@ -389,22 +449,28 @@ if rank == 0:
     print("max |param(2 ranks) - param(1 rank, global batch)| =", worst)
     assert worst <= 2e-4, worst          # three Adam steps (lr 5e-4) apart at most through rounding-level gradient differences
 # The range guard is global: ONE rank's forward leaves the half range (simulated: its fine network's status word is set
-# as the clamping kernel would set it) -> the bucket shares the words before Adam, BOTH ranks withhold the step, BOTH
-# raise at the next check, and the step counts are wound back on both.
+# as the clamping kernel would set it) -> the word travels as the tail element of the fine network's gradient buffer, the
+# summed tail guards Adam on BOTH ranks (no extra collective), BOTH withhold the step, BOTH raise at the next check --
+# the rank whose own words are clear because its optimizer counted a withheld step -- and the step counts are wound back.
+ts.drain()
 before = [p.detach().clone() for n in ts.nets for p in n.parameters()]
 steps_before = float(ts.optimizer.state[next(ts.nets[1].parameters())]['step'])
 if rank == 1:
     ts.nets[1].status_word().fill_(1)
 ts.step_view(H, W, K, c2w, image, near=2.0, far=6.0, n_rand=128)
+ts.drain()
 fine_before = before[len(list(ts.nets[0].parameters())):]
 assert all(torch.equal(a, p.detach()) for a, p in zip(fine_before, ts.nets[1].parameters())), "a guarded step reached the weights"
-assert int(ts.nets[1].status_word().item()) == 1, f"rank {rank}: the status word was not shared"
-raised = False
+assert int(ts.nets[1].status_word().item()) == rank, f"rank {rank}: status words are per rank (the tails carry them)"
+tails = ts.bucket.tails()
+assert len(tails) == 2 and float(tails[0]) == 0.0 and float(tails[1]) == 1.0, [float(t) for t in tails]
+raised = None
 try:
     ts.check_range()
-except FloatingPointError:
-    raised = True
-assert raised, f"rank {rank} did not raise"
+except FloatingPointError as e:
+    raised = str(e)
+assert raised is not None, f"rank {rank} did not raise"
+assert ("another rank" in raised) == (rank == 0), raised
 assert float(ts.optimizer.state[next(ts.nets[1].parameters())]['step']) == steps_before       # wound back
 # (the coarse network's word was clear on both ranks: its step went through, identically)
 digest = [float(p.detach().double().sum()) for p in ts.nets[0].parameters()]
@@ -416,7 +482,8 @@ dist.destroy_process_group()
 '''
 
 
-def test_data_parallel_training_step_two_ranks_on_one_gpu(P, tmp_path):
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
+def test_data_parallel_training_step_two_ranks_on_one_gpu(P, tmp_path, pipeline):
     """The multi-GPU step as the driver will launch it, minus the second GPU: two ranks (gloo backend, both on cuda:0)
     each render their shard of a global batch chosen by the counter-based generator, the post-accumulate hooks enqueue
     one in-place all-reduce per network from inside backward, the guarded flat Adam steps.  Replicas stay bit-identical
@@ -427,11 +494,11 @@ def test_data_parallel_training_step_two_ranks_on_one_gpu(P, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "dp_gpu_worker.py"
     script.write_text(_DP_GPU_WORKER)
-    port = 29700 + (os.getpid() % 200)
+    port = 29700 + (os.getpid() % 200) + 200 * pipeline
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script), root], env=env, stdout=subprocess.PIPE,
+        procs.append(subprocess.Popen([sys.executable, str(script), root, str(pipeline)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for rank, (p, out) in enumerate(zip(procs, outs)):

@@ -47,7 +47,7 @@ def test_header_is_plain_c_and_links(built, tmp_path):
     from plnerf_amd import _lib
     header = open(os.path.join(ROOT, "include", "plnerf_hip.h")).read()
     declared = set(re.findall(r"^(?:int|size_t|const char\*)\s+(plnerf_\w+)\s*\(", header, flags=re.M))
-    listed = set(re.findall(r"\(any_fn\)(plnerf_\w+)", open(os.path.join(ROOT, "tests", "abi_check.c")).read()))
+    listed = set(re.findall(r"\)\s*=\s*(plnerf_\w+);", open(os.path.join(ROOT, "tests", "abi_check.c")).read()))
     assert declared == listed == set(_lib.SIGNATURES), (declared ^ listed, declared ^ set(_lib.SIGNATURES))
     exe = str(tmp_path / "abi_check")
     libdir = os.path.dirname(_lib.LIB_PATH)
@@ -57,6 +57,56 @@ def test_header_is_plain_c_and_links(built, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
     assert f"{len(declared)} entry points" in out.stdout
+
+
+def _header_prototypes():
+    """{name: (return type, [parameter types])} parsed from include/plnerf_hip.h (comments stripped)."""
+    import re
+    header = open(os.path.join(ROOT, "include", "plnerf_hip.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    protos = {}
+    for ret, name, args in re.findall(r"^(int|size_t|const char\*)\s+(plnerf_\w+)\s*\(([^;]*?)\)\s*;", code, flags=re.M | re.S):
+        params = []
+        for a in (x.strip() for x in " ".join(args.split()).split(",")):
+            if a == "void":
+                continue
+            params.append(re.match(r"^(.*?)\b\w+$", a).group(1).strip())
+        protos[name] = (ret, params)
+    return protos
+
+
+def test_ctypes_signatures_match_the_header(built):
+    """_lib.SIGNATURES restates the header's argument lists by hand; a swapped c_int / c_float in a 30-argument call would
+    be silent undefined behaviour.  Parse every prototype of include/plnerf_hip.h into its ABI class per argument
+    (pointer, 32-bit int, 32-bit unsigned, 64-bit int, 64-bit unsigned / size_t, float) and compare with the ctypes
+    declaration's, argument by argument, return type included."""
+    import ctypes
+    from plnerf_amd import _lib
+
+    def c_class(t):
+        t = t.replace("const ", "").strip()
+        if t.endswith("*") or t == "plnerf_stream_t":
+            return "ptr"
+        return {"int": "i32", "float": "f32", "uint64_t": "u64", "uint32_t": "u32", "int64_t": "i64", "size_t": "u64",
+                "unsigned": "u32"}[t]      # (size_t and uint64_t are one ctypes object on LP64)
+
+    def ct_class(t):
+        if t is ctypes.c_char_p or t is ctypes.c_void_p or (isinstance(t, type) and issubclass(t, ctypes._Pointer)):
+            return "ptr"
+        return {ctypes.c_int: "i32", ctypes.c_float: "f32", ctypes.c_uint64: "u64", ctypes.c_uint32: "u32",
+                ctypes.c_int64: "i64", ctypes.c_size_t: "u64"}[t]
+    protos = _header_prototypes()
+    assert set(protos) == set(_lib.SIGNATURES)
+    for name, (ret, params) in protos.items():
+        res, args = _lib.SIGNATURES[name]
+        want_ret = "ptr" if ret.endswith("*") else c_class(ret)
+        assert ct_class(res) == want_ret, (name, "return", ret, res)
+        assert len(args) == len(params), (name, len(args), len(params))
+        for k, (c, t) in enumerate(zip(params, args)):
+            assert ct_class(t) == c_class(c), (name, k, c, t)
+    # host-side pointer arguments are declared as typed ctypes pointers (not void*): the binding passes arrays there
+    assert _lib.SIGNATURES["plnerf_select_rays"][1][6] is not ctypes.c_void_p
+    assert _lib.SIGNATURES["plnerf_embed_rows"][1][9] is not ctypes.c_void_p
 
 
 def test_pe_sincos_reduction_on_host(tmp_path):
