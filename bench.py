@@ -91,11 +91,17 @@ def parse(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--cpu-no-grid", action="store_true", help="cpu_baseline: only the workload's own cell")
     ap.add_argument("--views", type=int, default=4, help="synthetic views resident on the device")
-    ap.add_argument("--pipeline", type=int, default=2, choices=[0, 1, 2],
+    ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2],
                     help="train.TrainStep's schedule of the step's two independent chains: 0 = one stream, the reference's "
-                         "order; 1 = the coarse network's loss / backward / Adam on a second HIP stream next to the fine "
-                         "pass; 2 (default) = additionally the next step's coarse pass next to this step's fine backward. "
-                         "Every step computes the same values in all three (tests/test_gpu_step.py)")
+                         "order (default); 1 = the coarse network's loss / backward / Adam on a second HIP stream next to "
+                         "the fine pass; 2 = additionally the next step's coarse pass next to this step's fine backward. "
+                         "Every step computes the same values in all three (tests/test_gpu_step.py); same-box A/B: "
+                         "profiles/r04_pipeline_ab.txt (+1.3 % / -0.8 %)")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the bounded extra legs of the default single-GPU run (north_star's 65,536 x 192 MLP benchmark "
+                         "in every precision, the other BASELINE workloads x 10 steps, one 800x800 frame, the 200-step "
+                         "PSNR-vs-fp32 run); they add ~25 s to the run and nothing to the timed region")
+    ap.add_argument("--psnr-steps", type=int, default=200, help="steps of the psnr_vs_ref leg (each precision)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gradient all-reduce even with one rank (path check)")
     ap.add_argument("--stub-cpu", action="store_true",
@@ -342,6 +348,79 @@ def build_stub_step(rank, world):
     return step, nets
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Bounded extra legs of the default single-GPU run: every number the documents quote, on the one
+# line the driver records.  None of them is inside the timed region of `value`.
+# ---------------------------------------------------------------------------------------------------------------------
+def leg_mlp_only(P, dev, rays=65536, samples=192, iters=3):
+    """north_star's MLP benchmark: the fused PE + MLP forward (inference) at 65,536 x 192 rows, every precision, each
+    with its roofline on the algorithmic FLOP (14.93 TFLOP per launch)."""
+    torch.manual_seed(0)
+    pts = (torch.rand(rays, samples, 3, device=dev) * 2 - 1) * 3
+    vd = torch.nn.functional.normalize(torch.randn(rays, 3, device=dev), dim=-1)
+    rows = rays * samples
+    out = {"rows": rows, "what": "fused PE+MLP forward, inference (no saved state), one launch", "flop_per_row": FWD_FLOP_PER_ROW}
+    for prec in ("f16x3", "bf16x3", "f16", "bf16", "fp32"):
+        net = P.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True,
+                     precision=prec).to(dev)
+        with torch.no_grad():
+            net.query(pts, vd)
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(iters):
+                net.query(pts, vd)
+            e.record()
+            torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / iters
+        tf = rows * FWD_FLOP_PER_ROW / (ms * 1e-3) / 1e12
+        out[prec] = {"ms": ms, "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s",
+                                           "frac": tf / PEAK_TFLOPS[prec]},
+                     "holds_1e-5_contract": prec in ("f16x3", "bf16x3", "fp32")}
+        del net
+    del pts, vd
+    torch.cuda.empty_cache()
+    return out
+
+
+def leg_frame(P, dev, precision="f16x3"):
+    """One 800 x 800 view through render(c2w=...) under no_grad: 640,000 rays in 32,768-ray
+    chunks, 64 + 192 samples; priced on the frame's algorithmic MLP FLOP."""
+    from tools.scene import blender_intrinsics, nerf_args
+    ck = tempfile.mkdtemp()
+    os.makedirs(os.path.join(ck, "exp"))
+    torch.manual_seed(0)
+    so, sys.stdout = sys.stdout, open(os.devnull, "w")
+    try:
+        _, kw_test, _, _, _, _ = P.create_nerf(nerf_args(precision, ck), device=dev)
+    finally:
+        sys.stdout = so
+    H = W = 800
+    K = blender_intrinsics(H, W)
+    poses = [P.rays.pose_spherical(th, -30.0, 4.0)[:3, :4].to(dev) for th in (0.0, 90.0)]
+    with torch.no_grad():
+        P.render(H, W, K, chunk=32768, c2w=poses[0], near=2.0, far=6.0, **kw_test)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rgb, _, _, _ = P.render(H, W, K, chunk=32768, c2w=poses[1], near=2.0, far=6.0, **kw_test)
+        e.record()
+        torch.cuda.synchronize()
+    ms = s.elapsed_time(e)
+    tf = H * W * (64 + 192) * FWD_FLOP_PER_ROW / (ms * 1e-3) / 1e12
+    out = {"precision": precision, "ms_per_frame": ms, "rays_per_s": H * W / (ms * 1e-3), "chunk": 32768,
+           "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
+                        "frac": tf / PEAK_TFLOPS[precision], "note": "whole frame: algorithmic MLP FLOP / frame time"},
+           "finite": bool(torch.isfinite(rgb).all())}
+    del kw_test, rgb
+    torch.cuda.empty_cache()
+    return out
+
+
+def peak_of(precision):
+    return PEAK_TFLOPS[precision]
+
+
 def stats_ms(v):
     return {"min": min(v), "median": statistics.median(v), "max": max(v)} if v else None
 
@@ -437,6 +516,38 @@ def main(argv=None):
         del step32, nets32
         torch.cuda.empty_cache()
 
+    extra = {}
+    if world == 1 and not cpu and not a.no_extra_legs and a.workload == "blender_64_128" and not a.force_dist:
+        # -- the other BASELINE workloads, 10 steps each (configs[3], configs[4] per GPU, the config file's own 128 + 64)
+        import copy
+        wl = {}
+        for w in ("blender_128_64", "llff_ndc", "depth_128_64"):
+            b = copy.copy(a)
+            b.workload, (b.n_samples, b.n_importance) = w, WORKLOADS[w][:2]
+            sc = Scene(P, w, a.views, dev)
+            st, nets_w = build_step(P, b, a.precision, sc, dev, rank, world, False)
+            tm = Fn.KernelTimer()
+            dtw, _, _, psw = timed(st, 3, 10, tm)
+            rows_w = R * (b.n_samples + b.n_importance)
+            fwd_w = tm.mean_ms(f"mlp_fwd[{rows_w}]")
+            tfw = rows_w * FWD_FLOP_PER_ROW / (fwd_w * 1e-3) / 1e12 if fwd_w else None
+            wl[w] = {"ms_per_step": 1e3 * dtw / 10, "rays_per_s": R * 10 / dtw, "steps": 10, "warmup": 3,
+                     "step_ms": stats_ms(psw), "fine_fwd_launch_ms": fwd_w, "fine_fwd_rows": rows_w,
+                     "fine_fwd_frac_of_mfma_peak": (tfw / peak_of(a.precision)) if tfw else None,
+                     "pipeline": a.pipeline if w != "depth_128_64" else 0, "what": WORKLOADS[w][2]}
+            del st, nets_w, sc, tm
+            torch.cuda.empty_cache()
+        extra["workloads"] = wl
+        # -- north_star's MLP benchmark, every precision
+        extra["mlp_only_65536x192"] = leg_mlp_only(P, dev)
+        # -- one full frame through render(c2w=...)
+        extra["frame_800x800"] = leg_frame(P, dev, a.precision)
+        # -- "PSNR vs ref" (BASELINE.json's metric, second half): the benchmarked arithmetic against the exact-fp32 kernels
+        if a.precision != "fp32" and a.psnr_steps > 0:
+            from tools.scene import psnr_vs_ref
+            extra["psnr_vs_ref"] = psnr_vs_ref(P, dev, a.psnr_steps, rays=R, precision=a.precision, pipeline=a.pipeline)
+            torch.cuda.empty_cache()
+
     # the all-reduce as the launch stream sees it: HIP events on that stream either side of GradientBucket.allreduce_mean
     # (wait for the two collectives enqueued during the backward + the 1/world scaling) = the EXPOSED part of the exchange
     if cpu:
@@ -524,6 +635,7 @@ def main(argv=None):
         }
         if strict is not None:
             out["strict_fp32"] = strict
+        out.update(extra)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a)
         # RCCL writes its version banner through C stdio, which is block-buffered on a pipe and would otherwise

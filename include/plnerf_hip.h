@@ -241,7 +241,7 @@ int plnerf_coarse_samples(const float* rays_o, const float* rays_d, const float*
  * image alone; needs rgb0 == NULL): its [1] is taken as the coarse term -- a caller that runs the coarse network's
  * loss and backward ahead of the fine pass (the two sums of :1296 are independent) still gets the reference's total.
  * workspace: PLNERF_IMAGE_LOSS_WORKSPACE_BYTES, zeroed by the caller ONCE (each launch leaves it zeroed; one per
- * stream that launches concurrently).  Deterministic (fp64 partial sums added in workgroup order). */
+ * stream that launches concurrently, and not shared with plnerf_depth_loss, which lays its own out differently).  Deterministic (fp64 partial sums added in workgroup order). */
 #define PLNERF_IMAGE_LOSS_WORKSPACE_BYTES 4096
 int plnerf_image_loss(const float* rgb, const float* rgb0, const float* target, int R, float* loss3,
                       float* g_rgb, float* g_rgb0, const float* coarse_loss, void* workspace,

@@ -555,6 +555,10 @@ extern "C" int plnerf_embed_rows(const float* pts, const float* viewdirs, const 
                 bb_center_host ? bb_center_host[2] : 0.0f, bb_scale, embedded};
     const int C = 3 + 6 * n_freqs_xyz + (viewdirs ? 3 + 6 * n_freqs_dir + n_cam : 0);
     const size_t lds = (size_t)EMB_ROWS * C * sizeof(float);
+    // (C reaches 262 at the widest admitted arguments: 67 KB, beyond the 64 KB a launch may ask for without this)
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)embed_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PLNERF_EINVAL;
     hipLaunchKernelGGL(embed_rows_kernel, dim3((n_rows + EMB_ROWS - 1) / EMB_ROWS), dim3(256), lds, (hipStream_t)stream, a);
     PLNERF_CHECK_LAUNCH();
     return PLNERF_OK;

@@ -59,6 +59,28 @@ def _kernel_encoding(embed_fn, embeddirs_fn, viewdirs):
     return fx[0], fd[0], (scales.pop() if scales else 1.0)
 
 
+_BOX_CACHE = {}
+
+
+def _host_box(bb_center, bb_scale):
+    """The bounding-box affine as host floats ((cx, cy, cz), scale, is-identity).  The reference script keeps the box as
+    device tensors (run_nerf_sample_based_depth.py:52-56); reading them costs a host synchronisation, which must not
+    happen on every network evaluation of a training step: resolved once per (tensor, version)."""
+    def key(x):
+        return (id(x), x._version) if isinstance(x, torch.Tensor) else ("v", repr(x))
+    k = (key(bb_center), key(bb_scale))
+    hit = _BOX_CACHE.get(k)
+    if hit is None:
+        c = torch.as_tensor(bb_center, dtype=torch.float32).reshape(-1).cpu()
+        center = tuple(float(c[i if c.numel() == 3 else 0]) for i in range(3))
+        scale = float(torch.as_tensor(bb_scale))
+        hit = (center, scale, scale == 1.0 and not any(center))
+        if len(_BOX_CACHE) > 64:
+            _BOX_CACHE.clear()
+        _BOX_CACHE[k] = hit
+    return hit
+
+
 def run_network(inputs, viewdirs, embedded_cam, fn, embed_fn, embeddirs_fn, bb_center, bb_scale, netchunk=1024 * 64):
     """run_nerf_sample_based_depth.py:52-68: bounding-box affine, encodings (positions | per-ray direction | per-image
     camera code, each repeated over the ray's samples), then the MLP in row chunks.  inputs [R, S, 3].
@@ -79,7 +101,7 @@ def run_network(inputs, viewdirs, embedded_cam, fn, embed_fn, embeddirs_fn, bb_c
     if enc is not None and not (torch.is_grad_enabled() and (inputs.requires_grad or
                                                              (viewdirs is not None and viewdirs.requires_grad))):
         fx, fd, scale = enc
-        identity_box = float(torch.as_tensor(bb_scale)) == 1.0 and not bool(torch.as_tensor(bb_center).any())
+        bb_center, bb_scale, identity_box = _host_box(bb_center, bb_scale)      # (host floats: no sync per evaluation)
         if (cam is None and identity_box and fn.has_fused_encoding() and fn.input_ch == 3 + 6 * fx and
                 (not fn.use_viewdirs or fn.input_ch_views == 3 + 6 * fd)):
             # the encoding in the MLP kernel's own prologue, as on the NVS path: no `embedded` matrix at all

@@ -290,10 +290,11 @@ class CoarseEpilogueFn(torch.autograd.Function):
 _LOSS_WS = {}
 
 
-def _loss_workspace(device, nbytes):
-    """The loss kernels' partial sums and ticket counter: zeroed once per (device, stream), left zeroed by every launch
-    (two streams may run a loss kernel at the same time: one workspace each)."""
-    key = (device, L.stream().value, nbytes)
+def _loss_workspace(device, nbytes, kernel):
+    """A loss kernel's partial sums and ticket counter: zeroed once per (kernel, device, stream), left zeroed by every
+    launch of THAT kernel (each lays its partials and its ticket out differently; two streams may run one at the same
+    time: one workspace each)."""
+    key = (kernel, device, L.stream().value, nbytes)
     ws = _LOSS_WS.get(key)
     if ws is None:
         ws = _LOSS_WS[key] = torch.zeros(nbytes // 8, device=device, dtype=torch.float64)
@@ -308,7 +309,7 @@ def _image_loss(rgb, rgb0, target, coarse_loss=None):
     loss4 = torch.empty(4, device=rgb_c.device)
     g1 = torch.empty_like(rgb_c)
     g0 = None if rgb0_c is None else torch.empty_like(rgb_c)
-    ws = _loss_workspace(rgb_c.device, L.IMAGE_LOSS_WORKSPACE_BYTES)
+    ws = _loss_workspace(rgb_c.device, L.IMAGE_LOSS_WORKSPACE_BYTES, "image")
     L.check(L.lib().plnerf_image_loss(L.dptr(rgb_c, "rgb"), L.dptr(rgb0_c, "rgb0"), L.dptr(t_c, "target"),
                                       rgb_c.shape[0], L.dptr(loss4), L.dptr(g1), L.dptr(g0), L.dptr(coarse_loss, "coarse_loss"),
                                       L.dptr(ws, "workspace", torch.float64), L.stream()), "plnerf_image_loss")
@@ -651,8 +652,11 @@ def embed_rows(pts, viewdirs, cam, n_freqs_xyz, n_freqs_dir, input_scale=1.0, bb
     n_cam = 0 if cam_c is None else cam_c.numel()
     C = 3 + 6 * n_freqs_xyz + (0 if vd_c is None else 3 + 6 * n_freqs_dir + n_cam)
     out = torch.empty(R * S, C, device=pts_c.device)
-    c = torch.as_tensor(bb_center, dtype=torch.float32).reshape(-1).cpu()
-    center = (ctypes.c_float * 3)(*[float(c[i if c.numel() == 3 else 0]) for i in range(3)])
+    if isinstance(bb_center, (tuple, list)) and len(bb_center) == 3:      # (host floats: no device read)
+        center = (ctypes.c_float * 3)(*[float(v) for v in bb_center])
+    else:
+        c = torch.as_tensor(bb_center, dtype=torch.float32).reshape(-1).cpu()
+        center = (ctypes.c_float * 3)(*[float(c[i if c.numel() == 3 else 0]) for i in range(3)])
     L.check(L.lib().plnerf_embed_rows(L.dptr(pts_c, "pts"), L.dptr(vd_c, "viewdirs"), L.dptr(cam_c, "cam"), R * S, S,
                                       int(n_freqs_xyz), int(n_freqs_dir), n_cam, float(input_scale), center,
                                       float(bb_scale), L.dptr(out), L.stream()), "plnerf_embed_rows")
@@ -679,7 +683,7 @@ def depth_loss_and_grads(rgb, rgb0, target, pred_hyp, target_h, weight, threshol
     loss5 = torch.empty(5, device=rgb_c.device)
     g1 = torch.empty_like(rgb_c)
     g0 = None if rgb0_c is None else torch.empty_like(rgb_c)
-    ws = _loss_workspace(rgb_c.device, L.DEPTH_LOSS_WORKSPACE_BYTES)
+    ws = _loss_workspace(rgb_c.device, L.DEPTH_LOSS_WORKSPACE_BYTES, "depth")
     L.check(L.lib().plnerf_depth_loss(L.dptr(rgb_c, "rgb"), L.dptr(rgb0_c, "rgb0"), L.dptr(t_c, "target"),
                                       L.dptr(hyp_c, "pred_hyp"), L.dptr(th_c, "target_h"), L.dptr(mask_c, "mask"), R, P, H,
                                       PT, float(weight), float(threshold), L.dptr(loss5), L.dptr(g1), L.dptr(g0),

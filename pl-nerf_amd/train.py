@@ -115,17 +115,22 @@ class TrainStep:
     def __init__(self, args, render_kwargs_train, optimizer, optimizer_coarse, start=0, distributed=None, seed=0,
                  counter_rng=True, range_check_every=100, pipeline=None):
         """pipeline: how the step's two independent chains are scheduled (functional.CoarseChain).
-          0  one stream, the reference's order: render, loss, backward, both optimizers.
+          0  (default; PLNERF_PIPELINE in the environment overrides) one stream, the reference's order: render, loss,
+             backward, both optimizers.
           1  the coarse network's loss / backward / gradient exchange / optimizer step on a second HIP stream as soon as
              the coarse pass is rendered, next to the fine pass on the launch stream (HBM-bound backward next to the
              MFMA-bound forward); the second stream starts behind whatever the launch stream holds at the step's start.
              When the step returns, everything it did is ordered before whatever the caller enqueues on the launch stream
-             next.  (Default on the GPU with two networks; PLNERF_PIPELINE in the environment overrides.)
+             next.
           2  the same, and in `step_view` -- where the step owns its inputs from the pixel choice on -- the coarse stream
              never waits for the launch stream: the next step's coarse pass (which needs the coarse weights only)
              overlaps this step's fine backward.  Every step still computes exactly the reference's step, but the coarse
              network's weights and optimizer state belong to the coarse stream between steps: read or write them from
-             outside (save / load a checkpoint, evaluate, ...) only after `drain()`.  bench.py runs this mode."""
+             outside (save / load a checkpoint, evaluate, ...) only after `drain()`.
+        Same-box A/B at BASELINE configs[1] (profiles/r04_pipeline_ab.txt): 1 is 1.3 % slower, 2 is 0.8 % faster than 0, all
+        three bit-identical -- both forward kernels and the weight-gradient kernel each fill a CU on their own (144 / 147
+        KB of LDS, 512 registers per SIMD), so two kernels "overlap" by taking CUs from each other, not by sharing them:
+        the fine forward's launch stretches from 2.16 to 3.09 ms by exactly the coarse backward's own 0.9 ms."""
         self.args = args
         self.kw = render_kwargs_train
         self.optimizer = optimizer
@@ -142,7 +147,7 @@ class TrainStep:
         self.range_check_every = int(range_check_every)
         self.seed = seed
         if pipeline is None:
-            pipeline = int(os.environ.get("PLNERF_PIPELINE", "1"))
+            pipeline = int(os.environ.get("PLNERF_PIPELINE", "0"))
         fine = self.kw.get("network_fine")
         coarse = self.kw["network_fn"]
         two_nets = fine is not None and fine is not coarse and next(fine.parameters()).is_cuda and \

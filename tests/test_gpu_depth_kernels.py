@@ -28,7 +28,10 @@ def P():
     return plnerf_amd
 
 
-@pytest.mark.parametrize("cfg", [(9, 0, np.pi, 0), (9, 0, np.pi, 4), (10, 4, 1.0, 0), (3, 2, np.pi, 2), (0, 0, 1.0, 0)])
+# (the last case: the widest row the entry point admits -- 262 channels, 67 KB of LDS per workgroup, beyond the 64 KB a
+# launch gets without hipFuncAttributeMaxDynamicSharedMemorySize; a float's sin / cos at 2^15 x is still exact enough)
+@pytest.mark.parametrize("cfg", [(9, 0, np.pi, 0), (9, 0, np.pi, 4), (10, 4, 1.0, 0), (3, 2, np.pi, 2), (0, 0, 1.0, 0),
+                                 (16, 16, 1.0, 64)])
 def test_embed_rows_matches_the_reference_expressions(P, cfg):
     from plnerf_amd import functional as Fn
     fx, fd, scale, n_cam = cfg
@@ -55,11 +58,11 @@ def test_embed_rows_matches_the_reference_expressions(P, cfg):
     assert got.shape == want.shape
     err = float((got - want).abs().max())
     print(f"embed_rows fx={fx} fd={fd} scale={scale:.3f} cam={n_cam}: max err {err:.2e}")
-    assert err <= 5e-7
+    assert err <= (5e-7 if fx <= 10 else 2e-2)          # (band 2^15: the ARGUMENT's own rounding is ~2e-3 rad there)
     assert torch.equal(got[:, :3], want[:, :3])         # the affine and the identity block: bit-equal
     # positions only (no view directions)
     got_x = Fn.embed_rows(g(pts), None, None, fx, 0, input_scale=scale, bb_center=center, bb_scale=bscale).cpu()
-    assert got_x.shape[1] == 3 + 6 * fx and float((got_x - want[:, :3 + 6 * fx]).abs().max()) <= 5e-7
+    assert got_x.shape[1] == 3 + 6 * fx and float((got_x - want[:, :3 + 6 * fx]).abs().max()) <= (5e-7 if fx <= 10 else 2e-2)
 
 
 @pytest.mark.parametrize("case", ["full", "no_coarse", "target_per_point", "mask_threshold", "no_depth_term"])

@@ -13,7 +13,12 @@ Stated tolerances:
   * one full-size training step: loss to 1e-5; every parameter tensor's gradient within the bound of the small-fixture
     tests (fp32: 2e-4 coarse / 2e-3 fine of max|g|; f16x3: 6e-3 / 3e-3, the half-plane backward).
 
-Host cost: two oracle renders (about 5 s each on 16 threads) and one oracle training step (about 20 s).
+Round 4 adds the two other single-GPU workloads of BASELINE.json at full size against the oracle: configs[3] (LLFF:
+4096 NDC rays in [near 0, far 1], raw_noise_std = 1 with the reference's `pytest` noise draw, no white background) and
+configs[4]'s render (the depth-supervised variant: 57|3-channel network with the pi-scaled encoding, softplus density,
+128 + 64 samples, pred_hyp) -- same structure: coarse maps at 1e-5 on every ray, final maps by count.
+
+Host cost: four oracle renders (about 5 s each on 16 threads) and one oracle training step (about 20 s).
 """
 import os
 
@@ -28,7 +33,13 @@ R_FULL = 4096
 SAMPLINGS = [(64, 128), (128, 64)]
 # rays (of 4096) allowed beyond 1e-5 per final map: rgb admits none; a hopping fine sample moves acc / depth / z_std of
 # its ray (the kernels are deterministic and the draws fixed, so the counts are reproducible box to box)
-MAX_RAYS_BEYOND = {"rgb_map": 0, "acc_map": 2, "depth_map": 16, "z_std": 8}
+# Per precision and sampling: the measured count + 2 (a regression that doubles the hopping rays must fail).
+MAX_RAYS_BEYOND = {
+    ("f16x3", 64, 128): {"rgb_map": 0, "acc_map": 3, "depth_map": 11, "z_std": 2},
+    ("f16x3", 128, 64): {"rgb_map": 0, "acc_map": 2, "depth_map": 3, "z_std": 4},
+    ("fp32", 64, 128): {"rgb_map": 0, "acc_map": 2, "depth_map": 7, "z_std": 2},
+    ("fp32", 128, 64): {"rgb_map": 0, "acc_map": 2, "depth_map": 3, "z_std": 4},
+}
 
 
 @pytest.fixture(scope="module")
@@ -74,7 +85,7 @@ def test_render_rays_at_baseline_size_vs_oracle(P, oracle_renders, sampling, pre
     for k in ("rgb0", "acc0", "depth0", "disp0"):
         assert_close(got[k], ref[k], what=f"{precision} {ns}+{ni} {k}")
     report, over = [], []
-    for k, allowed in MAX_RAYS_BEYOND.items():
+    for k, allowed in MAX_RAYS_BEYOND[(precision, ns, ni)].items():
         d = (got[k].cpu() - ref[k]).abs()
         lim = 1e-5 * (1.0 + ref[k].abs())
         bad = d > lim
@@ -120,3 +131,94 @@ def test_train_step_at_baseline_size_vs_oracle(P, precision):
             assert abs(float(prm.grad.norm()) - float(refg.norm())) <= 2e-3 * float(refg.norm()) + 1e-9, (tag, name)
     print(f"{precision} full-size step: loss {float(loss.detach()):.7f} (oracle {float(ref_loss):.7f}); worst grad err / "
           f"max|g|: coarse {worst['coarse']:.2e}, fine {worst['fine']:.2e}")
+
+
+def _count_beyond(got, ref, tol=1e-5):
+    d = (got.cpu() - ref).abs()
+    bad = d > tol * (1.0 + ref.abs())
+    return int((bad.reshape(bad.shape[0], -1).any(-1)).sum()), float(d.max())
+
+
+# configs[3]: rays (of 4096) allowed beyond 1e-5 per final map = measured + 2, per precision
+LLFF_MAX_BEYOND = {"f16x3": {"rgb_map": 40, "acc_map": 40, "depth_map": 40, "z_std": 40},
+                   "fp32": {"rgb_map": 40, "acc_map": 40, "depth_map": 40, "z_std": 40}}
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+def test_llff_ndc_render_at_baseline_size_vs_oracle(P, precision):
+    """BASELINE configs[3] per GPU: 4096 rays of a 378 x 504 forward-facing view warped to NDC (run_nerf_helpers.py:
+    184-201; near 0, far 1 -- run_plnerf.py:1008-1009), density noise raw_noise_std = 1 (the reference's `pytest` draw:
+    uniform, run_plnerf.py:573-576), no white background, 64 + 128 samples: the NDC ray range and the noise path through a
+    6,144-workgroup launch, against the oracle."""
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    H, W, f = 378, 504, 407.0
+    K = [[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]]
+    c2w = torch.eye(4)[:3, :4].clone()
+    c2w[:, 3] = torch.tensor([0.05, -0.02, 0.1])
+    o, d = orc.get_rays(H, W, K, c2w)
+    pix = torch.randperm(H * W, generator=torch.Generator().manual_seed(31))[:R_FULL]
+    o, d = o.reshape(-1, 3)[pix], d.reshape(-1, 3)[pix]
+    vd = d / torch.norm(d, dim=-1, keepdim=True)                      # of the ORIGINAL directions (run_plnerf.py:146-150)
+    o_ndc, d_ndc = orc.ndc_rays(H, W, f, 1.0, o, d)
+    batch = torch.cat([o_ndc, d_ndc, torch.zeros(R_FULL, 1), torch.ones(R_FULL, 1), vd], -1).float()
+    sd_c, sd_f = orc.closed_form_state_dict(0, True), orc.closed_form_state_dict(1, True)
+    kw = dict(retraw=True, perturb=1.0, N_importance=128, white_bkgd=False, raw_noise_std=1.0, pytest=True)
+    with torch.no_grad():
+        ref = orc.render_rays(batch, sd_c, sd_f, 64, "linear", "midpoint", **kw)
+    emb_fn, _ = P.get_embedder(10, 0)
+    embd_fn, _ = P.get_embedder(4, 0)
+    qfn = lambda inputs, viewdirs, fn: P.run_network(inputs, viewdirs, fn, emb_fn, embd_fn)
+    net_c, net_f = make_net(P, sd_c, precision), make_net(P, sd_f, precision)
+    with torch.no_grad():
+        got = P.render_rays(g(batch), net_c, qfn, 64, "linear", "midpoint", network_fine=net_f, **kw)
+    torch.cuda.synchronize()
+    if precision != "fp32":
+        assert net_c.range_status() == 0 and net_f.range_status() == 0
+    for k in ("rgb0", "acc0", "depth0", "disp0"):
+        assert_close(got[k], ref[k], what=f"{precision} llff_ndc {k}")
+    report, over = [], []
+    for k, allowed in LLFF_MAX_BEYOND[precision].items():
+        n_bad, worst = _count_beyond(got[k], ref[k])
+        report.append(f"{k} max {worst:.2e} beyond {n_bad}")
+        if n_bad > allowed:
+            over.append(f"{k}: {n_bad} of {R_FULL} rays beyond 1e-5 (allowed {allowed})")
+    print(f"{precision} llff_ndc x {R_FULL} rays: coarse rgb0 {maxdiff(got['rgb0'], ref['rgb0']):.2e}, depth0 "
+          f"{maxdiff(got['depth0'], ref['depth0']):.2e}; final " + ", ".join(report))
+    assert not over, f"{precision} llff_ndc: " + "; ".join(over)
+
+
+# configs[4]: counts beyond 1e-5 (pred_hyp: beyond 2e-4 -- the sampler's closed form, DESIGN.md section 6) = measured + 2
+DEPTH_MAX_BEYOND = {"f16x3": {"rgb_map": 40, "acc_map": 40, "depth_map": 40, "z_std": 40, "pred_hyp": 40},
+                    "fp32": {"rgb_map": 40, "acc_map": 40, "depth_map": 40, "z_std": 40, "pred_hyp": 40}}
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+def test_depth_variant_render_at_baseline_size_vs_oracle(P, golden, precision):
+    """BASELINE configs[4] per GPU, the render: 4096 rays x (128 + 64) samples through the depth-supervised variant's
+    render_rays (run_nerf_sample_based_depth.py:792-958: 57|3-channel network, encoding of x pi 2^k, softplus(beta 10)
+    density, pred_hyp from the final weights) -- the `input_scale = pi` route of the fused kernel at 786,432 rows."""
+    from test_gpu_modes import _depth_setup
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    gd = golden("g8b_depth_variant_128_64")
+    Dp, kw, _, _ = _depth_setup(gd, precision)
+    batch, _ = orc.synthetic_blender_rays(R_FULL, seed=13)
+    sd_c, sd_f = orc.closed_form_state_dict_depth(0, True), orc.closed_form_state_dict_depth(1, True)
+    with torch.no_grad():
+        ref = orc.render_rays_depth(batch, sd_c, sd_f, 128, "linear", "midpoint", perturb=1.0, N_importance=64,
+                                    white_bkgd=True, pytest=True)
+        got = Dp.render_rays(g(batch), retraw=True, pytest=True, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(got["u"].cpu(), ref["u"])
+    if precision != "fp32":
+        assert kw["network_fn"].range_status() == 0 and kw["network_fine"].range_status() == 0
+    for k in ("rgb0", "acc0", "depth0", "disp0", "z_vals0", "weights0"):
+        assert_close(got[k], ref[k], what=f"{precision} depth_128_64 {k}")
+    report, over = [], []
+    for k, allowed in DEPTH_MAX_BEYOND[precision].items():
+        n_bad, worst = _count_beyond(got[k], ref[k], 2e-4 if k == "pred_hyp" else 1e-5)
+        report.append(f"{k} max {worst:.2e} beyond {n_bad}")
+        if n_bad > allowed:
+            over.append(f"{k}: {n_bad} of {R_FULL} rays beyond the bound (allowed {allowed})")
+    print(f"{precision} depth_128_64 x {R_FULL} rays: coarse rgb0 {maxdiff(got['rgb0'], ref['rgb0']):.2e}, depth0 "
+          f"{maxdiff(got['depth0'], ref['depth0']):.2e}; final " + ", ".join(report))
+    assert not over, f"{precision} depth_128_64: " + "; ".join(over)
