@@ -238,10 +238,9 @@ def build_step(P, a, precision, scene, dev, rank, world, force_dist):
         args = depth_args(a, precision)
         kw, _, _, grad_vars, opt = Dp.create_nerf(args, device=dev)
         nets = [kw["network_fn"], kw["network_fine"]]
-        ts = Dp.DepthTrainStep(args, kw, opt, grad_vars, distributed=world > 1)
+        ts = Dp.DepthTrainStep(args, kw, opt, grad_vars, distributed=world > 1, seed=0)      # (counter-based draws: sharding-invariant)
         if force_dist and world == 1:
             ts.bucket = dp.GradientBucket(nets)
-        torch.manual_seed(1000 + rank)     # this variant draws with torch.rand: decorrelate the ranks' draws
 
         def step(i):
             v = i % len(scene.poses)

@@ -196,6 +196,21 @@ int plnerf_coarse_epilogue(const float* raw, const float* z, const float* near, 
                            float* tau, float* T, float* z_fine, float* pts, float* z_std,
                            plnerf_stream_t stream);
 
+/* The depth-supervised variant's LAST stage as one launch (depth_supervised_exps/run_nerf_sample_based_depth.py:
+ * 909-934, piecewise-linear mode): raw2outputs of the final pass, then sample_pdf_reformulation_return_u on ITS
+ * weights / tau / T -> the depth hypotheses pred_hyp (not clamped), and z_std = std(pred_hyp, unbiased=False).
+ * Bit-identical to plnerf_quad_fwd followed by plnerf_sample_pl on the same inputs.  Outputs as plnerf_quad_fwd
+ * (weights [R,S+1], tau, T [R,S+2]: the sampler's backward and the caller need them) plus samples [R,N],
+ * inds [R,N] and -- if u_out is given -- the draws used [R,N].  u as in plnerf_coarse_epilogue (NULL: drawn in the
+ * kernel, counter stream 4).  Backward: plnerf_sample_pl_bwd, then plnerf_quad_bwd with its g_tau / g_T. */
+int plnerf_fine_epilogue(const float* raw, const float* z, const float* near, const float* far,
+                         const float* rays_d, const float* noise, const float* u, int u_row_stride,
+                         uint64_t seed, uint32_t step, int ray_id0, int R, int S, int N, int color_mode,
+                         int white_bkgd, int farcolorfix, float zero_tol, float epsilon, float* rgb_map,
+                         float* disp_map, float* acc_map, float* depth_map, float* weights, float* tau,
+                         float* T, float* samples, int64_t* inds, float* u_out, float* z_std,
+                         plnerf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * The caller side of the path (run_plnerf.py:1259-1296), device-side.
  *
@@ -250,9 +265,11 @@ int plnerf_image_loss(const float* rgb, const float* rgb0, const float* target, 
 /* The depth-supervised loop's loss (depth_supervised_exps/run_nerf_sample_based_depth.py:1126-1150):
  *   total = img2mse(rgb, target) + space_carving_weight * compute_space_carving_loss(pred_hyp, target_h)
  *           + img2mse(rgb0, target)
- * with compute_space_carving_loss of depth_supervised_exps/model/run_nerf_helpers.py:52-86 in its per-ray form
- * (is_joint = False): distances[h, r, p] = mask[r] * |pred_hyp[r, p] - target_h[h, r, p]|, zeroed below `threshold`
- * (> 0), min over the n_hyp hypotheses, mean over points and rays.
+ * with compute_space_carving_loss of depth_supervised_exps/model/run_nerf_helpers.py:52-86:
+ * distances[h, r, p] = mask[r] * |pred_hyp[r, p] - target_h[h, r, p]|, zeroed below `threshold` (> 0); then
+ * is_joint = 0 (:79-84): min over the n_hyp hypotheses per ray and point, mean over points and rays;
+ * is_joint != 0 (:72-77): mean over the rays first, min over the hypotheses per POINT column (the hypothesis is chosen
+ * per image), mean over the points.
  * pred_hyp [R, n_points]; target_h [n_hyp, R, target_points] with target_points = 1 or n_points; mask [R] or NULL.
  * loss5 [5] = {total, image (fine), image (coarse), space carving (unweighted), psnr of the fine image term};
  * g_rgb, g_rgb0 [R, 3], g_hyp [R, n_points] = d total / d (rgb, rgb0, pred_hyp).  rgb0 and pred_hyp may be NULL
@@ -262,8 +279,8 @@ int plnerf_image_loss(const float* rgb, const float* rgb0, const float* target, 
 #define PLNERF_DEPTH_LOSS_WORKSPACE_BYTES 4096
 int plnerf_depth_loss(const float* rgb, const float* rgb0, const float* target, const float* pred_hyp,
                       const float* target_h, const float* mask, int R, int n_points, int n_hyp, int target_points,
-                      float space_carving_weight, float threshold, float* loss5, float* g_rgb, float* g_rgb0,
-                      float* g_hyp, void* workspace, plnerf_stream_t stream);
+                      int is_joint, float space_carving_weight, float threshold, float* loss5, float* g_rgb,
+                      float* g_rgb0, float* g_hyp, void* workspace, plnerf_stream_t stream);
 
 /* run_network's input assembly for a caller-side encoding (depth_supervised_exps/run_nerf_sample_based_depth.py:52-68
  * with the Embedder of depth_supervised_exps/model/run_nerf_helpers.py:100-130; input_scale = 1 gives the NVS
@@ -325,23 +342,31 @@ int plnerf_mlp_saved_layout(int precision, int has_embedded, int fwd_kernel);
  * depth_supervised_exps/model/run_nerf_helpers.py:100-130, arguments evaluated as fl(fl(x pi) 2^k)) -- or
  * embedded [n_rows, input_ch + input_ch_views] (a caller-supplied encoding; NeRF.forward's
  * own signature).  saved == NULL for inference.  raw_out [n_rows,4].  fwd_kernel: PLNERF_FWD_KERNEL_* (pass the same
- * value to plnerf_mlp_saved_layout). */
+ * value to plnerf_mlp_saved_layout).
+ * density_beta: 0 = the four channels leave as the network computes them (run_nerf_helpers.py:124); > 0 = the density
+ * channel leaves as softplus_beta(sigma) = log(1 + exp(beta sigma)) / beta (beta sigma > 20: sigma) -- the NeRF of the
+ * depth-supervised variant, F.softplus(alpha, beta=10), depth_supervised_exps/model/run_nerf_helpers.py:200 -- in the
+ * kernel's last store instead of three element-wise launches behind it. */
 int plnerf_mlp_fwd(const void* packed, int precision, const float* pts, const float* viewdirs,
                    const float* embedded, int input_ch, int input_ch_views, int n_rows,
-                   int samples_per_ray, float input_scale, float* raw_out, void* saved, int fwd_kernel,
-                   plnerf_stream_t stream);
+                   int samples_per_ray, float input_scale, float density_beta, float* raw_out, void* saved,
+                   int fwd_kernel, plnerf_stream_t stream);
 
 /* Backward: g_raw [n_rows,4] -> gradients of all 24 parameter tensors, written (not
  * accumulated) to grads[24] (device pointers, same shapes as params).  Needs the `saved`
  * buffer of the matching forward call and a workspace of
  * plnerf_mlp_bwd_workspace_bytes().  Inputs (pts / viewdirs) receive no gradient, as on
  * the reference path (they do not depend on parameters; z_samples is detached,
- * run_plnerf.py:728).  status_out (may be NULL): one float, set to 1 if the network's range status word
+ * run_plnerf.py:728).  density_beta / raw_out: the forward's density activation and ITS OUTPUT [n_rows,4] (needed when
+ * density_beta > 0, else may be NULL): g_raw is then the gradient with respect to the activated output, and the
+ * activation's derivative sigmoid(beta sigma) = 1 - exp(-beta raw_out[., 3]) is applied on entry (into the workspace:
+ * g_raw itself is not written).  status_out (may be NULL): one float, set to 1 if the network's range status word
  * (plnerf_mlp_status_offset) is non-zero when the gradients are complete, else 0 -- a data-parallel caller puts it
  * behind the gradients in the buffer it all-reduces (SUM), so "some rank's forward left the half range" reaches
  * every rank with the gradient itself and can guard plnerf_adam_step there. */
 int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, int input_ch,
-                   int input_ch_views, int n_rows, const void* saved, int saved_layout, void* workspace,
+                   int input_ch_views, int n_rows, const void* saved, int saved_layout,
+                   const float* raw_out, float density_beta, void* workspace,
                    float* const* grads, float* status_out, plnerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------

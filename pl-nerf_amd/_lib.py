@@ -47,6 +47,8 @@ SIGNATURES = {
     "plnerf_merge_sort": (c_i, [c_f] * 4 + [c_i] * 3 + [c_f] + [c_s]),
     "plnerf_coarse_epilogue": (c_i, [c_f] * 8 + [c_i, ctypes.c_uint64, ctypes.c_uint32] + [c_i] * 7 +
                                [ctypes.c_float] * 2 + [c_f] * 10 + [c_s]),
+    "plnerf_fine_epilogue": (c_i, [c_f] * 7 + [c_i, ctypes.c_uint64, ctypes.c_uint32] + [c_i] * 7 + [ctypes.c_float] * 2 +
+                             [c_f] * 11 + [c_s]),
     "plnerf_uniform": (c_i, [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_i, c_i, c_i, c_f, c_s]),
     "plnerf_normal": (c_i, [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_i, c_i, c_i, c_f, c_s]),
     "plnerf_select_rays": (c_i, [c_i, c_i] + [ctypes.c_float] * 4 + [ctypes.POINTER(ctypes.c_float), c_f] + [c_i] * 4 +
@@ -54,15 +56,16 @@ SIGNATURES = {
                            [c_s]),
     "plnerf_coarse_samples": (c_i, [c_f] * 6 + [ctypes.c_uint64, ctypes.c_uint32] + [c_i] * 5 + [c_f] * 2 + [c_s]),
     "plnerf_image_loss": (c_i, [c_f] * 3 + [c_i] + [c_f] * 5 + [c_s]),
-    "plnerf_depth_loss": (c_i, [c_f] * 6 + [c_i] * 4 + [ctypes.c_float] * 2 + [c_f] * 5 + [c_s]),
+    "plnerf_depth_loss": (c_i, [c_f] * 6 + [c_i] * 5 + [ctypes.c_float] * 2 + [c_f] * 5 + [c_s]),
     "plnerf_embed_rows": (c_i, [c_f] * 3 + [c_i] * 5 + [ctypes.c_float, ctypes.POINTER(ctypes.c_float), ctypes.c_float,
                                 c_f, c_s]),
     "plnerf_mlp_packed_bytes": (ctypes.c_size_t, [c_i]),
     "plnerf_mlp_pack_weights": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_i, c_i, c_i, c_f, c_s]),
     "plnerf_mlp_saved_bytes": (ctypes.c_size_t, [c_i, c_i]),
     "plnerf_mlp_bwd_workspace_bytes": (ctypes.c_size_t, [c_i, c_i]),
-    "plnerf_mlp_fwd": (c_i, [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_float, c_f, c_f, c_i, c_s]),
-    "plnerf_mlp_bwd": (c_i, [c_f, c_i, c_f, c_i, c_i, c_i, c_f, c_i, c_f, ctypes.POINTER(ctypes.c_void_p), c_f, c_s]),
+    "plnerf_mlp_fwd": (c_i, [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_float, ctypes.c_float, c_f, c_f, c_i, c_s]),
+    "plnerf_mlp_bwd": (c_i, [c_f, c_i, c_f, c_i, c_i, c_i, c_f, c_i, c_f, ctypes.c_float, c_f, ctypes.POINTER(ctypes.c_void_p), c_f,
+                             c_s]),
     "plnerf_mlp_saved_layout": (c_i, [c_i, c_i, c_i]),
     "plnerf_adam_step": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_int64] + [ctypes.c_float] * 4 + [c_i, ctypes.c_float, ctypes.c_float,
                                 c_f, c_f, c_f, c_s]),

@@ -25,6 +25,19 @@ __device__ __forceinline__ float tmin(float a, float b) {
     return (a != a || b != b) ? __builtin_nanf("") : (a < b ? a : b);
 }
 
+// The density activation of the depth-supervised variant (depth_supervised_exps/model/run_nerf_helpers.py:200:
+// F.softplus(sigma, beta=10)), torch's formula and threshold: x beta > 20 ? x : log1p(exp(x beta)) / beta.
+// beta <= 0: no activation.
+__device__ __forceinline__ float density_activation(const float x, const float beta) {
+    if (!(beta > 0.0f)) return x;
+    const float bx = x * beta;
+    return bx > 20.0f ? x : log1pf(expf(bx)) / beta;
+}
+// d softplus / dx = sigmoid(beta x), from the activation's OUTPUT y: 1 - exp(-beta y)  (exp(beta y) = 1 + exp(beta x))
+__device__ __forceinline__ float density_activation_grad(const float y, const float beta) {
+    return beta > 0.0f ? -expm1f(-beta * y) : 1.0f;
+}
+
 // Inclusive wave scans over 64 lanes (Hillis-Steele on __shfl_up, which lowers to
 // DPP row shifts / ds_bpermute on gfx950).
 __device__ __forceinline__ double wave_incl_prod(double v) {

@@ -42,9 +42,17 @@ struct EpiArgs {
     float* z_fine;           // [R, S+N]
     float* pts;              // [R, S+N, 3]
     float* z_std;            // [R]
+    // hypothesis mode (HYP: the depth-supervised variant's final stage, plnerf_fine_epilogue): the samples themselves
+    float* samples;          // [R, N], NOT clamped
+    int64_t* inds;           // [R, N] searchsorted indices (plnerf_sample_pl_bwd wants them)
+    float* u_out;            // [R, N] the draws used (the variant's render_rays returns them)
 };
 
-template <int KPL>
+// HYP = false: the coarse pass's epilogue (samples clamped, merged, sorted, turned into positions).
+// HYP = true: raw2outputs + the *_return_u sampler of the depth-supervised variant's LAST stage
+// (run_nerf_sample_based_depth.py:923-934): the samples are the depth hypotheses pred_hyp -- not clamped, kept with their
+// indices and draws for the sampler's backward -- and z_std is theirs (:934); nothing is sorted or positioned.
+template <int KPL, bool HYP>
 __global__ __launch_bounds__(256) void coarse_epilogue_kernel(const EpiArgs a) {
     constexpr int MODE = PLNERF_MODE_LINEAR;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -138,7 +146,15 @@ __global__ __launch_bounds__(256) void coarse_epilogue_kernel(const EpiArgs a) {
         if (d >= zt) out = invert_segment(s0, s1, T0, tau0, tau1, u, eps, true);
         if (d <= -zt) out = invert_segment(s0, s1, T0, tau0, tau1, u, eps, false);
         if (out != out) out = s0;
-        out = tmin(tmax(out, lo), hi);            // torch.clamp(z_samples, near, far)
+        if constexpr (HYP) {
+            if (live) {
+                a.samples[(size_t)ray * N + k] = out;
+                a.inds[(size_t)ray * N + k] = ind;
+                if (a.u_out) a.u_out[(size_t)ray * N + k] = u;
+            }
+        } else {
+            out = tmin(tmax(out, lo), hi);        // torch.clamp(z_samples, near, far)
+        }
         smp[k] = out;
         ssum += (double)out;
     }
@@ -153,6 +169,7 @@ __global__ __launch_bounds__(256) void coarse_epilogue_kernel(const EpiArgs a) {
     }
     sq = wave_sum(sq);
     if (live && lane == 0) a.z_std[ray] = (float)sqrt(sq / (double)N);
+    if constexpr (HYP) return;
 
     // ---- sort(cat(z, samples)) in registers (merge_sort_kernel's network) ----
     uint32_t x[KPL];
@@ -202,12 +219,12 @@ __global__ __launch_bounds__(256) void coarse_epilogue_kernel(const EpiArgs a) {
     }
 }
 
-template <int KPL>
+template <int KPL, bool HYP = false>
 int launch(const EpiArgs& a, size_t lds, hipStream_t st) {
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)coarse_epilogue_kernel<KPL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)coarse_epilogue_kernel<KPL, HYP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-    hipLaunchKernelGGL(coarse_epilogue_kernel<KPL>, dim3((a.R + WAVES - 1) / WAVES), dim3(WAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((coarse_epilogue_kernel<KPL, HYP>), dim3((a.R + WAVES - 1) / WAVES), dim3(WAVES * 64), lds, st, a);
     PLNERF_CHECK_LAUNCH();
     return PLNERF_OK;
 }
@@ -248,4 +265,36 @@ extern "C" int plnerf_coarse_epilogue(const float* raw, const float* z, const fl
     if (nf <= 256) return launch<4>(a, lds, st);
     if (nf <= 512) return launch<8>(a, lds, st);
     return launch<16>(a, lds, st);
+}
+
+
+extern "C" int plnerf_fine_epilogue(const float* raw, const float* z, const float* near, const float* far,
+                                    const float* rays_d, const float* noise, const float* u, int u_row_stride,
+                                    uint64_t seed, uint32_t step, int ray_id0, int R, int S, int N, int color_mode,
+                                    int white_bkgd, int farcolorfix, float zero_tol, float epsilon, float* rgb_map,
+                                    float* disp_map, float* acc_map, float* depth_map, float* weights, float* tau,
+                                    float* T, float* samples, int64_t* inds, float* u_out, float* z_std,
+                                    plnerf_stream_t stream) {
+    if (R < 0 || S < 2 || N < 1) return PLNERF_EINVAL;
+    if (u && u_row_stride != 0 && u_row_stride != N) return PLNERF_EINVAL;
+    if (color_mode != PLNERF_COLOR_MIDPOINT && color_mode != PLNERF_COLOR_LEFT) return PLNERF_EINVAL;
+    if (S > PLNERF_MAX_SAMPLES || N > 1024) return PLNERF_ERANGE;
+    if (R == 0) return PLNERF_OK;
+    if (!raw || !z || !near || !far || !rays_d || !rgb_map || !disp_map || !acc_map || !depth_map || !weights || !tau ||
+        !T || !samples || !inds || !z_std)
+        return PLNERF_EINVAL;
+    EpiArgs a{};
+    a.in = RayIn{raw, z, near, far, rays_d, noise, S};
+    a.u = u; a.u_row_stride = u_row_stride;
+    // (stream id 4: the hypotheses' draw is not the coarse pass's importance draw, stream 1)
+    a.rng = RngArgs{(uint32_t)seed, (uint32_t)(seed >> 32), 4u, step, ray_id0, u ? 0 : 1};
+    a.R = R; a.S = S; a.N = N; a.color_mode = color_mode; a.white_bkgd = white_bkgd; a.farcolorfix = farcolorfix;
+    a.zero_tol = zero_tol; a.eps = epsilon;
+    a.rgb_map = rgb_map; a.disp_map = disp_map; a.acc_map = acc_map; a.depth_map = depth_map;
+    a.weights = weights; a.tau = tau; a.T = T; a.z_std = z_std;
+    a.samples = samples; a.inds = inds; a.u_out = u_out;
+    a.lds_stride = ((4 * (S + 2) + 3 * S + N) + 3) & ~3;
+    const size_t lds = (size_t)WAVES * a.lds_stride * sizeof(float);
+    if (lds > 160 * 1024) return PLNERF_ERANGE;
+    return launch<1, true>(a, lds, (hipStream_t)stream);      // (KPL sizes the sort network only: unused here)
 }

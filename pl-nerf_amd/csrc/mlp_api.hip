@@ -91,17 +91,19 @@ extern "C" size_t plnerf_mlp_bwd_workspace_bytes(int n_rows, int precision) {
     if (!known(precision) || n_rows < 0) return 0;
     const size_t partials = ((size_t)lay::MAX_SPLITS * lay::PART_PER_SPLIT + (size_t)lay::MAX_HEAD_WGS * lay::HEAD_PART) *
                             sizeof(float);
-    if (precision == PLNERF_PREC_FP32) return (size_t)lay::DZ_PER_ROW * (size_t)n_rows * sizeof(float) + partials;
-    return impl::h16_dz_bytes(n_rows) + lay::WSH_SCALARS_BYTES + partials;
+    const size_t g_eff = (size_t)n_rows * 16;      // the upstream gradient after the density activation's derivative
+    if (precision == PLNERF_PREC_FP32) return (size_t)lay::DZ_PER_ROW * (size_t)n_rows * sizeof(float) + partials + g_eff;
+    return impl::h16_dz_bytes(n_rows) + lay::WSH_SCALARS_BYTES + partials + g_eff;
 }
 
 extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pts, const float* viewdirs,
                               const float* embedded, int input_ch, int input_ch_views, int n_rows,
-                              int samples_per_ray, float input_scale, float* raw_out, void* saved,
+                              int samples_per_ray, float input_scale, float density_beta, float* raw_out, void* saved,
                               int fwd_kernel, plnerf_stream_t stream) {
     if (!known(precision)) return PLNERF_ENOSYS;
     if (!kernel_arg_ok(fwd_kernel)) return PLNERF_EINVAL;
-    if (n_rows < 0 || !geometry_ok(input_ch, input_ch_views)) return PLNERF_EINVAL;
+    if (n_rows < 0 || !geometry_ok(input_ch, input_ch_views) || !(density_beta >= 0.0f) || !(density_beta < 1e6f)) return PLNERF_EINVAL;
+    const impl::FwdOpt opt{input_scale, density_beta};
     // the in-kernel encoding: 3 + 6 L position channels (L <= 10) and 3 + 6 M direction channels (M <= 4) -- a prefix of
     // the reference default's 63 | 27 (the unused bands meet zero-padded weights) -- with the encoder's input scale
     if (!embedded && ((input_ch - 3) % 6 != 0 || input_ch < 3 || input_ch > lay::XYZ_CH || (input_ch_views - 3) % 6 != 0 ||
@@ -112,44 +114,62 @@ extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pt
     if (!embedded && (!pts || !viewdirs || samples_per_ray < 1)) return PLNERF_EINVAL;
     if (precision == PLNERF_PREC_FP32)
         return impl::f32_fwd(packed, pts, viewdirs, embedded, input_ch, input_ch_views, n_rows, samples_per_ray,
-                             input_scale, raw_out, saved, (hipStream_t)stream);
+                             opt, raw_out, saved, (hipStream_t)stream);
     if (f16_of(precision) && use_rr(saved != nullptr, ns_of(precision), embedded != nullptr, fwd_kernel))
         return impl::rr_fwd(packed, (const unsigned char*)packed + impl::bf16_packed_bytes(ns_of(precision)),
                             ns_of(precision), pts, viewdirs, embedded, input_ch, input_ch_views, n_rows, samples_per_ray,
-                            input_scale, raw_out, saved, status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);
+                            opt, raw_out, saved, status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);
     // bf16 elements: the register-resident kernel serves inference with the in-kernel encoding (unless pp is forced)
     if (!f16_of(precision) && use_rr_bf16(saved != nullptr, ns_of(precision), embedded != nullptr, fwd_kernel))
         return impl::rr_fwd_bf16(packed, (const unsigned char*)packed + impl::bf16_packed_bytes(ns_of(precision)),
                                  ns_of(precision), pts, viewdirs, embedded, input_ch, input_ch_views, n_rows, samples_per_ray,
-                                 input_scale, raw_out, saved, status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);
+                                 opt, raw_out, saved, status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);
     return impl::bf16_fwd(packed, ns_of(precision), f16_of(precision), pts, viewdirs, embedded, input_ch,
-                          input_ch_views, n_rows, samples_per_ray, input_scale, raw_out, saved,
+                          input_ch_views, n_rows, samples_per_ray, opt, raw_out, saved,
                           status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);
 }
 
 extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, int input_ch,
-                              int input_ch_views, int n_rows, const void* saved, int saved_layout, void* workspace,
+                              int input_ch_views, int n_rows, const void* saved, int saved_layout,
+                              const float* raw_out, float density_beta, void* workspace,
                               float* const* grads, float* status_out, plnerf_stream_t stream) {
     if (saved_layout != lay::SV_LAYOUT_ROWS && saved_layout != lay::SV_LAYOUT_TILED) return PLNERF_EINVAL;
     if (saved_layout == lay::SV_LAYOUT_TILED && !ns_of(precision)) return PLNERF_EINVAL;
     if (!known(precision)) return PLNERF_ENOSYS;
     if (!packed || !g_raw || !saved || !workspace || !grads || n_rows < 1) return PLNERF_EINVAL;
     if (!geometry_ok(input_ch, input_ch_views)) return PLNERF_EINVAL;
+    if (!(density_beta >= 0.0f) || !(density_beta < 1e6f) || (density_beta > 0.0f && !raw_out)) return PLNERF_EINVAL;
     for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i)
         if (!grads[i]) return PLNERF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    const bool act = density_beta > 0.0f;
+    const size_t part_bytes = ((size_t)lay::MAX_SPLITS * lay::PART_PER_SPLIT + (size_t)lay::MAX_HEAD_WGS * lay::HEAD_PART) * sizeof(float);
     if (precision == PLNERF_PREC_FP32) {
         float* dz = (float*)workspace;
+        float* partials = dz + (size_t)lay::DZ_PER_ROW * (size_t)n_rows;
+        if (act) {      // the activation's derivative first: every kernel below reads the effective gradient
+            float* g_eff = (float*)((unsigned char*)partials + part_bytes);
+            const int rc0 = impl::absmax_act(g_raw, raw_out, density_beta, n_rows, g_eff, nullptr, st);
+            if (rc0) return rc0;
+            g_raw = g_eff;
+        }
         const int rc = impl::f32_dgrad(packed, g_raw, n_rows, (const float*)saved, dz, st);
         if (rc) return rc;
-        return impl::wgrad(g_raw, n_rows, saved, dz, nullptr, dz + (size_t)lay::DZ_PER_ROW * (size_t)n_rows, grads,
+        return impl::wgrad(g_raw, n_rows, saved, dz, nullptr, partials, grads,
                            input_ch, input_ch_views, false, lay::SV_LAYOUT_ROWS, nullptr, status_out, st);
     }
     // 16-bit modes: [dz half planes][max |g_raw|][partials]
     unsigned char* ws = (unsigned char*)workspace;
     unsigned* gmax = (unsigned*)(ws + impl::h16_dz_bytes(n_rows));
     float* partials = (float*)(ws + impl::h16_dz_bytes(n_rows) + lay::WSH_SCALARS_BYTES);
-    int rc = impl::absmax(g_raw, (size_t)n_rows * 4, gmax, st);
+    int rc;
+    if (act) {      // one pass: the activation's derivative and the launch scale's maximum
+        float* g_eff = (float*)((unsigned char*)partials + part_bytes);
+        rc = impl::absmax_act(g_raw, raw_out, density_beta, n_rows, g_eff, gmax, st);
+        g_raw = g_eff;
+    } else {
+        rc = impl::absmax(g_raw, (size_t)n_rows * 4, gmax, st);
+    }
     if (rc) return rc;
     rc = impl::bf16_dgrad(packed, ns_of(precision), g_raw, n_rows, saved, ws, gmax, st);
     if (rc) return rc;

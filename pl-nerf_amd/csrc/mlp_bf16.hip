@@ -67,12 +67,12 @@ int bf16_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, int f1
 }
 
 int bf16_fwd(const void* packed, int ns, int f16, const float* pts, const float* viewdirs, const float* embedded,
-             int xyz_ch, int dir_ch, int n_rows, int samples_per_ray, float pe_scale, float* raw_out, void* saved,
+             int xyz_ch, int dir_ch, int n_rows, int samples_per_ray, FwdOpt opt, float* raw_out, void* saved,
              unsigned* status, hipStream_t st) {
     return f16 ? plnerf_h16_f16::h16_fwd(packed, ns, pts, viewdirs, embedded, xyz_ch, dir_ch, n_rows, samples_per_ray,
-                                         pe_scale, raw_out, saved, status, st)
+                                         opt, raw_out, saved, status, st)
                : plnerf_h16_bf16::h16_fwd(packed, ns, pts, viewdirs, embedded, xyz_ch, dir_ch, n_rows, samples_per_ray,
-                                          pe_scale, raw_out, saved, status, st);      // (bf16 elements: PLNERF_RANGE_SAVED only)
+                                          opt, raw_out, saved, status, st);      // (bf16 elements: PLNERF_RANGE_SAVED only)
 }
 
 int bf16_dgrad(const void* packed, int ns, const float* g_raw, int n_rows, const void* saved, void* dz,

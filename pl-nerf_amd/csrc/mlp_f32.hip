@@ -163,6 +163,7 @@ struct FwdArgs {
     float* raw_out;
     float* saved;
     float pe_scale;       // the in-kernel encoding's input scale: sin / cos(x * pe_scale * 2^k) (1, or pi: depth variant)
+    float act_beta;       // > 0: sigma leaves as softplus(beta)(sigma) (common.h: density_activation)
 };
 
 // bias (+relu) epilogue: accumulators -> LDS tile in place (+ saved plane in HBM)
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_f32_kernel(FwdArgs a) {
             o.x = o0 + pk[HB_BR + 0];
             o.y = o1 + pk[HB_BR + 1];
             o.z = o2 + pk[HB_BR + 2];
-            o.w = sigma;
+            o.w = density_activation(sigma, a.act_beta);
             reinterpret_cast<float4*>(a.raw_out)[row0 + hrow] = o;
         }
     }
@@ -1088,6 +1089,38 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float4* __restrict__ 
     }
 }
 
+// The density activation's derivative, folded into the backward's entry: g_eff = g_raw with its sigma column multiplied by
+// d softplus / d sigma, evaluated from the activation's OUTPUT raw_out[., 3] (common.h) -- written to the workspace
+// (the caller's gradient buffer is not touched) -- and, for the 16-bit modes, max |g_eff| in the same pass (what
+// absmax_kernel does for a network without activation).
+__global__ __launch_bounds__(256) void absmax_act_kernel(const float4* __restrict__ g, const float* __restrict__ raw,
+                                                         const float beta, float4* __restrict__ g_eff, size_t n4,
+                                                         unsigned* out) {
+    __shared__ float wmax[4];
+    float m = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = g[i];
+        v.w = v.w * density_activation_grad(raw[4 * i + 3], beta);
+        g_eff[i] = v;
+        const float c[4] = {fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m = (c[k] > m || c[k] != c[k]) ? c[k] : m;
+    }
+    if (!out) return;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_xor(m, d);
+        m = (o > m || o != o) ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) m = (wmax[w] > m || wmax[w] != wmax[w]) ? wmax[w] : m;
+        if (m != 0.0f) atomicMax(out, __float_as_uint(m));
+    }
+}
+
 inline int splits_for(int n_rows, bool h16) {
     const int cap = h16 ? WG_SPLITS : PLNERF_WG_SPLITS_F32;
     int s = (n_rows + 1023) / 1024;
@@ -1126,10 +1159,10 @@ int f32_pack(const float* const* params, int xyz_ch, int dir_ch, void* packed, h
 }
 
 int f32_fwd(const void* packed, const float* pts, const float* viewdirs, const float* embedded, int xyz_ch,
-            int dir_ch, int n_rows, int samples_per_ray, float pe_scale, float* raw_out, void* saved, hipStream_t st) {
+            int dir_ch, int n_rows, int samples_per_ray, FwdOpt opt, float* raw_out, void* saved, hipStream_t st) {
     constexpr int NI = 2, TM = 32 * NI;
     FwdArgs a{(const float*)packed, pts, viewdirs, embedded, xyz_ch, dir_ch, n_rows,
-              samples_per_ray < 1 ? 1 : samples_per_ray, raw_out, (float*)saved, pe_scale};
+              samples_per_ray < 1 ? 1 : samples_per_ray, raw_out, (float*)saved, opt.pe_scale, opt.act_beta};
     const size_t lds = (size_t)TM * (LDA + LDP + LDD) * sizeof(float);
     dim3 grid((n_rows + TM - 1) / TM), block(256);
     if (saved) {
@@ -1165,6 +1198,17 @@ int absmax(const float* x, size_t n, unsigned* out, hipStream_t st) {
     size_t blocks = (n4 + 255) / 256;
     if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, st, (const float4*)x, n4, out);
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}
+
+int absmax_act(const float* g_raw, const float* raw_out, float beta, int n_rows, float* g_eff, unsigned* out, hipStream_t st) {
+    if (out && hipMemsetAsync(out, 0, sizeof(unsigned), st) != hipSuccess) return PLNERF_ELAUNCH;
+    const size_t n4 = (size_t)n_rows;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(absmax_act_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, st, (const float4*)g_raw,
+                       raw_out, beta, (float4*)g_eff, n4, out);
     PLNERF_CHECK_LAUNCH();
     return PLNERF_OK;
 }

@@ -8,12 +8,18 @@
 namespace plnerf {
 namespace impl {
 
+// what a forward launch takes besides its buffers
+struct FwdOpt {
+    float pe_scale;     // the in-kernel encoding's input scale (1: run_nerf_helpers.py:24-54; pi: the depth variant's Embedder)
+    float act_beta;     // > 0: the density channel leaves as softplus(beta)(sigma) (common.h: density_activation); 0: as it is
+};
+
 size_t f32_packed_bytes();
 int f32_pack(const float* const* params, int xyz_ch, int dir_ch, void* packed, hipStream_t st);
 // xyz_ch / dir_ch = input_ch / input_ch_views of the network (columns of `embedded`)
 // pe_scale: the in-kernel encoding's input scale (1: run_nerf_helpers.py:24-54; pi: the depth variant's Embedder)
 int f32_fwd(const void* packed, const float* pts, const float* viewdirs, const float* embedded, int xyz_ch,
-            int dir_ch, int n_rows, int samples_per_ray, float pe_scale, float* raw_out, void* saved, hipStream_t st);
+            int dir_ch, int n_rows, int samples_per_ray, FwdOpt opt, float* raw_out, void* saved, hipStream_t st);
 int f32_dgrad(const void* packed, const float* g_raw, int n_rows, const float* saved, float* dz, hipStream_t st);
 // Weight gradients.  h16 = false: fp32 planes on the fp32 MFMA (fp32 mode); h16 = true: half planes on
 // v_mfma_f32_32x32x16_f16, partial sums divided by the dz scale derived from *gmax (16-bit modes).
@@ -22,6 +28,9 @@ int f32_dgrad(const void* packed, const float* g_raw, int n_rows, const float* s
 int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dz, const unsigned* gmax, float* partials,
           float* const* grads, int xyz_ch, int dir_ch, bool h16, int saved_layout, const unsigned* status,
           float* status_out, hipStream_t st);
+// g_eff [n_rows, 4] = g_raw with the sigma column times the density activation's derivative (from raw_out, the forward's
+// activated output); out (nullable): max |g_eff| as fp32 bits, like absmax
+int absmax_act(const float* g_raw, const float* raw_out, float beta, int n_rows, float* g_eff, unsigned* out, hipStream_t st);
 // max |x| over n floats as fp32 bits (non-negative floats order like unsigned integers) -> *out
 int absmax(const float* x, size_t n, unsigned* out, hipStream_t st);
 // bytes of the half dz planes of n_rows rows, rounded up to 16
@@ -33,7 +42,7 @@ size_t bf16_packed_bytes(int ns);
 int bf16_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, int f16, void* packed, unsigned* status,
               hipStream_t st);
 int bf16_fwd(const void* packed, int ns, int f16, const float* pts, const float* viewdirs, const float* embedded,
-             int xyz_ch, int dir_ch, int n_rows, int samples_per_ray, float pe_scale, float* raw_out, void* saved,
+             int xyz_ch, int dir_ch, int n_rows, int samples_per_ray, FwdOpt opt, float* raw_out, void* saved,
              unsigned* status, hipStream_t st);
 int bf16_dgrad(const void* packed, int ns, const float* g_raw, int n_rows, const void* saved, void* dz,
                const unsigned* gmax, hipStream_t st);
@@ -54,16 +63,17 @@ struct RrFwdArgs {
     const float* embedded;  // caller-supplied encoding [n_rows][in_ch + view_ch] (EMB kernels), else pts / viewdirs
     int in_ch, view_ch;
     float pe_scale;         // in-kernel encoding: sin / cos(x * pe_scale * 2^k)
+    float act_beta;         // > 0: sigma leaves as softplus(beta)(sigma)
 };
 bool rr_embedded_ok(int ns);
 int rr_fwd(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs, const float* embedded,
-           int in_ch, int view_ch, int n_rows, int samples_per_ray, float pe_scale, float* raw_out, void* saved,
+           int in_ch, int view_ch, int n_rows, int samples_per_ray, FwdOpt opt, float* raw_out, void* saved,
            unsigned* status, hipStream_t st);
 // the same kernel on bf16 elements (mlp_rr_body.inc compiled with RR_BF16): inference, and -- split mode only -- the
 // training forward and caller-embedded inputs
 int rr_pack_bf16(const float* const* params, int xyz_ch, int dir_ch, int ns, void* section, hipStream_t st);
 int rr_fwd_bf16(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs,
-                const float* embedded, int in_ch, int view_ch, int n_rows, int samples_per_ray, float pe_scale,
+                const float* embedded, int in_ch, int view_ch, int n_rows, int samples_per_ray, FwdOpt opt,
                 float* raw_out, void* saved, unsigned* status, hipStream_t st);
 
 }  // namespace impl

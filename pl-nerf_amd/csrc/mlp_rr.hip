@@ -51,10 +51,10 @@ int rr_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, void* se
 // `embedded` (a caller-supplied encoding, [n_rows][in_ch + view_ch]) is served in split mode only (ns == 2: rr_embedded_ok)
 bool rr_embedded_ok(int ns) { return ns == 2; }
 int rr_fwd(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs, const float* embedded,
-           int in_ch, int view_ch, int n_rows, int samples_per_ray, float pe_scale, float* raw_out, void* saved,
+           int in_ch, int view_ch, int n_rows, int samples_per_ray, FwdOpt opt, float* raw_out, void* saved,
            unsigned* status, hipStream_t st) {
     RrFwdArgs a{packed, section, pts, viewdirs, n_rows, samples_per_ray < 1 ? 1 : samples_per_ray, raw_out, saved,
-                         status, embedded, in_ch, view_ch, pe_scale};
+                         status, embedded, in_ch, view_ch, opt.pe_scale, opt.act_beta};
     if (embedded) {
         if (ns != 2) return PLNERF_EINVAL;
         return saved ? rr_launch_2_train_emb(a, st) : rr_launch_2_infer_emb(a, st);

@@ -24,10 +24,10 @@ int rr_pack_bf16(const float* const* params, int xyz_ch, int dir_ch, int ns, voi
 }
 
 int rr_fwd_bf16(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs,
-                const float* embedded, int in_ch, int view_ch, int n_rows, int samples_per_ray, float pe_scale,
+                const float* embedded, int in_ch, int view_ch, int n_rows, int samples_per_ray, FwdOpt opt,
                 float* raw_out, void* saved, unsigned* status, hipStream_t st) {
     RrFwdArgs a{packed, section, pts, viewdirs, n_rows, samples_per_ray < 1 ? 1 : samples_per_ray, raw_out, saved,
-                status, embedded, in_ch, view_ch, pe_scale};
+                status, embedded, in_ch, view_ch, opt.pe_scale, opt.act_beta};
     if (embedded) {      // (split mode only, like the IEEE-half build)
         if (ns != 2) return PLNERF_EINVAL;
         return saved ? rr_launch_bf16_2_train_emb(a, st) : rr_launch_bf16_2_infer_emb(a, st);

@@ -283,6 +283,7 @@ struct DepthLossArgs {
     const float* target_h;     // [H, R, PT] with PT = 1 (one depth per ray and hypothesis) or P
     const float* mask;         // [R] or nullptr
     int R, P, H, PT;
+    int is_joint;              // the hypothesis is chosen per IMAGE (per point column), not per ray (model/run_nerf_helpers.py:72-77)
     float weight, threshold;
     float* loss5;              // {total, img, img0, space carving (unweighted), psnr of img}
     float* g_rgb; float* g_rgb0; float* g_hyp;
@@ -293,6 +294,9 @@ constexpr int DL_BLOCKS = 128, DL_THREADS = 256;
 
 __global__ __launch_bounds__(DL_THREADS) void depth_loss_kernel(const DepthLossArgs a) {
     __shared__ double part[3][DL_THREADS / 64];
+    __shared__ double jred[DL_THREADS / 64];
+    __shared__ double jbest;
+    __shared__ int jarg;
     __shared__ unsigned last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
     const int n = 3 * a.R;
@@ -312,7 +316,47 @@ __global__ __launch_bounds__(DL_THREADS) void depth_loss_kernel(const DepthLossA
             }
         }
     }
-    if (a.hyp) {
+    if (a.hyp && a.is_joint) {
+        // is_joint (model/run_nerf_helpers.py:72-77): quantile_mean[h, p] = mean over the RAYS of distances[h, r, p]; the
+        // hypothesis is chosen per point column, min over h; loss = mean over p.  A workgroup owns whole columns
+        // (p = b, b + DL_BLOCKS, ...): it sums a column over all rays itself -- fixed thread-strided order, fixed tree --
+        // so the choice needs no second launch and the result is deterministic; its partial is the chosen column sum.
+        const float gs = a.weight / ((float)a.R * (float)a.P);
+        for (int p = b; p < a.P; p += DL_BLOCKS) {
+            for (int h = 0; h < a.H; ++h) {
+                double sum = 0.0;
+                for (int r = tid; r < a.R; r += DL_THREADS) {
+                    const float m = a.mask ? a.mask[r] : 1.0f;
+                    const float t = a.target_h[((size_t)h * a.R + r) * a.PT + (a.PT == 1 ? 0 : p)];
+                    float d = fabsf(a.hyp[(size_t)r * a.P + p] - t) * m;
+                    if (a.threshold > 0.0f && d < a.threshold) d = 0.0f;
+                    sum += (double)d;
+                }
+                sum = wave_sum(sum);
+                if (lane == 0) jred[wave] = sum;
+                __syncthreads();
+                if (tid == 0) {
+                    double tot = 0.0;
+                    for (int w = 0; w < DL_THREADS / 64; ++w) tot += jred[w];
+                    // (compared as the reference compares them: fp32 means; first minimum on ties, like torch.min)
+                    const float mean = (float)(tot / (double)a.R);
+                    if (h == 0 || mean < (float)(jbest / (double)a.R)) { jbest = tot; jarg = h; }
+                }
+                __syncthreads();
+            }
+            const int hs = jarg;
+            if (tid == 0) sc += jbest;
+            for (int r = tid; r < a.R; r += DL_THREADS) {
+                const float m = a.mask ? a.mask[r] : 1.0f;
+                const float t = a.target_h[((size_t)hs * a.R + r) * a.PT + (a.PT == 1 ? 0 : p)];
+                const float diff = a.hyp[(size_t)r * a.P + p] - t;
+                float gd = diff > 0.0f ? m : (diff < 0.0f ? -m : 0.0f);
+                if (a.threshold > 0.0f && fabsf(diff) * m < a.threshold) gd = 0.0f;
+                a.g_hyp[(size_t)r * a.P + p] = gd * gs;
+            }
+            __syncthreads();
+        }
+    } else if (a.hyp) {
         // distances[h, r, p] = mask[r] * |pred[r, p] - target[h, r, p]|  (torch.norm over a trailing axis of length 1),
         // zeroed below the threshold; best = min over h (first minimum on ties, like torch.min); loss = mean over r, p
         const int np = a.R * a.P;
@@ -529,14 +573,14 @@ extern "C" int plnerf_image_loss(const float* rgb, const float* rgb0, const floa
 
 extern "C" int plnerf_depth_loss(const float* rgb, const float* rgb0, const float* target, const float* pred_hyp,
                                  const float* target_h, const float* mask, int R, int n_points, int n_hyp,
-                                 int target_points, float space_carving_weight, float threshold, float* loss5,
+                                 int target_points, int is_joint, float space_carving_weight, float threshold, float* loss5,
                                  float* g_rgb, float* g_rgb0, float* g_hyp, void* workspace, plnerf_stream_t stream) {
     static_assert(DL_BLOCKS * 3 * sizeof(double) + sizeof(unsigned) <= PLNERF_DEPTH_LOSS_WORKSPACE_BYTES, "workspace");
     if (R < 1 || !rgb || !target || !loss5 || !g_rgb || (rgb0 && !g_rgb0) || !workspace) return PLNERF_EINVAL;
     if (pred_hyp && (!target_h || !g_hyp || n_points < 1 || n_hyp < 1 || (target_points != 1 && target_points != n_points)))
         return PLNERF_EINVAL;
-    DepthLossArgs a{rgb, rgb0, target, pred_hyp, target_h, mask, R, n_points, n_hyp, target_points, space_carving_weight,
-                    threshold, loss5, g_rgb, g_rgb0, g_hyp, (double*)workspace,
+    DepthLossArgs a{rgb, rgb0, target, pred_hyp, target_h, mask, R, n_points, n_hyp, target_points, is_joint ? 1 : 0,
+                    space_carving_weight, threshold, loss5, g_rgb, g_rgb0, g_hyp, (double*)workspace,
                     (unsigned*)((double*)workspace + DL_BLOCKS * 3)};
     hipLaunchKernelGGL(depth_loss_kernel, dim3(DL_BLOCKS), dim3(DL_THREADS), 0, (hipStream_t)stream, a);
     PLNERF_CHECK_LAUNCH();

@@ -23,7 +23,8 @@ from . import functional as Fn
 from . import raybatch as RB
 from .nerf import Embedder, NeRF
 from .optim import FlatAdam
-from .render import MAX_ROWS_PER_LAUNCH, batchify, raw2outputs as _raw2outputs, sample_pdf, sample_pdf_reformulation
+from .render import (MAX_ROWS_PER_LAUNCH, _draw_noise, _draw_u as _nvs_draw_u, _rgb_sigma, batchify, raw2outputs as _raw2outputs,
+                     sample_pdf, sample_pdf_reformulation)
 
 
 def get_embedder(multires, i=0):
@@ -59,6 +60,7 @@ def _kernel_encoding(embed_fn, embeddirs_fn, viewdirs):
     return fx[0], fd[0], (scales.pop() if scales else 1.0)
 
 
+FUSE_STAGES = True      # (tests switch it off to compare the one-launch stages with the separate launches, bit for bit)
 _BOX_CACHE = {}
 
 
@@ -137,10 +139,14 @@ def _draw_u(n_rays, N_samples, det, pytest, load_u, joint, device):
     """The draw of the *_return_u samplers (model/run_nerf_helpers.py:619-638; joint: 792-812)."""
     if load_u is not None:
         return load_u
+    draws = None if pytest else Fn.DRAWS
     if det:
         u = Fn.cpu_linspace(N_samples, device).expand(n_rays, N_samples)
-    elif joint:
-        u = torch.rand(N_samples, device=device).unsqueeze(0).repeat(n_rays, 1)
+    elif joint:      # one row for the whole image
+        row = (_joint_row(draws, N_samples, device) if draws is not None else torch.rand(N_samples, device=device))
+        u = row.unsqueeze(0).repeat(n_rays, 1)
+    elif draws is not None:
+        u = draws.uniform(n_rays, N_samples, Fn.FineEpilogueFn.HYP_STREAM, device)
     else:
         u = torch.rand(n_rays, N_samples, device=device)
     if pytest:
@@ -150,6 +156,17 @@ def _draw_u(n_rays, N_samples, det, pytest, load_u, joint, device):
         else:
             u = torch.Tensor(np.random.rand(n_rays, N_samples)).to(device)
     return u
+
+
+def _joint_row(draws, n, device):
+    """The is_joint draw -- ONE row of u for the whole image -- from the counters of global ray 0, so that every rank of
+    a sharded batch sees the same row."""
+    keep = draws.ray_id0, draws.chunk_offset
+    draws.ray_id0, draws.chunk_offset = 0, 0
+    try:
+        return draws.uniform(1, n, Fn.FineEpilogueFn.HYP_STREAM, device).reshape(-1)
+    finally:
+        draws.ray_id0, draws.chunk_offset = keep
 
 
 def sample_pdf_reformulation_return_u(bins, weights, tau, T, near, far, N_samples, det=False, pytest=False,
@@ -170,10 +187,13 @@ def sample_pdf_return_u(bins, weights, N_samples, det=False, pytest=False, load_
 
 
 def _draw_t_rand(n_rays, n_samples, pytest, device):
-    """The stratified jitter of run_nerf_sample_based_depth.py:781-788: np.random.seed(0) draws under pytest, else
-    torch.rand."""
+    """The stratified jitter of run_nerf_sample_based_depth.py:781-788: np.random.seed(0) draws under pytest; else from
+    an installed functional.DrawSource (counter-based on the global ray id: the step does not depend on how the batch
+    is sharded), else torch.rand as the reference."""
     if pytest:
         return Fn.numpy_uniform([n_rays, n_samples], device)
+    if Fn.DRAWS is not None:
+        return Fn.DRAWS.uniform(n_rays, n_samples, Fn.DrawSource.T_RAND, device)
     return torch.rand(n_rays, n_samples, device=device)
 
 
@@ -200,11 +220,18 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
     near, far = ray_batch[:, 6:7].contiguous(), ray_batch[:, 7:8].contiguous()
     t_vals = Fn.cpu_linspace(N_samples, dev)
     fused_glue = ray_batch.is_cuda and N_rays > 0 and not (torch.is_grad_enabled() and ray_batch.requires_grad)
+    draws = None if pytest else Fn.DRAWS      # counter-based draws inside the consuming kernels (functional.DrawSource)
+    if draws is not None:
+        draws.noise_calls = 0
+    # The stages between and behind the two network evaluations as ONE launch each, like the NVS path's (piecewise-linear
+    # mode): plnerf_coarse_epilogue (raw2outputs + importance sampling + clamp + sort + positions) and
+    # plnerf_fine_epilogue (raw2outputs + the hypotheses' sampler + z_std); bit-identical to the separate calls below.
+    fused = FUSE_STAGES and fused_glue and mode == "linear" and color_mode in ("midpoint", "left")
     if fused_glue:
         # depths, jitter and positions in one launch (plnerf_coarse_samples: bit-identical to the expressions below,
-        # which are :775-790 and run_plnerf.py:683-708 alike); the jitter is drawn here as the reference draws it
-        t_rand = _draw_t_rand(N_rays, N_samples, pytest, dev) if perturb > 0. else None
-        z_vals, pts = Fn.coarse_samples(rays_o, rays_d, near, far, t_vals, t_rand, lindisp, perturb > 0., None)
+        # which are :775-790 and run_plnerf.py:683-708 alike); the jitter from the reference's draw, or in the kernel
+        t_rand = _draw_t_rand(N_rays, N_samples, pytest, dev) if (perturb > 0. and draws is None) else None
+        z_vals, pts = Fn.coarse_samples(rays_o, rays_d, near, far, t_vals, t_rand, lindisp, perturb > 0., draws)
     else:
         if not lindisp:
             z_vals = near * (1. - t_vals) + far * t_vals
@@ -214,9 +241,36 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
             z_vals = perturb_z_vals(z_vals, pytest)
         pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
     raw = network_query_fn(pts, viewdirs, embedded_cam, network_fn)
-    rgb_map, disp_map, acc_map, weights, depth_map, tau, T = raw2outputs(
-        raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std, pytest=pytest, white_bkgd=white_bkgd,
-        farcolorfix=farcolorfix)
+
+    def last_stage(raw, z_vals, n, load_u):
+        """raw2outputs of the final pass + the depth hypotheses on its weights (:909-934), one launch."""
+        det = perturb == 0.
+        if load_u is not None or det or pytest or draws is None:
+            u = _draw_u(N_rays, n, det, pytest, load_u, is_joint, dev).contiguous()
+        else:      # drawn inside the kernel; is_joint: one row from the counters of ray 0
+            u = _joint_row(draws, n, dev) if is_joint else None
+        rgb, disp, acc, depth, w, tau, T, hyp, u_used, _, z_std = Fn.FineEpilogueFn.apply(
+            _rgb_sigma(raw), z_vals, near, far, rays_d, _draw_noise(raw, raw_noise_std, pytest), u, n, color_mode,
+            white_bkgd, False, zero_tol, epsilon, draws)
+        return rgb, disp, acc, w, depth, hyp, u_used, z_std
+
+    if fused and N_importance == 0:
+        rgb_map, disp_map, acc_map, weights, depth_map, pred_depth_hyp, u, _ = last_stage(raw, z_vals, N_samples, None)
+    elif fused:
+        z_vals_0 = z_vals
+        det = perturb == 0.
+        u0 = _nvs_draw_u([N_rays], N_importance, det, pytest, dev) if (pytest or det or draws is None) else None
+        rgb_map_0, disp_map_0, acc_map_0, depth_map_0, z_vals, pts, _, weights_0 = Fn.CoarseEpilogueFn.apply(
+            _rgb_sigma(raw), z_vals, near, far, rays_o, rays_d, _draw_noise(raw, raw_noise_std, pytest), u0,
+            N_importance, color_mode, white_bkgd, False, zero_tol, epsilon, draws, True)
+        run_fn = network_fn if network_fine is None else network_fine
+        raw = network_query_fn(pts, viewdirs, embedded_cam, run_fn)
+        rgb_map, disp_map, acc_map, weights, depth_map, pred_depth_hyp, u, z_std = last_stage(raw, z_vals, N_importance,
+                                                                                             cached_u)
+    else:
+        rgb_map, disp_map, acc_map, weights, depth_map, tau, T = raw2outputs(
+            raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std, pytest=pytest, white_bkgd=white_bkgd,
+            farcolorfix=farcolorfix)
 
     def hypotheses(z_vals, weights, tau, T, n, load_u):
         if mode == "linear":
@@ -231,7 +285,9 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
             raise ValueError("mode must be 'linear' or 'constant'")
         return s, u
 
-    if N_importance == 0:
+    if fused:
+        pass
+    elif N_importance == 0:
         pred_depth_hyp, u = hypotheses(z_vals, weights, tau, T, N_samples, None)
     else:
         rgb_map_0, disp_map_0, acc_map_0, depth_map_0, z_vals_0, weights_0 = \
@@ -328,41 +384,51 @@ def render(H, W, intrinsic, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near
 render_hyp = render
 
 
+class _SpaceCarvingFn(torch.autograd.Function):
+    """compute_space_carving_loss on the GPU: plnerf_depth_loss's carving term and its gradient (the image terms of that
+    launch run on a dummy pixel and are discarded)."""
+
+    @staticmethod
+    def forward(ctx, pred, target_h, mask, threshold, is_joint):
+        dummy = pred.new_zeros(pred.shape[0], 3)
+        # weight 1: loss5[3] is the unweighted term, g_hyp its gradient
+        loss5, _, _, g_hyp = Fn.depth_loss_and_grads(dummy, None, dummy, pred, target_h, 1.0, threshold=threshold, mask=mask,
+                                                     is_joint=is_joint)
+        ctx.g = g_hyp
+        return loss5[3]
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.g * g, None, None, None, None
+
+
 def compute_space_carving_loss(pred_depth, target_hypothesis, is_joint=False, mask=None, norm_p=2, threshold=0.0):
-    """model/run_nerf_helpers.py:52-86.  pred_depth [n_rays, n_points]; target_hypothesis
-    [n_hyp, n_rays, 1 or n_points].  A handful of small reductions: torch ops on the device."""
-    n_rays, n_points = pred_depth.shape
-    if target_hypothesis.shape[-1] == 1:
-        target = target_hypothesis.repeat(1, 1, n_points)
-    else:
-        target = target_hypothesis
-    distances = torch.norm(pred_depth.unsqueeze(-1) - target.unsqueeze(-1), p=norm_p, dim=-1)
-    if mask is not None:
-        distances = distances * mask.unsqueeze(0).repeat(distances.shape[0], 1).unsqueeze(-1)
-    if threshold > 0:
-        distances = torch.where(distances < threshold, torch.zeros((), device=distances.device), distances)
-    if is_joint:
-        quantile_mean = torch.mean(distances, axis=1)
-        return torch.mean(torch.min(quantile_mean, axis=0)[0], axis=-1)
-    best_hyp = torch.min(distances, dim=0)[0]
-    return torch.mean(torch.mean(best_hyp, dim=-1))
+    """model/run_nerf_helpers.py:52-86.  pred_depth [n_rays, n_points]; target_hypothesis [n_hyp, n_rays, 1 or
+    n_points]; returns the scalar loss, differentiable with respect to pred_depth.  The distance is a p-norm over a
+    trailing axis of length ONE, i.e. |pred - target| for every p >= 1; the reductions (per ray: min over hypotheses,
+    mean; is_joint: mean over rays, min over hypotheses per point, mean) run in plnerf_depth_loss."""
+    if not norm_p >= 1:
+        raise ValueError("norm_p must be >= 1 (the norm runs over an axis of length one: it is the absolute value)")
+    if not pred_depth.is_cuda:
+        raise RuntimeError(f"plnerf_amd: compute_space_carving_loss runs in plnerf_depth_loss and needs GPU tensors, got "
+                           f"{pred_depth.device} (there is no CPU fallback)")
+    return _SpaceCarvingFn.apply(pred_depth, target_hypothesis, mask, float(threshold), bool(is_joint))
 
 
 def get_space_carving_idx(pred_depth, target_hypothesis, is_joint=False, mask=None, norm_p=2, threshold=0.0):
-    """model/run_nerf_helpers.py:19-49: index of the best depth hypothesis, per ray (or per image when is_joint), for
-    the caller's hypothesis cache.  pred_depth [H, W, n_points]; target_hypothesis [n_hyp, H, W, 1]."""
-    H, W, n_points = pred_depth.shape
-    target = target_hypothesis.repeat(1, 1, 1, n_points)
-    distances = torch.norm(pred_depth.unsqueeze(-1) - target.unsqueeze(-1), p=norm_p, dim=-1)
-    if mask is not None:
-        distances = distances * mask.unsqueeze(0).repeat(distances.shape[0], 1).unsqueeze(-1)
+    """model/run_nerf_helpers.py:19-49: which hypothesis compute_space_carving_loss would pick, for the caller's
+    hypothesis cache -- per ray and point [H, W, n_points], or (is_joint) the one index of the whole image repeated to
+    [H, W, 1].  pred_depth [H, W, n_points]; target_hypothesis [n_hyp, H, W, 1].  (A data-pipeline helper, off the
+    training step: a few torch reductions.)"""
+    d = (pred_depth[None] - target_hypothesis).abs()                     # [n_hyp, H, W, n_points]
+    if mask is not None:                                                  # one value per pixel, [H, W] or flat
+        d = d * mask.reshape(1, pred_depth.shape[0], pred_depth.shape[1], 1)
     if threshold > 0:
-        distances = torch.where(distances < threshold, torch.zeros((), device=distances.device), distances)
+        d = d.masked_fill(d < threshold, 0.0)
     if is_joint:
-        total_loss = torch.mean(torch.mean(distances, axis=1), axis=1)
-        best_idx = torch.argmin(total_loss, dim=0)
-        return best_idx.unsqueeze(0).unsqueeze(0).repeat(H, W, 1)
-    return torch.argmin(distances, dim=0)
+        best = d.flatten(1).mean(1).argmin()
+        return best.expand(pred_depth.shape[0], pred_depth.shape[1], 1)
+    return d.argmin(0)
 
 
 def create_nerf(args, scene_render_params=None, device=None):
@@ -410,7 +476,12 @@ class DepthTrainStep:
     loss = mse(rgb) + space_carving_weight * space_carving(pred_hyp, target_h) + mse(rgb0); backward;
     clip_grad_value_(0.1); Adam.  `ray_batch` is the packed [R, 11] batch render_rays takes."""
 
-    def __init__(self, args, render_kwargs_train, optimizer, grad_vars, distributed=None, range_check_every=100):
+    def __init__(self, args, render_kwargs_train, optimizer, grad_vars, distributed=None, range_check_every=100, seed=0,
+                 counter_rng=True):
+        """counter_rng: the step's draws (stratified jitter, importance samples, the hypotheses' u) come from a
+        functional.DrawSource keyed on (seed, step, GLOBAL ray id) and are generated inside the kernels that consume
+        them -- a global batch gives the same step whether one rank renders it or N ranks a shard each, like
+        train.TrainStep.  False: torch.rand, as the reference draws."""
         from . import dp
         self.args, self.kw, self.optimizer, self.grad_vars = args, render_kwargs_train, optimizer, grad_vars
         self.global_step = 0
@@ -420,6 +491,8 @@ class DepthTrainStep:
         nets = self.nets = [n for n in (self.kw["network_fn"], self.kw.get("network_fine")) if n is not None]
         distributed = torch.distributed.is_initialized() if distributed is None else distributed
         self.bucket = None
+        self.rank = torch.distributed.get_rank() if distributed else 0
+        self.draws = Fn.DrawSource(seed=seed) if counter_rng else None
         if distributed and torch.distributed.get_world_size() > 1:
             dp.broadcast_parameters(nets)      # replicas start from rank 0's weights (see train.TrainStep)
             dp.broadcast_optimizer_state([optimizer])
@@ -440,20 +513,27 @@ class DepthTrainStep:
     def __call__(self, ray_batch, target_s, target_h, space_carving_mask=None, cached_u=None, pytest=False):
         a = self.args
         kw = {k: v for k, v in self.kw.items() if k not in ("ndc", "near", "far")}
-        out = render_rays(ray_batch, retraw=True, is_joint=getattr(a, "is_joint", False), cached_u=cached_u,
-                          quad_solution_v2=getattr(a, "quad_solution_v2", False), pytest=pytest, **kw)
+        prev = Fn.DRAWS
+        if self.draws is not None and ray_batch.is_cuda:
+            self.draws.step, self.draws.ray_id0 = self.global_step, self.rank * ray_batch.shape[0]
+            Fn.set_draw_source(self.draws)
+        try:
+            out = render_rays(ray_batch, retraw=True, is_joint=getattr(a, "is_joint", False), cached_u=cached_u,
+                              quad_solution_v2=getattr(a, "quad_solution_v2", False), pytest=pytest, **kw)
+        finally:
+            Fn.set_draw_source(prev)
         self.optimizer.zero_grad()
         carve = getattr(a, "space_carving_weight", 0.) > 0. and self.global_step + 1 > getattr(a, "warm_start_nerf", 0)
         rgb, rgb0 = out['rgb_map'], out.get('rgb0')
-        fused = (rgb.is_cuda and rgb.dim() == 2 and rgb.shape == target_s.shape and
-                 not (carve and getattr(a, "is_joint", False)))
+        fused = rgb.is_cuda and rgb.dim() == 2 and rgb.shape == target_s.shape
         if fused:
             # both image terms, the space-carving term and the three gradients in one launch (plnerf_depth_loss);
             # backward((rgb, rgb0, pred_hyp), (their gradients)) is loss.backward()
             hyp = out["pred_hyp"] if carve else None
             loss5, g_rgb, g_rgb0, g_hyp = Fn.depth_loss_and_grads(
                 rgb, rgb0, target_s, hyp, target_h if carve else None, getattr(a, "space_carving_weight", 0.),
-                threshold=getattr(a, "space_carving_threshold", 0.0), mask=space_carving_mask if carve else None)
+                threshold=getattr(a, "space_carving_threshold", 0.0), mask=space_carving_mask if carve else None,
+                is_joint=getattr(a, "is_joint", False))
             loss, img_loss, sc = loss5[0], loss5[1], loss5[3]
             roots = [(rgb, g_rgb)] + ([(rgb0, g_rgb0)] if rgb0 is not None else []) + ([(hyp, g_hyp)] if carve else [])
             torch.autograd.backward(tuple(r for r, _ in roots), tuple(gr for _, gr in roots))

@@ -251,7 +251,7 @@ class CoarseEpilogueFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, raw, z, near, far, rays_o, rays_d, noise, u, N, color_mode, white_bkgd, farcolorfix, zero_tol,
-                eps, draws):
+                eps, draws, want_weights=False):
         R, S = z.shape
         dev = raw.device
         _expect(tuple(raw.shape) == (R, S, 4), f"raw must be [{R}, {S}, 4], got {tuple(raw.shape)}")
@@ -267,24 +267,93 @@ class CoarseEpilogueFn(torch.autograd.Function):
         disp, acc, depth, z_std = (torch.empty(R, device=dev) for _ in range(4))
         z_fine = torch.empty(R, S + N, device=dev)
         pts = torch.empty(R, S + N, 3, device=dev)
+        # (the coarse weights reach HBM only for a caller that returns them: the depth-supervised variant's `weights0`)
+        weights = torch.empty(R, S + 1, device=dev) if want_weights else None
         seed, step, ray0 = (draws.seed, draws.step, draws.first_ray()) if draws is not None else (0, 0, 0)
         L.check(L.lib().plnerf_coarse_epilogue(
             L.dptr(raw_c, "raw"), L.dptr(z_c, "z_vals"), L.dptr(near_c, "near"), L.dptr(far_c, "far"),
             L.dptr(o_c, "rays_o"), L.dptr(d_c, "rays_d"), L.dptr(noise_c, "noise"), L.dptr(u_c, "u"), stride, seed, step,
             ray0, R, S, int(N), L.COLOR[color_mode], int(bool(white_bkgd)), int(bool(farcolorfix)), float(zero_tol),
-            float(eps), L.dptr(rgb), L.dptr(disp), L.dptr(acc), L.dptr(depth), None, None, None, L.dptr(z_fine),
+            float(eps), L.dptr(rgb), L.dptr(disp), L.dptr(acc), L.dptr(depth), L.dptr(weights), None, None, L.dptr(z_fine),
             L.dptr(pts), L.dptr(z_std), L.stream()), "plnerf_coarse_epilogue")
         ctx.save_for_backward(raw_c, z_c, near_c, far_c, d_c, noise_c if noise_c is not None else torch.empty(0),
                               depth, acc)
         ctx.cfg = ("linear", color_mode, bool(white_bkgd), bool(farcolorfix), noise_c is not None)
-        ctx.mark_non_differentiable(z_fine, pts, z_std)
+        if weights is None:
+            weights = torch.empty(0, device=dev)
+        ctx.mark_non_differentiable(z_fine, pts, z_std, weights)
         ctx.set_materialize_grads(False)
+        if want_weights:
+            return rgb, disp, acc, depth, z_fine, pts, z_std, weights
         return rgb, disp, acc, depth, z_fine, pts, z_std
 
     @staticmethod
-    def backward(ctx, g_rgb, g_disp, g_acc, g_depth, g_z, g_pts, g_std):
+    def backward(ctx, g_rgb, g_disp, g_acc, g_depth, g_z, g_pts, g_std, g_w=None):
         g_raw = _quad_backward(ctx.saved_tensors, ctx.cfg, g_rgb, g_disp, g_acc, None, g_depth, None, None)
-        return (g_raw,) + (None,) * 14
+        return (g_raw,) + (None,) * 15
+
+
+class FineEpilogueFn(torch.autograd.Function):
+    """The depth-supervised variant's last stage in piecewise-linear mode as one launch (plnerf_fine_epilogue):
+    raw2outputs of the final pass and sample_pdf_reformulation_return_u on its weights / tau / T -> the depth
+    hypotheses (depth_supervised_exps/run_nerf_sample_based_depth.py:909-934), plus z_std = std(hypotheses).
+    Differentiable with respect to `raw` through the maps, the weights AND the hypotheses (which keep their tape in the
+    reference: :923-934): backward = plnerf_sample_pl_bwd (g_hyp -> g_tau, g_T), then plnerf_quad_bwd.
+    u: [R, N], one shared row [N] (is_joint), or None = drawn in the kernel from `draws`."""
+    HYP_STREAM = 4
+
+    @staticmethod
+    def forward(ctx, raw, z, near, far, rays_d, noise, u, N, color_mode, white_bkgd, farcolorfix, zero_tol, eps, draws):
+        R, S = z.shape
+        dev = raw.device
+        _expect(tuple(raw.shape) == (R, S, 4), f"raw must be [{R}, {S}, 4], got {tuple(raw.shape)}")
+        raw_c, z_c = _f32c(raw), _f32c(z)
+        near_c, far_c = _f32c(near).reshape(-1), _f32c(far).reshape(-1)
+        d_c = _f32c(rays_d)
+        noise_c = None if noise is None else _f32c(noise)
+        u_c = None if u is None else _f32c(u)
+        _expect(u_c is None or tuple(u_c.shape) in ((N,), (R, N)), "u must be [N] or [R, N]")
+        _expect(u_c is not None or draws is not None, "no draws: pass u or a DrawSource")
+        stride = 0 if (u_c is None or u_c.dim() == 1) else N
+        rgb = torch.empty(R, 3, device=dev)
+        disp, acc, depth, z_std = (torch.empty(R, device=dev) for _ in range(4))
+        w = torch.empty(R, S + 1, device=dev)
+        tau, T = torch.empty(R, S + 2, device=dev), torch.empty(R, S + 2, device=dev)
+        hyp = torch.empty(R, N, device=dev)
+        inds = torch.empty(R, N, device=dev, dtype=torch.int64)
+        u_used = u_c if (u_c is not None and u_c.dim() == 2) else torch.empty(R, N, device=dev)
+        seed, step, ray0 = (draws.seed, draws.step, draws.first_ray()) if draws is not None else (0, 0, 0)
+        L.check(L.lib().plnerf_fine_epilogue(
+            L.dptr(raw_c, "raw"), L.dptr(z_c, "z_vals"), L.dptr(near_c, "near"), L.dptr(far_c, "far"), L.dptr(d_c, "rays_d"),
+            L.dptr(noise_c, "noise"), L.dptr(u_c, "u"), stride, seed, step, ray0, R, S, int(N), L.COLOR[color_mode],
+            int(bool(white_bkgd)), int(bool(farcolorfix)), float(zero_tol), float(eps), L.dptr(rgb), L.dptr(disp),
+            L.dptr(acc), L.dptr(depth), L.dptr(w), L.dptr(tau), L.dptr(T), L.dptr(hyp), L.dptr(inds, "inds", torch.int64),
+            None if u_used is u_c else L.dptr(u_used), L.dptr(z_std), L.stream()), "plnerf_fine_epilogue")
+        ctx.save_for_backward(raw_c, z_c, near_c, far_c, d_c, noise_c if noise_c is not None else torch.empty(0),
+                              depth, acc, tau, T, u_used, inds)
+        ctx.cfg = ("linear", color_mode, bool(white_bkgd), bool(farcolorfix), noise_c is not None)
+        ctx.sampler = (float(zero_tol), float(eps))
+        ctx.mark_non_differentiable(u_used, inds, z_std)
+        ctx.set_materialize_grads(False)
+        return rgb, disp, acc, depth, w, tau, T, hyp, u_used, inds, z_std
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_depth, g_w, g_tau, g_T, g_hyp, g_u, g_inds, g_std):
+        raw_c, z_c, near_c, far_c, d_c, noise_c, depth, acc, tau, T, u_used, inds = ctx.saved_tensors
+        if g_hyp is not None:
+            R, S = z_c.shape
+            N = inds.shape[-1]
+            zero_tol, eps = ctx.sampler
+            gt, gT = torch.empty(R, S + 2, device=z_c.device), torch.empty(R, S + 2, device=z_c.device)
+            L.check(L.lib().plnerf_sample_pl_bwd(
+                L.dptr(z_c), L.dptr(tau), L.dptr(T), L.dptr(near_c), L.dptr(far_c), L.dptr(u_used), N,
+                L.dptr(inds, "inds", torch.int64), L.dptr(_f32c(g_hyp)), R, S, N, zero_tol, eps, L.dptr(gt), L.dptr(gT),
+                L.stream()), "plnerf_sample_pl_bwd")
+            g_tau = gt if g_tau is None else g_tau + gt
+            g_T = gT if g_T is None else g_T + gT
+        g_raw = _quad_backward((raw_c, z_c, near_c, far_c, d_c, noise_c, depth, acc), ctx.cfg, g_rgb, g_disp, g_acc, g_w,
+                               g_depth, g_tau, g_T)
+        return (g_raw,) + (None,) * 13
 
 
 _LOSS_WS = {}
@@ -380,6 +449,9 @@ class MlpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pts, viewdirs, embedded, cam, spr, net, want_grad, *params):
         pe_scale = float(getattr(net, "_query_scale", 1.0))      # (set by NeRF.query for the duration of the call)
+        # the density activation (depth-supervised variant: softplus, beta 10) in the kernel's last store; its
+        # derivative on the backward's entry, from the activated output saved below
+        beta = float(getattr(net, "density_beta", 0.0))
         prec = L.PRECISION[net.precision]
         # The kernels produce parameter gradients only (the sample positions carry no gradient
         # on the reference's path).  A gradient requested for an MLP *input* would be dropped silently by returning
@@ -413,8 +485,8 @@ class MlpFn(torch.autograd.Function):
             ev[0].record()
         L.check(L.lib().plnerf_mlp_fwd(
             L.dptr(packed, "packed"), prec, L.dptr(pts_c, "pts"), L.dptr(vd_c, "viewdirs"),
-            L.dptr(emb_c, "embedded"), int(net.input_ch), int(net.hip_view_ch), n_rows, int(spr), pe_scale, L.dptr(raw),
-            L.dptr(saved), L.FWD_KERNEL, L.stream()), "plnerf_mlp_fwd")
+            L.dptr(emb_c, "embedded"), int(net.input_ch), int(net.hip_view_ch), n_rows, int(spr), pe_scale, beta,
+            L.dptr(raw), L.dptr(saved), L.FWD_KERNEL, L.stream()), "plnerf_mlp_fwd")
         if timer is not None:
             ev[1].record()
         ctx.net, ctx.prec, ctx.n_rows = net, prec, n_rows
@@ -425,6 +497,9 @@ class MlpFn(torch.autograd.Function):
         ctx.n_cam = 0 if cam is None else int(cam.numel())
         # (the view layer's weight, for the camera code's gradient: the packed copy is not in [out][in] order)
         ctx.view_weight = params[16].detach() if (ctx.n_cam and need_grad) else None
+        ctx.beta = beta
+        if beta > 0.0 and saved is not None:
+            ctx.save_for_backward(raw)      # (an output: autograd keeps it without a reference cycle)
         return raw
 
     @staticmethod
@@ -454,8 +529,9 @@ class MlpFn(torch.autograd.Function):
             ev[0].record()
         L.check(L.lib().plnerf_mlp_bwd(
             L.dptr(ctx.packed), prec, L.dptr(g, "g_raw"), int(ctx.net.input_ch), int(ctx.net.hip_view_ch), n_rows,
-            L.dptr(ctx.saved_acts), ctx.saved_layout, L.dptr(ws), L.ptr_table(grads, "grads"),
-            ctypes.c_void_p(full.data_ptr() + 4 * n_grad), L.stream()), "plnerf_mlp_bwd")
+            L.dptr(ctx.saved_acts), ctx.saved_layout, L.dptr(ctx.saved_tensors[0]) if ctx.beta > 0.0 else None, ctx.beta,
+            L.dptr(ws), L.ptr_table(grads, "grads"), ctypes.c_void_p(full.data_ptr() + 4 * n_grad), L.stream()),
+            "plnerf_mlp_bwd")
         if timer is not None:
             ev[1].record()
         g_cam = None
@@ -663,8 +739,9 @@ def embed_rows(pts, viewdirs, cam, n_freqs_xyz, n_freqs_dir, input_scale=1.0, bb
     return out
 
 
-def depth_loss_and_grads(rgb, rgb0, target, pred_hyp, target_h, weight, threshold=0.0, mask=None):
-    """plnerf_depth_loss: the depth-supervised loop's loss and its three gradients in one launch.
+def depth_loss_and_grads(rgb, rgb0, target, pred_hyp, target_h, weight, threshold=0.0, mask=None, is_joint=False):
+    """plnerf_depth_loss: the depth-supervised loop's loss and its three gradients in one launch (is_joint: the
+    hypothesis is chosen per image -- per point column -- instead of per ray, model/run_nerf_helpers.py:72-77).
     Returns (loss5 = [total, img, img0, space carving, psnr], g_rgb, g_rgb0, g_hyp); rgb0 / pred_hyp may be None."""
     rgb_c, t_c = _f32c(rgb), _f32c(target)
     rgb0_c = None if rgb0 is None else _f32c(rgb0)
@@ -686,6 +763,7 @@ def depth_loss_and_grads(rgb, rgb0, target, pred_hyp, target_h, weight, threshol
     ws = _loss_workspace(rgb_c.device, L.DEPTH_LOSS_WORKSPACE_BYTES, "depth")
     L.check(L.lib().plnerf_depth_loss(L.dptr(rgb_c, "rgb"), L.dptr(rgb0_c, "rgb0"), L.dptr(t_c, "target"),
                                       L.dptr(hyp_c, "pred_hyp"), L.dptr(th_c, "target_h"), L.dptr(mask_c, "mask"), R, P, H,
-                                      PT, float(weight), float(threshold), L.dptr(loss5), L.dptr(g1), L.dptr(g0),
+                                      PT, int(bool(is_joint)), float(weight), float(threshold), L.dptr(loss5), L.dptr(g1),
+                                      L.dptr(g0),
                                       L.dptr(g_h), L.dptr(ws, "workspace", torch.float64), L.stream()), "plnerf_depth_loss")
     return loss5, g1, g0, g_h

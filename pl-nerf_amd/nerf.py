@@ -162,16 +162,16 @@ class NeRF(nn.Module):
     def _outputs(self, raw):
         """The kernels' four channels as the reference module returns them: with output_linear the reference has
         output_ch columns (5 when N_importance > 0, run_plnerf.py:424); raw2outputs reads the first four, the rest is
-        returned as zeros."""
-        raw = self._activate(raw)
+        returned as zeros.  (The density activation, if any, happened in the kernel: density_beta.)"""
         if not self.use_viewdirs and self.output_linear.out_features > 4:
             raw = torch.cat([raw, raw.new_zeros(*raw.shape[:-1], self.output_linear.out_features - 4)], -1)
         return raw
 
-    def _activate(self, raw):
-        if self.density_activation == "softplus":   # depth_supervised_exps/model/run_nerf_helpers.py:200
-            return torch.cat([raw[..., :3], F.softplus(raw[..., 3:], beta=10)], -1)
-        return raw
+    @property
+    def density_beta(self):
+        """plnerf_mlp_fwd / _bwd's `density_beta`: F.softplus(alpha, beta=10) on the density channel
+        (depth_supervised_exps/model/run_nerf_helpers.py:200) inside the kernels, 0 = none."""
+        return 10.0 if self.density_activation == "softplus" else 0.0
 
     def param_list(self):
         """The 24 parameter tensors of the network the kernels are compiled for (D = 8, W = 256, skip after layer 4,

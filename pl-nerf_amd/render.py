@@ -248,7 +248,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_
             u = _draw_u([N_rays], N_importance, det, pytest, dev) if (pytest or det or draws is None) else None
             rgb_map_0, disp_map_0, acc_map_0, depth_map_0, z_vals, pts, z_std = Fn.CoarseEpilogueFn.apply(
                 _rgb_sigma(raw), z_vals, near, far, rays_o, rays_d, _draw_noise(raw, raw_noise_std, pytest), u,
-                N_importance, color_mode, white_bkgd, farcolorfix, zero_tol, epsilon, draws)
+                N_importance, color_mode, white_bkgd, farcolorfix, zero_tol, epsilon, draws, False)
         else:
             rgb_map, disp_map, acc_map, weights, depth_map, tau, T = raw2outputs(
                 raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std, pytest=pytest, white_bkgd=white_bkgd,

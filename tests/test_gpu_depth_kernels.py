@@ -17,7 +17,7 @@ import pytest
 import torch
 
 from oracle import plnerf_oracle as orc
-from test_gpu_parity import dev, g
+from test_gpu_parity import assert_close, dev, g
 
 pytestmark = pytest.mark.gpu
 
@@ -65,33 +65,38 @@ def test_embed_rows_matches_the_reference_expressions(P, cfg):
     assert got_x.shape[1] == 3 + 6 * fx and float((got_x - want[:, :3 + 6 * fx]).abs().max()) <= (5e-7 if fx <= 10 else 2e-2)
 
 
-@pytest.mark.parametrize("case", ["full", "no_coarse", "target_per_point", "mask_threshold", "no_depth_term"])
+@pytest.mark.parametrize("case", ["full", "no_coarse", "target_per_point", "mask_threshold", "no_depth_term",
+                                  "joint", "joint_target_per_point", "joint_mask_threshold"])
 def test_depth_loss_and_gradients_match_autograd(P, case):
+    """plnerf_depth_loss against autograd of the oracle's restatement of the reference loss, per-ray and is_joint
+    (model/run_nerf_helpers.py:52-86); and depth.compute_space_carving_loss -- the reference-named function, backed by
+    the same kernel -- as a differentiable scalar."""
     from plnerf_amd import depth as Dp, functional as Fn
+    joint = case.startswith("joint")
     gen = torch.Generator().manual_seed(9)
     R, Pn, H = 300, 64, 3
     rgb = torch.rand(R, 3, generator=gen).requires_grad_(True)
     rgb0 = torch.rand(R, 3, generator=gen).requires_grad_(True)
     target = torch.rand(R, 3, generator=gen)
     hyp = (2.0 + 4.0 * torch.rand(R, Pn, generator=gen)).requires_grad_(True)
-    th = 2.0 + 4.0 * torch.rand(H, R, Pn if case == "target_per_point" else 1, generator=gen)
+    th = 2.0 + 4.0 * torch.rand(H, R, Pn if case.endswith("target_per_point") else 1, generator=gen)
     th[1, 5] = hyp.detach()[5, :1] if th.shape[-1] == 1 else hyp.detach()[5]      # an exact hit: |x| at 0
-    mask = (torch.rand(R, generator=gen) > 0.3).float() if case == "mask_threshold" else None
-    thr = 0.25 if case == "mask_threshold" else 0.0
+    mask = (torch.rand(R, generator=gen) > 0.3).float() if case.endswith("mask_threshold") else None
+    thr = 0.25 if case.endswith("mask_threshold") else 0.0
     w = 0.007
     use0, use_h = case != "no_coarse", case != "no_depth_term"
     loss = torch.mean((rgb - target) ** 2)
     img = loss
     sc = torch.zeros(())
     if use_h:
-        sc = Dp.compute_space_carving_loss(hyp, th, is_joint=False, mask=mask, norm_p=2, threshold=thr)
+        sc = orc.compute_space_carving_loss(hyp, th, is_joint=joint, mask=mask, norm_p=2, threshold=thr)
         loss = loss + w * sc
     if use0:
         loss = loss + torch.mean((rgb0 - target) ** 2)
     loss.backward()
     loss5, g1, g0, gh = Fn.depth_loss_and_grads(g(rgb.detach()), g(rgb0.detach()) if use0 else None, g(target),
                                                 g(hyp.detach()) if use_h else None, g(th) if use_h else None, w,
-                                                threshold=thr, mask=None if mask is None else g(mask))
+                                                threshold=thr, mask=None if mask is None else g(mask), is_joint=joint)
     l5 = loss5.cpu()
     assert abs(float(l5[0]) - float(loss)) <= 1e-6 * abs(float(loss)) + 1e-8, (float(l5[0]), float(loss))
     assert abs(float(l5[1]) - float(img)) <= 1e-6 * float(img) + 1e-8
@@ -108,6 +113,13 @@ def test_depth_loss_and_gradients_match_autograd(P, case):
         close(gh, hyp.grad, "g_hyp")
         assert float(gh.cpu()[5].abs().max()) >= 0.0      # (finite at the exact hit: torch.norm's sub-gradient 0)
         assert torch.isfinite(gh).all()
+        # the reference-named function on the device: same value, and a gradient through autograd
+        x = g(hyp.detach()).requires_grad_(True)
+        val = Dp.compute_space_carving_loss(x, g(th), is_joint=joint, mask=None if mask is None else g(mask), norm_p=2,
+                                            threshold=thr)
+        assert abs(float(val) - float(sc)) <= 1e-6 * abs(float(sc)) + 1e-8
+        (3.0 * val).backward()
+        close(x.grad * (w / 3.0), hyp.grad, "compute_space_carving_loss grad")
 
 
 @pytest.mark.parametrize("precision", ["fp32", "f16x3"])
@@ -248,3 +260,116 @@ def test_camera_code_against_the_reference_fixture(P, golden, precision):
     print(f"{precision} G8c: raw {err:.2e}; " + ", ".join(f"{k} {v:.2e}" for k, v in rel.items()))
     assert err <= 1e-5 * (1.0 + float(T(gd["raw"]).abs().max()))
     assert all(v <= tol for v in rel.values()), rel
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16"])
+def test_density_activation_inside_the_kernels_equals_softplus_behind_them(P, precision):
+    """NeRF(density_activation="softplus") applies F.softplus(sigma, beta=10)
+    (depth_supervised_exps/model/run_nerf_helpers.py:200) in the forward kernel's last store and its derivative on the
+    backward's entry (plnerf_mlp_fwd / _bwd `density_beta`).  Against the same network without activation followed by
+    torch's softplus and autograd: outputs to 1e-6, every parameter gradient to 2e-6 of its largest entry -- the two
+    backward passes run the SAME kernels on the same saved state; only where sigmoid(beta sigma) is multiplied in
+    differs.  Inputs cover both branches of softplus (beta sigma > 20) and very negative densities."""
+    import torch.nn.functional as F
+    sd = orc.closed_form_state_dict(0, True)
+
+    def net(act):
+        n = P.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True,
+                   precision=precision, density_activation=act)
+        n.load_state_dict(sd)
+        return n.to(dev())
+    a, b = net("softplus"), net(None)
+    gen = torch.Generator().manual_seed(3)
+    R, S = 70, 33
+    pts = g((torch.rand(R, S, 3, generator=gen) * 2 - 1) * 2.5)
+    vd = g(torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1))
+    cot = g(torch.randn(R, S, 4, generator=gen))
+    ya = a.query(pts, vd)
+    yb = b.query(pts, vd)
+    yb = torch.cat([yb[..., :3], F.softplus(yb[..., 3:], beta=10)], -1)
+    sig = yb[..., 3]
+    assert float(sig.max()) > 2.5 and float(sig.min()) < 1e-6, (float(sig.min()), float(sig.max()))   # both regimes present
+    assert_close(ya, yb.detach(), atol=1e-6, rtol=1e-6, what=f"{precision} softplus forward")
+    (ya * cot).sum().backward()
+    (yb * cot).sum().backward()
+    worst = 0.0
+    for (name, p), q in zip(a.named_parameters(), b.parameters()):
+        scale = max(float(q.grad.abs().max()), 1e-12)
+        worst = max(worst, float((p.grad - q.grad).abs().max()) / scale)
+    print(f"{precision}: in-kernel softplus vs torch softplus behind the kernel: worst grad diff / max|g| = {worst:.2e}")
+    assert worst <= 2e-6 if precision == "fp32" else worst <= 2e-3
+
+
+def test_depth_render_one_launch_stages_equal_the_separate_launches(P, golden):
+    """depth.render_rays in piecewise-linear mode runs the coarse -> fine transition as plnerf_coarse_epilogue and the
+    last stage (raw2outputs + the hypotheses' sampler + z_std) as plnerf_fine_epilogue.  Switched off
+    (depth.FUSE_STAGES), the same call runs plnerf_quad_fwd / plnerf_sample_pl / plnerf_merge_sort / plnerf_ray_points /
+    torch.std one after the other: every output must be bit-identical, and so must the gradients of a loss through the
+    maps AND pred_hyp (the fused backward = plnerf_sample_pl_bwd + plnerf_quad_bwd, like the separate one)."""
+    from test_gpu_modes import _depth_setup
+    from plnerf_amd import depth as Dp
+    gd = golden("g8b_depth_variant_128_64")
+    batch, _ = orc.synthetic_blender_rays(300, seed=21)
+    batch = g(batch)
+    outs, grads = [], []
+    for fuse in (True, False):
+        _, kw, grad_vars, _ = _depth_setup(gd, "fp32")
+        Dp.FUSE_STAGES = fuse
+        try:
+            ret = Dp.render_rays(batch, retraw=True, pytest=True, **kw)
+            loss = ret["rgb_map"].sum() + 0.3 * ret["rgb0"].mean() + 0.01 * ret["pred_hyp"].square().mean() + \
+                ret["depth_map"].mean()
+            loss.backward()
+        finally:
+            Dp.FUSE_STAGES = True
+        outs.append({k: v.detach().clone() for k, v in ret.items()})
+        grads.append([p.grad.detach().clone() for p in grad_vars])
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+    # N_importance = 0: the hypotheses come from the one network's own pass
+    _, kw, _, _ = _depth_setup(gd, "fp32")
+    kw1 = dict(kw, N_importance=0, network_fine=None)
+    single = []
+    for fuse in (True, False):
+        Dp.FUSE_STAGES = fuse
+        try:
+            with torch.no_grad():
+                single.append(Dp.render_rays(batch, retraw=True, pytest=True, **kw1))
+        finally:
+            Dp.FUSE_STAGES = True
+    for k in single[0]:
+        assert torch.equal(single[0][k], single[1][k]), k
+
+
+def test_depth_step_is_invariant_to_sharding_of_the_batch(P, golden):
+    """With a DrawSource installed (DepthTrainStep does) every draw of the depth-supervised render -- jitter, importance
+    samples, the hypotheses' u, is_joint's one row -- is a function of (seed, step, GLOBAL ray id): a batch rendered in
+    one piece equals the same rays rendered as two shards (to the MLP kernels' summation-order rounding), and the
+    returned draws are bit-equal."""
+    from test_gpu_modes import _depth_setup
+    from plnerf_amd import depth as Dp, functional as Fn
+    gd = golden("g8b_depth_variant_128_64")
+    _, kw, _, _ = _depth_setup(gd, "f16x3")
+    batch, _ = orc.synthetic_blender_rays(96, seed=22)
+    rays = g(batch)
+
+    def run(rows, id0, **over):
+        prev = Fn.set_draw_source(Fn.DrawSource(seed=8, ray_id0=id0, step=4))
+        try:
+            with torch.no_grad():
+                return Dp.render_rays(rows, retraw=True, **dict(kw, **over))
+        finally:
+            Fn.set_draw_source(prev)
+    for over in ({}, {"is_joint": True}):
+        whole = run(rays, 0, **over)
+        a, b = run(rays[:40], 0, **over), run(rays[40:], 40, **over)
+        assert torch.equal(torch.cat([a["u"], b["u"]], 0), whole["u"])
+        if over:
+            assert torch.equal(whole["u"][0], whole["u"][-1])      # one row for the whole image
+        for k in ("rgb_map", "depth_map", "rgb0", "pred_hyp", "z_vals"):
+            assert_close(torch.cat([a[k], b[k]], 0), whole[k].cpu(), atol=2e-4 if k == "pred_hyp" else 2e-5, rtol=2e-5,
+                         what=f"two shards {k} {over}")
+    other = run(rays, 1)
+    assert not torch.equal(other["u"], run(rays, 0)["u"])

@@ -140,8 +140,9 @@ def _count_beyond(got, ref, tol=1e-5):
 
 
 # configs[3]: rays (of 4096) allowed beyond 1e-5 per final map = measured + 2, per precision
-LLFF_MAX_BEYOND = {"f16x3": {"rgb_map": 40, "acc_map": 40, "depth_map": 40, "z_std": 40},
-                   "fp32": {"rgb_map": 40, "acc_map": 40, "depth_map": 40, "z_std": 40}}
+# (measured: f16x3 acc 7 / depth 10; fp32 acc 2 / depth 4 / z_std 1 -- the density noise makes more samples hop)
+LLFF_MAX_BEYOND = {"f16x3": {"rgb_map": 0, "acc_map": 9, "depth_map": 12, "z_std": 2},
+                   "fp32": {"rgb_map": 0, "acc_map": 4, "depth_map": 6, "z_std": 3}}
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "fp32"])
@@ -188,8 +189,10 @@ def test_llff_ndc_render_at_baseline_size_vs_oracle(P, precision):
 
 
 # configs[4]: counts beyond 1e-5 (pred_hyp: beyond 2e-4 -- the sampler's closed form) = measured + 2
-DEPTH_MAX_BEYOND = {"f16x3": {"rgb_map": 40, "acc_map": 40, "depth_map": 40, "z_std": 40, "pred_hyp": 40},
-                    "fp32": {"rgb_map": 40, "acc_map": 40, "depth_map": 40, "z_std": 40, "pred_hyp": 40}}
+# (measured: f16x3 rgb 1 / acc 4 / depth 43 / z_std 46 / pred_hyp 25: 1 % of the rays -- this network's softplus densities
+# are everywhere positive, so far more cdf bins carry weight a sample can hop between than under the NVS networks' relu)
+DEPTH_MAX_BEYOND = {"f16x3": {"rgb_map": 3, "acc_map": 6, "depth_map": 45, "z_std": 48, "pred_hyp": 27},
+                    "fp32": {"rgb_map": 3, "acc_map": 6, "depth_map": 45, "z_std": 48, "pred_hyp": 27}}
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "fp32"])
