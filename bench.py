@@ -248,7 +248,7 @@ def build_step(P, a, precision, scene, dev, rank, world, force_dist):
                                                    scene.near, scene.far, seed=0, step=i, ray_id0=rank * a.rays,
                                                    want_pixels=True)
             target_h = scene.hyp[v][:, pix[:, 0].long(), pix[:, 1].long()].unsqueeze(-1)
-            loss, _, _, _ = ts(cols.packed(), target, target_h)
+            loss, _, _, _ = ts(cols, target, target_h)
             return loss
         return step, nets
     args = make_args(a, ck, precision)

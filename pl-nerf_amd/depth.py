@@ -14,6 +14,7 @@ What differs from the NVS path (render.py):
   * one Adam over both networks, gradient values clipped to 0.1 (:1155-1157).
 """
 import os
+import sys
 
 import numpy as np
 import torch
@@ -23,8 +24,16 @@ from . import functional as Fn
 from . import raybatch as RB
 from .nerf import Embedder, NeRF
 from .optim import FlatAdam
-from .render import (MAX_ROWS_PER_LAUNCH, _draw_noise, _draw_u as _nvs_draw_u, _rgb_sigma, batchify, raw2outputs as _raw2outputs,
-                     sample_pdf, sample_pdf_reformulation)
+from .render import (MAX_ROWS_PER_LAUNCH, _draw_noise, _rgb_sigma, batchify, raw2outputs as _raw2outputs, sample_pdf,
+                     sample_pdf_reformulation)
+
+_RENDER = sys.modules[__name__.rsplit(".", 1)[0] + ".render"]      # (the package attribute `render` is the function)
+
+
+def _nvs_draw_u(*args):
+    """The importance draw of the NVS sampler (render._draw_u), looked up at call time like sample_pdf_reformulation
+    itself does (a test that injects its draws there reaches both routes)."""
+    return _RENDER._draw_u(*args)
 
 
 def get_embedder(multires, i=0):
@@ -215,11 +224,17 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
     depth_map, z_vals, weights, pred_hyp, u (+ raw; + rgb0, disp0, acc0, depth0, z_vals0, weights0, z_std)."""
     dev = ray_batch.device
     N_rays = ray_batch.shape[0]
-    rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
-    viewdirs = ray_batch[:, 8:11].contiguous() if use_viewdirs else None
-    near, far = ray_batch[:, 6:7].contiguous(), ray_batch[:, 7:8].contiguous()
+    if isinstance(ray_batch, RB.RayColumns):      # (what plnerf_select_rays writes: no packing, no slice copies)
+        rays_o, rays_d, near, far = ray_batch.rays_o, ray_batch.rays_d, ray_batch.near.reshape(-1, 1), \
+            ray_batch.far.reshape(-1, 1)
+        viewdirs = ray_batch.viewdirs if use_viewdirs else None
+    else:
+        rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
+        viewdirs = ray_batch[:, 8:11].contiguous() if use_viewdirs else None
+        near, far = ray_batch[:, 6:7].contiguous(), ray_batch[:, 7:8].contiguous()
     t_vals = Fn.cpu_linspace(N_samples, dev)
-    fused_glue = ray_batch.is_cuda and N_rays > 0 and not (torch.is_grad_enabled() and ray_batch.requires_grad)
+    fused_glue = ray_batch.is_cuda and N_rays > 0 and not (torch.is_grad_enabled() and
+                                                           getattr(ray_batch, "requires_grad", False))
     draws = None if pytest else Fn.DRAWS      # counter-based draws inside the consuming kernels (functional.DrawSource)
     if draws is not None:
         draws.noise_calls = 0

@@ -189,10 +189,10 @@ def test_llff_ndc_render_at_baseline_size_vs_oracle(P, precision):
 
 
 # configs[4]: counts beyond 1e-5 (pred_hyp: beyond 2e-4 -- the sampler's closed form) = measured + 2
-# (measured: f16x3 rgb 1 / acc 4 / depth 43 / z_std 46 / pred_hyp 25: 1 % of the rays -- this network's softplus densities
+# (measured: f16x3 rgb 1 / acc 4 / depth 43 / z_std 46 / pred_hyp 25; fp32 1 / 5 / 53 / 47 / 24: 1 % of the rays -- this network's softplus densities
 # are everywhere positive, so far more cdf bins carry weight a sample can hop between than under the NVS networks' relu)
 DEPTH_MAX_BEYOND = {"f16x3": {"rgb_map": 3, "acc_map": 6, "depth_map": 45, "z_std": 48, "pred_hyp": 27},
-                    "fp32": {"rgb_map": 3, "acc_map": 6, "depth_map": 45, "z_std": 48, "pred_hyp": 27}}
+                    "fp32": {"rgb_map": 3, "acc_map": 7, "depth_map": 55, "z_std": 49, "pred_hyp": 26}}
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "fp32"])

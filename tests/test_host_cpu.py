@@ -440,6 +440,51 @@ for step in range(3):
     gathered = [None] * world
     dist.all_gather_object(gathered, digest)
     assert gathered[0] == gathered[1], f"replicas diverged at step {step}"
+# The exchange as train.TrainStep uses it since round 4: the buffer carries the network's range status as a tail element
+# (functional.MlpFn.backward's layout: 24 gradients + GRAD_TAIL floats, registered as net._grad_flat), `finish` leaves the
+# SUM in .grad and hands back the 1 / world factor for the optimizer's step kernel, `tails` the summed status words --
+# one collective per network, no scaling pass, no status collective.
+class FlatGradTailFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, net, flag, *params):
+        ctx.save_for_backward(x)
+        ctx.shapes, ctx.net, ctx.flag = [p.shape for p in params], net, flag
+        return sum(torch.cos((k + 1) * x) * p.sum() for k, p in enumerate(params))
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        sizes = [int(torch.Size(s).numel()) for s in ctx.shapes]
+        full = torch.empty(sum(sizes) + dp.GradientBucket.TAIL, dtype=torch.float32)
+        full[sum(sizes):] = 0.0
+        full[sum(sizes)] = ctx.flag                       # (what the weight-gradient reduction kernel writes)
+        ctx.net.__dict__["_grad_flat"] = full
+        grads = [t.view(s) for t, s in zip(full[:sum(sizes)].split(sizes), ctx.shapes)]
+        for k, gr in enumerate(grads):
+            gr.fill_(float((g * torch.cos((k + 1) * x)).sum()))
+        return (None, None, None) + tuple(grads)
+
+
+for n in nets:
+    n.zero_grad(set_to_none=True)
+out = FlatGradTailFn.apply(X[lo:hi], nets[0], 1.0 if rank == 1 else 0.0, *nets[0].parameters()) + \
+    0.5 * FlatGradTailFn.apply(X[lo:hi], nets[1], 0.0, *nets[1].parameters())
+((out - Y[lo:hi]) ** 2).sum().backward()                  # (sum, not mean: the SUM over ranks is then the full-batch gradient)
+assert bucket.pending() == 2
+scale = bucket.finish([nets[1]], defer_scale=True)        # the fine network first, as the two-stream step does ...
+assert scale == 0.5 and bucket.pending() == 1
+scale = bucket.finish([nets[0]], defer_scale=True)        # ... then the other one
+assert scale == 0.5 and bucket.pending() == 0 and bucket.collectives == 1
+tails = bucket.tails()
+assert [float(t) for t in tails] == [1.0, 0.0], [float(t) for t in tails]      # rank 1's flag reached both ranks, net 0 only
+for r in ref:
+    r.zero_grad(set_to_none=True)
+out = FlatGradFn.apply(X, *ref[0].parameters()) + 0.5 * FlatGradFn.apply(X, *ref[1].parameters())
+((out - Y) ** 2).sum().backward()
+for n, r in zip(nets, ref):
+    for p, q in zip(n.parameters(), r.parameters()):      # .grad holds the SUM over the ranks = the full batch's gradient
+        assert float((p.grad - q.grad).abs().max()) <= 1e-3 * float(q.grad.abs().max()) + 1e-6
+    assert n._grad_flat.data_ptr() == next(n.parameters()).grad.data_ptr()       # in place
 print(f"rank {rank} ok")
 '''
 
