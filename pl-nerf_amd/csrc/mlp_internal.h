@@ -34,7 +34,12 @@ int absmax_act(const float* g_raw, const float* raw_out, float beta, int n_rows,
 // max |x| over n floats as fp32 bits (non-negative floats order like unsigned integers) -> *out
 int absmax(const float* x, size_t n, unsigned* out, hipStream_t st);
 // bytes of the half dz planes of n_rows rows, rounded up to 16
-inline size_t h16_dz_bytes(int n_rows) { return (size_t)4864 * (((size_t)n_rows + 63) / 64 * 64); }      // (lay::dz_rows)
+#ifndef PLNERF_BWD_TM
+#define PLNERF_BWD_TM 128
+#endif
+inline size_t h16_dz_bytes(int n_rows) {      // (lay::dz_rows)
+    return (size_t)4864 * (((size_t)n_rows + PLNERF_BWD_TM - 1) / PLNERF_BWD_TM * PLNERF_BWD_TM);
+}
 
 // 16-bit-operand MFMA modes.  ns = 1: plain operands; ns = 2: 3-term split (hi/lo planes).
 // f16 = 0: bf16 elements; f16 = 1: IEEE half elements.

@@ -122,12 +122,18 @@ __host__ __device__ constexpr size_t sv_tiled_index(size_t row, int col, int wid
 // The half dz planes (backward workspace): rows padded to the dgrad kernel's 64-row tiles; the 256-wide planes dz0..dz7
 // and dz_feature in the TILED order above (the dgrad kernel's accumulators leave as contiguous KiB fragments, no LDS ->
 // HBM copy pass; the weight-gradient kernels read them as they are), dz_view (128 wide, not an MFMA product) row-major.
-constexpr int DZ_ROW_PAD = 64;
+#ifndef PLNERF_BWD_TM
+#define PLNERF_BWD_TM 128     // rows per workgroup tile of the half dgrad kernel (mlp_h16_body.inc)
+#endif
+constexpr int DZ_ROW_PAD = PLNERF_BWD_TM;
 __host__ __device__ constexpr size_t dz_rows(size_t n_rows) { return (n_rows + DZ_ROW_PAD - 1) / DZ_ROW_PAD * DZ_ROW_PAD; }
 constexpr int SVH_BYTES_PER_ROW = SV_FLOATS * 2 + SV_MASK_BYTES;   // 5328
 constexpr int DZH_BYTES_PER_ROW = DZ_PER_ROW * 2;                  // 4864
 constexpr int WSH_SCALARS_BYTES = 16;                              // max |g_raw| (fp32 bits) + pad
-constexpr float DZH_TARGET_EXP = 4.0f;                             // scaled max |g_raw| in [2^3, 2^4)
+#ifndef PLNERF_DZH_TARGET_EXP
+#define PLNERF_DZH_TARGET_EXP 4
+#endif
+constexpr float DZH_TARGET_EXP = (float)(PLNERF_DZH_TARGET_EXP);   // scaled max |g_raw| in [2^3, 2^4)
 constexpr float H16_MAX = 65504.0f;
 
 // split-K partial sums of the weight gradients (per split)

@@ -18,14 +18,22 @@ ap.add_argument("--views", type=int, default=8)
 ap.add_argument("--pipeline", type=int, default=0)
 ap.add_argument("--seeds", default="0,1,2")
 ap.add_argument("--no-twin", action="store_true")
+ap.add_argument("--only-run", action="store_true", help="the precision's run alone (no fp32 reference, no twin)")
 a = ap.parse_args()
 rows = []
 for seed in [int(x) for x in a.seeds.split(",")]:
     out = psnr_vs_ref(P, torch.device("cuda:0"), a.steps, rays=a.rays, precision=a.precision, views=a.views,
-                      seed=seed, pipeline=a.pipeline, with_twin=not a.no_twin)
+                      seed=seed, pipeline=a.pipeline, with_twin=not a.no_twin, only_run=a.only_run)
     out["seed"] = seed
     rows.append(out)
     print(json.dumps(out), flush=True)
+
+
+if a.only_run:
+    print(json.dumps({"summary": True, "only_run": True, "precision": a.precision, "lib": os.environ.get("PLNERF_HIP_LIB", "default"),
+                      "psnr_train_tail_mean": [r["run"]["psnr_train_tail_mean"] for r in rows],
+                      "psnr_heldout_view": [r["run"]["psnr_heldout_view"] for r in rows]}), flush=True)
+    sys.exit(0)
 
 
 def ms(v):

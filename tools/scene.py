@@ -108,7 +108,7 @@ def train_psnr(P, scene, precision, steps, dev, rays=4096, seed=0, pipeline=0, t
             "loss_tail_mean": float(losses[-tail:].mean())}
 
 
-def psnr_vs_ref(P, dev, steps, rays=4096, precision="f16x3", views=8, seed=0, pipeline=0, with_twin=False):
+def psnr_vs_ref(P, dev, steps, rays=4096, precision="f16x3", views=8, seed=0, pipeline=0, with_twin=False, only_run=False):
     """The benchmarked arithmetic against the exact-fp32 kernels (reference-equal gradients, pinned to the oracle at
     1e-5 by tests/test_gpu_fullsize.py) on the same scene, weights and draws: {run, ref, gap_db ...}."""
     scene = AnalyticScene(P, views, dev)
@@ -125,6 +125,8 @@ def psnr_vs_ref(P, dev, steps, rays=4096, precision="f16x3", views=8, seed=0, pi
             {k: v.clone() for k, v in kw0["network_fine"].state_dict().items()})
     del kw0
     run = train_psnr(P, scene, precision, steps, dev, rays, seed, pipeline, init=init)
+    if only_run:      # (a kernel variant's run alone: the fp32 reference of the same seed is already on file)
+        return {"run": run}
     ref = train_psnr(P, scene, "fp32", steps, dev, rays, seed, pipeline, init=init)
     twin = None
     if with_twin:
