@@ -40,7 +40,7 @@ if ROOT not in sys.path:
 
 FWD_FLOP_PER_ROW = 1186816      # 2 x 593,408 MAC per network evaluation
 TRAIN_FLOP_PER_ROW = 3489024    # forward + wgrad + dgrad
-TRAFFIC_FILE = "r03_traffic.json"   # refreshed per round by tools/pmc_traffic.sh
+TRAFFIC_FILE = "r04_traffic.json"   # refreshed per round by tools/pmc_traffic.sh
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s HBM3E
 # training forward, algorithmic bytes per row: saved state written + xyz read (12) + raw written (16)
 FWD_TRAIN_BYTES_PER_ROW = {"fp32": 2596 * 4 + 28, "h16": 2528 * 2 + 272 + 28}   # fp32 planes | half planes + relu masks
@@ -457,8 +457,9 @@ def main(argv=None):
         scene = Scene(P, a.workload, a.views, dev)
         step, nets = build_step(P, a, a.precision, scene, dev, rank, world, a.force_dist)
     if a.force_dist and world == 1 and not cpu:     # exercise the RCCL path on one GPU
-        _allreduce = dp.GradientBucket.allreduce_mean
-        dp.GradientBucket.allreduce_mean = lambda self, group=None, force=False: _allreduce(self, group, True)
+        _finish = dp.GradientBucket.finish
+        dp.GradientBucket.finish = lambda self, modules=None, defer_scale=False, group=None, force=False: \
+            _finish(self, modules, defer_scale, group, True)
     R = a.rays
     rows_fine = R * (a.n_samples + a.n_importance)
 

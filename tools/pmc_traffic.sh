@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/pmc_traffic; rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d $out/$c --output-format csv -- python $R/bench.py --no-cpu-baseline --no-strict-fp32 --steps 3 --warmup 1 > $out/bench_$c.json 2> $out/err_$c.log
+  rocprofv3 --pmc $c -d $out/$c --output-format csv -- python $R/bench.py --no-cpu-baseline --no-strict-fp32 --no-extra-legs --steps 3 --warmup 1 > $out/bench_$c.json 2> $out/err_$c.log
 done
 python $R/tools/pmc_summary.py $out/FETCH_SIZE $out/WRITE_SIZE > $out/summary.txt
 python - <<PY
