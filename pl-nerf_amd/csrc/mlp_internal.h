@@ -35,7 +35,7 @@ int absmax_act(const float* g_raw, const float* raw_out, float beta, int n_rows,
 int absmax(const float* x, size_t n, unsigned* out, hipStream_t st);
 // bytes of the half dz planes of n_rows rows, rounded up to 16
 #ifndef PLNERF_BWD_TM
-#define PLNERF_BWD_TM 128
+#define PLNERF_BWD_TM 192
 #endif
 inline size_t h16_dz_bytes(int n_rows) {      // (lay::dz_rows)
     return (size_t)4864 * (((size_t)n_rows + PLNERF_BWD_TM - 1) / PLNERF_BWD_TM * PLNERF_BWD_TM);

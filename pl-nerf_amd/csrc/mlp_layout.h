@@ -123,7 +123,7 @@ __host__ __device__ constexpr size_t sv_tiled_index(size_t row, int col, int wid
 // and dz_feature in the TILED order above (the dgrad kernel's accumulators leave as contiguous KiB fragments, no LDS ->
 // HBM copy pass; the weight-gradient kernels read them as they are), dz_view (128 wide, not an MFMA product) row-major.
 #ifndef PLNERF_BWD_TM
-#define PLNERF_BWD_TM 128     // rows per workgroup tile of the half dgrad kernel (mlp_h16_body.inc)
+#define PLNERF_BWD_TM 192     // rows per workgroup tile of the half dgrad kernel (mlp_h16_body.inc)
 #endif
 constexpr int DZ_ROW_PAD = PLNERF_BWD_TM;
 __host__ __device__ constexpr size_t dz_rows(size_t n_rows) { return (n_rows + DZ_ROW_PAD - 1) / DZ_ROW_PAD * DZ_ROW_PAD; }
