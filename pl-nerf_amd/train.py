@@ -268,6 +268,10 @@ class TrainStep:
             Fn.CHAIN = None
         rgb0 = extras.get('rgb0')
         chained = chain is not None and chain.calls == 1
+        if chain is not None and not chained:
+            # render_rays did not take the two-stream path (an empty batch, ...): whatever it enqueued on the coarse
+            # stream comes before the one-stream tail below
+            chain.main.wait_stream(chain.stream)
         self.optimizer.zero_grad()
         if chained:
             # the coarse network's part of the step is already enqueued (and maybe done) on the coarse stream; here the
