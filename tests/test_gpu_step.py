@@ -505,3 +505,42 @@ def test_data_parallel_training_step_two_ranks_on_one_gpu(P, tmp_path, pipeline)
         assert p.returncode == 0, f"rank {rank} failed:\n{out[-3000:]}"
         assert f"rank {rank} ok" in out
     print([l for l in outs[0].splitlines() if l.startswith("max |param")])
+
+
+@pytest.mark.parametrize("precision,n_rows", [("f16x3", 131072), ("f16x3", 262144), ("f16x3", 1000), ("fp32", 8200),
+                                               ("fp32", 57400)])
+def test_weight_gradients_do_not_depend_on_what_the_workspace_held(P, precision, n_rows):
+    """Regression test of round 4's find: plnerf_mlp_bwd's split-K reduction must add only partials that a workgroup
+    wrote.  Rounding a row range's length up to whole stages used to leave the last ranges without a row (131,072 rows
+    over 85 ranges of 1,600: ranges 82-84; 262,144 -- the benchmark's coarse pass -- range 84), whose never-written
+    partials were summed into four gradient tensors.  Through the C ABI with a workspace the caller poisoned with NaN
+    against one it zeroed: the 24 gradients must be finite and bit-identical."""
+    import ctypes
+    from plnerf_amd import _lib as L
+    net = make_net(P, orc.closed_form_state_dict(0, False), precision)
+    prec = L.PRECISION[precision]
+    gen = torch.Generator().manual_seed(4)
+    spr = 8
+    n_rays = (n_rows + spr - 1) // spr
+    n_rows = n_rays * spr
+    pts = g((torch.rand(n_rows, 3, generator=gen) * 2 - 1) * 2.0)
+    vd = g(torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=gen), dim=-1))
+    g_raw = g(torch.randn(n_rows, 4, generator=gen))
+    packed = net.packed_weights()
+    raw = torch.empty(n_rows, 4, device=dev())
+    saved = torch.empty(L.lib().plnerf_mlp_saved_bytes(n_rows, prec) // 4, device=dev())
+    L.check(L.lib().plnerf_mlp_fwd(L.dptr(packed), prec, L.dptr(pts), L.dptr(vd), None, 63, 27, n_rows, spr, 1.0, 0.0,
+                                   L.dptr(raw), L.dptr(saved), L.FWD_KERNEL, L.stream()), "plnerf_mlp_fwd")
+    layout = L.lib().plnerf_mlp_saved_layout(prec, 0, L.FWD_KERNEL)
+    shapes = [p.shape for p in net.parameters()]
+    results = []
+    for fill in (float("nan"), 0.0):
+        ws = torch.full((L.lib().plnerf_mlp_bwd_workspace_bytes(n_rows, prec) // 4,), fill, device=dev())
+        grads = [torch.full(tuple(s), float("nan"), device=dev()) for s in shapes]
+        L.check(L.lib().plnerf_mlp_bwd(L.dptr(packed), prec, L.dptr(g_raw), 63, 27, n_rows, L.dptr(saved), layout, None, 0.0,
+                                       L.dptr(ws), L.ptr_table(grads, "grads"), None, L.stream()), "plnerf_mlp_bwd")
+        torch.cuda.synchronize()
+        results.append(grads)
+    for (name, _), a, b in zip(net.named_parameters(), *results):
+        assert torch.isfinite(a).all(), f"{name}: non-finite gradient entries out of a NaN-poisoned workspace"
+        assert torch.equal(a, b), f"{name}: the gradient depends on the workspace's previous contents"
