@@ -81,6 +81,7 @@ def _host_box(bb_center, bb_scale):
         return (id(x), x._version) if isinstance(x, torch.Tensor) else ("v", repr(x))
     k = (key(bb_center), key(bb_scale))
     hit = _BOX_CACHE.get(k)
+    hit = hit[0] if hit is not None else None
     if hit is None:
         c = torch.as_tensor(bb_center, dtype=torch.float32).reshape(-1).cpu()
         center = tuple(float(c[i if c.numel() == 3 else 0]) for i in range(3))
@@ -88,7 +89,8 @@ def _host_box(bb_center, bb_scale):
         hit = (center, scale, scale == 1.0 and not any(center))
         if len(_BOX_CACHE) > 64:
             _BOX_CACHE.clear()
-        _BOX_CACHE[k] = hit
+        # (the entry keeps the two objects alive: an id() can otherwise be handed to a new tensor after the old one died)
+        _BOX_CACHE[k] = (hit, bb_center, bb_scale)
     return hit
 
 

@@ -186,9 +186,10 @@ class TrainStep:
         return self._step(H, W, K, batch_rays, target_s, near, far, self._arm_chain(own_inputs=False))
 
     def _arm_chain(self, own_inputs):
-        """The step's CoarseChain, or None for the one-stream order (pipeline 0, or the `constant_init` warm-up and
-        other calls that do not take the two-network path: render_rays decides that itself and leaves the chain
-        unused).  The coarse stream waits for the launch stream unless the step owns its inputs (pipeline 2)."""
+        """The step's CoarseChain, or None for the one-stream order (pipeline 0).  render_rays decides itself whether a
+        call takes the two-stream path (two distinct networks, a non-empty GPU batch; `constant_init` steps do) and
+        leaves the chain unused otherwise -- _step then joins the streams.  The coarse stream waits for the launch stream
+        unless the step owns its inputs (pipeline 2)."""
         if self.chain is None:
             return None
         cross_step = self.pipeline >= 2 and own_inputs and self._chain_started
