@@ -203,11 +203,24 @@ class GradientBucket:
 
 def broadcast_optimizer_state(optimizers, src=0, group=None):
     """Rank `src`'s Adam moments and step counts to every rank (a checkpoint may have been restored on one rank only:
-    replicas that share weights but not moments diverge at the first step)."""
+    replicas that share weights but not moments diverge at the first step).  optim.FlatAdam keeps a group's moments as
+    two flat buffers: two broadcasts and one step count per group instead of three per parameter."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     for opt in optimizers:
-        for g in opt.param_groups:
+        flats = getattr(opt, "_flat", None)
+        for gi, g in enumerate(opt.param_groups):
+            fl = flats[gi] if flats is not None and gi < len(flats) else None
+            if fl is not None and all(opt.state.get(p) for p in g['params']):
+                dist.broadcast(fl['m'], src=src, group=group)
+                dist.broadcast(fl['v'], src=src, group=group)
+                steps = torch.tensor([float(opt.state[p]['step']) for p in g['params']], dtype=torch.float32,
+                                     device=fl['m'].device)
+                dist.broadcast(steps, src=src, group=group)
+                for p, v in zip(g['params'], steps.tolist()):
+                    opt.state[p]['step'] = torch.tensor(float(v))
+                fl.pop('uniform_step', None)
+                continue
             for p in g['params']:
                 st = opt.state.get(p)
                 have = torch.tensor([1 if st else 0], device=p.device)
@@ -235,9 +248,16 @@ def broadcast_scalar(value, src=0, group=None, device=None):
 
 def broadcast_parameters(modules, src=0, group=None):
     """Make every rank start from rank `src`'s weights (replicas then stay bit-identical,
-    since each applies the same averaged gradient with the same optimizer state)."""
+    since each applies the same averaged gradient with the same optimizer state).  A module whose parameters are the
+    consecutive slices of one buffer (optim.FlatAdam re-homes them so) goes in ONE broadcast."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
+    from .optim import flat_view_of
     for m in modules:
-        for p in m.parameters():
-            dist.broadcast(p.data, src=src, group=group)
+        ps = [p.data for p in m.parameters()]
+        flat = flat_view_of(ps) if ps and all(t.dtype == torch.float32 for t in ps) else None
+        if flat is not None:
+            dist.broadcast(flat, src=src, group=group)
+            continue
+        for p in ps:
+            dist.broadcast(p, src=src, group=group)
