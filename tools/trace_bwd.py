@@ -23,7 +23,9 @@ buf = np.zeros(64, dtype=np.uint64)
 assert lib.plnerf_debug_trace_f16(buf.ctypes.data) == 0
 t = buf.astype(np.int64)
 print(f"dgrad: total {t[42]-t[0]} clk;  views+feature+L7 part {t[1]-t[0]}")
+names = ("K(B) + epilogue(A)", "barrier", "K(A, next) + epilogue(B)", "barrier") if os.environ.get("PLNERF_TRACE_PIPE") else \
+        ("K loop", "barrier", "store_dz", "barrier")
 for k in range(7):
     b = 2 + 5 * k
-    prev = t[1] if k == 0 else t[b - 1 - 0]
-    print(f"  layer {7-k}: mask load {t[b]-(t[1] if k == 0 else t[b-1]):6d}  K loop {t[b+1]-t[b]:6d}  barrier {t[b+2]-t[b+1]:6d}  store_dz {t[b+3]-t[b+2]:6d}  barrier {t[b+4]-t[b+3]:6d}")
+    print(f"  layer {7-k}: loop top {t[b]-(t[1] if k == 0 else t[b-1]):6d}  " +
+          "  ".join(f"{n} {t[b+1+i]-t[b+i]:6d}" for i, n in enumerate(names)))
