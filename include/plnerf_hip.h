@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PLNERF_VERSION 400 /* major*10000 + minor*100 + patch */
+#define PLNERF_VERSION 401 /* major*10000 + minor*100 + patch */
 
 /* error codes */
 #define PLNERF_OK 0
@@ -241,6 +241,14 @@ int plnerf_select_rays(int H, int W, float fx, float fy, float cx, float cy, con
                        uint64_t seed, uint32_t step, int ray_id0, int R, float near, float far,
                        float* rays_o, float* rays_d, float* viewdirs, float* near_out, float* far_out,
                        float* target, int* pixels, plnerf_stream_t stream);
+
+/* ndc_rays (run_nerf_helpers.py:184-201; called by render, run_plnerf.py:153-155, with near = 1): forward-facing rays
+ * [n,3] warped to normalised device coordinates in one launch, bit-identical to the reference's fp32 expressions
+ * (focal and near are the call's Python floats: the scale factors -1 / (W / (2 focal)), -1 / (H / (2 focal)) and
+ * 2 near are formed in double and rounded once, as torch does with a scalar operand).  o_out / d_out may be rays_o /
+ * rays_d. */
+int plnerf_ndc_rays(int H, int W, double focal, double near, const float* rays_o, const float* rays_d, int n,
+                    float* o_out, float* d_out, plnerf_stream_t stream);
 
 /* plnerf_stratified_z + plnerf_ray_points in one launch (run_plnerf.py:683-708), bit-identical to
  * them.  perturb != 0: jitter from t_rand [R,S], or (t_rand == NULL) drawn in the kernel (stream 0). */

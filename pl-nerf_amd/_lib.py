@@ -54,6 +54,7 @@ SIGNATURES = {
     "plnerf_select_rays": (c_i, [c_i, c_i] + [ctypes.c_float] * 4 + [ctypes.POINTER(ctypes.c_float), c_f] + [c_i] * 4 +
                            [ctypes.c_uint64, ctypes.c_uint32, c_i, c_i, ctypes.c_float, ctypes.c_float] + [c_f] * 7 +
                            [c_s]),
+    "plnerf_ndc_rays": (c_i, [c_i, c_i, ctypes.c_double, ctypes.c_double, c_f, c_f, c_i, c_f, c_f, c_s]),
     "plnerf_coarse_samples": (c_i, [c_f] * 6 + [ctypes.c_uint64, ctypes.c_uint32] + [c_i] * 5 + [c_f] * 2 + [c_s]),
     "plnerf_image_loss": (c_i, [c_f] * 3 + [c_i] + [c_f] * 5 + [c_s]),
     "plnerf_depth_loss": (c_i, [c_f] * 6 + [c_i] * 5 + [ctypes.c_float] * 2 + [c_f] * 5 + [c_s]),

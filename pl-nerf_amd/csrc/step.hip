@@ -4,6 +4,7 @@
 //   plnerf_uniform         counter-based uniform draws (philox.h): the t_rand / u tensors, world-size invariant
 //   plnerf_normal          the same counters through Box-Muller: the density noise of raw2outputs (run_plnerf.py:568-570)
 //   plnerf_select_rays     run_plnerf.py:1259-1281: N_rand distinct random pixels of one view -> their rays
+//   plnerf_ndc_rays        run_nerf_helpers.py:184-201: the NDC warp of forward-facing rays
 //                          (get_rays, run_nerf_helpers.py:162-171), unit view directions (run_plnerf.py:148-150),
 //                          near / far columns and the target colours -- without building the H x W ray grid
 //   plnerf_coarse_samples  run_plnerf.py:683-708: stratified depths (jitter drawn in the kernel or read from a tensor)
@@ -143,6 +144,34 @@ __global__ __launch_bounds__(256) void select_rays_kernel(const SelectArgs a) {
         a.target[3 * (size_t)i + 2] = px[2];
     }
     if (a.pixels) { a.pixels[2 * (size_t)i] = row; a.pixels[2 * (size_t)i + 1] = col; }
+}
+
+// ---- normalised device coordinates of forward-facing rays (run_nerf_helpers.py:184-201), one thread per ray ----
+// Every operation separately rounded, in the order torch evaluates the reference's expressions (the scalars sx, sy,
+// near, 2 near, -2 near arrive already rounded to fp32, as torch rounds a Python scalar that meets an fp32 tensor).
+struct NdcArgs {
+    const float* rays_o;
+    const float* rays_d;
+    int n;
+    float sx, sy, near, two_near, minus_two_near;
+    float* o_out;
+    float* d_out;
+};
+
+__global__ __launch_bounds__(256) void ndc_rays_kernel(const NdcArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const float ox = a.rays_o[3 * (size_t)i], oy = a.rays_o[3 * (size_t)i + 1], oz = a.rays_o[3 * (size_t)i + 2];
+    const float dx = a.rays_d[3 * (size_t)i], dy = a.rays_d[3 * (size_t)i + 1], dz = a.rays_d[3 * (size_t)i + 2];
+    const float t = -(a.near + oz) / dz;                          // shift the origin to the near plane (:186-187)
+    const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
+    const float ox_oz = px / pz, oy_oz = py / pz;
+    a.o_out[3 * (size_t)i + 0] = (a.sx * px) / pz;                // o0, o1, o2 (:190-192): "s * x / z" is (s x) / z
+    a.o_out[3 * (size_t)i + 1] = (a.sy * py) / pz;
+    a.o_out[3 * (size_t)i + 2] = 1.0f + a.two_near / pz;
+    a.d_out[3 * (size_t)i + 0] = a.sx * (dx / dz - ox_oz);        // d0, d1, d2 (:194-196)
+    a.d_out[3 * (size_t)i + 1] = a.sy * (dy / dz - oy_oz);
+    a.d_out[3 * (size_t)i + 2] = a.minus_two_near / pz;
 }
 
 // ---- coarse depths + positions, one wavefront per ray ----
@@ -536,6 +565,21 @@ extern "C" int plnerf_select_rays(int H, int W, float fx, float fy, float cx, fl
     a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.near_out = near_out; a.far_out = far_out;
     a.target = target; a.pixels = pixels;
     hipLaunchKernelGGL(select_rays_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}
+
+extern "C" int plnerf_ndc_rays(int H, int W, double focal, double near, const float* rays_o, const float* rays_d, int n,
+                               float* o_out, float* d_out, plnerf_stream_t stream) {
+    if (H < 1 || W < 1 || n < 0 || !(focal != 0.0)) return PLNERF_EINVAL;
+    if (n == 0) return PLNERF_OK;
+    if (!rays_o || !rays_d || !o_out || !d_out) return PLNERF_EINVAL;
+    NdcArgs a{};
+    a.rays_o = rays_o; a.rays_d = rays_d; a.n = n; a.o_out = o_out; a.d_out = d_out;
+    a.sx = (float)(-1.0 / ((double)W / (2.0 * focal)));      // the reference's Python arithmetic: double, then one rounding
+    a.sy = (float)(-1.0 / ((double)H / (2.0 * focal)));
+    a.near = (float)near; a.two_near = (float)(2.0 * near); a.minus_two_near = (float)(-2.0 * near);
+    hipLaunchKernelGGL(ndc_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     PLNERF_CHECK_LAUNCH();
     return PLNERF_OK;
 }

@@ -1,7 +1,8 @@
 """Ray helpers with the reference's signatures (run_nerf_helpers.py:162-201).
 
 Row a12 of SURVEY.md section 8: negligible work (one pass over H*W pixels), kept as torch
-ops on whatever device `c2w` lives on; no HIP kernel is warranted.
+ops on whatever device `c2w` lives on -- except the NDC warp of rays already on the GPU, which is one launch
+(plnerf_ndc_rays) instead of the expression's twenty.
 """
 import math
 
@@ -33,13 +34,26 @@ def get_rays_np(H, W, K, c2w):
 
 def ndc_rays(H, W, focal, near, rays_o, rays_d):
     """Warp forward-facing rays to normalised device coordinates
-    (run_nerf_helpers.py:184-201): shift origins to the near plane, then project."""
+    (run_nerf_helpers.py:184-201): shift origins to the near plane, then project.
+    fp32 rays on the GPU that carry no gradient go through plnerf_ndc_rays -- one launch instead of ~20, the same bits;
+    anything else (host tensors: the loaders' rays; rays that need a gradient) is the expression itself."""
+    if (isinstance(rays_o, torch.Tensor) and rays_o.is_cuda and rays_o.dtype == torch.float32 and
+            isinstance(rays_d, torch.Tensor) and rays_d.is_cuda and rays_d.dtype == torch.float32 and
+            rays_o.shape == rays_d.shape and rays_o.shape[-1] == 3 and
+            not (torch.is_grad_enabled() and (rays_o.requires_grad or rays_d.requires_grad))):
+        from . import _lib as L
+        o_c, d_c = rays_o.detach().contiguous(), rays_d.detach().contiguous()
+        o_ndc, d_ndc = torch.empty_like(o_c), torch.empty_like(d_c)
+        L.check(L.lib().plnerf_ndc_rays(int(H), int(W), float(focal), float(near), L.dptr(o_c), L.dptr(d_c),
+                                        o_c.numel() // 3, L.dptr(o_ndc), L.dptr(d_ndc), L.stream()), "plnerf_ndc_rays")
+        return o_ndc, d_ndc
     t = -(near + rays_o[..., 2]) / rays_d[..., 2]
     o = rays_o + t[..., None] * rays_d
     sx = -1. / (W / (2. * focal))
     sy = -1. / (H / (2. * focal))
     ox_oz, oy_oz = o[..., 0] / o[..., 2], o[..., 1] / o[..., 2]
-    o_ndc = torch.stack([sx * ox_oz, sy * oy_oz, 1. + 2. * near / o[..., 2]], -1)
+    # (the reference writes "s * x / z": the product first, then the division -- one rounding apart from s * (x / z))
+    o_ndc = torch.stack([sx * o[..., 0] / o[..., 2], sy * o[..., 1] / o[..., 2], 1. + 2. * near / o[..., 2]], -1)
     d_ndc = torch.stack([sx * (rays_d[..., 0] / rays_d[..., 2] - ox_oz),
                          sy * (rays_d[..., 1] / rays_d[..., 2] - oy_oz),
                          -2. * near / o[..., 2]], -1)

@@ -21,6 +21,7 @@ from . import dp
 from . import functional as Fn
 from . import raybatch as RB
 from .optim import FlatAdam
+from .rays import ndc_rays
 from .render import render, render_rays
 
 
@@ -206,9 +207,13 @@ class TrainStep:
 
     def _render(self, H, W, K, rays, near, far, constant_init):
         chunk = getattr(self.args, "chunk", 1024 * 32)
-        direct = isinstance(rays, RB.RayColumns) and rays.shape[0] <= chunk and not self.kw.get("ndc", True) \
+        direct = isinstance(rays, RB.RayColumns) and rays.shape[0] <= chunk \
             and (rays.viewdirs is not None) == bool(self.kw.get("use_viewdirs", False))
         if direct:     # the columns go straight into render_rays: no packing, no slicing
+            if self.kw.get("ndc", True):      # forward-facing scenes: render's warp (run_plnerf.py:153-155) on the columns;
+                # the view directions stay those of the camera-space rays (:146-150), near / far the caller's (0, 1)
+                o_ndc, d_ndc = ndc_rays(H, W, K[0][0], 1., rays.rays_o, rays.rays_d)
+                rays = RB.RayColumns(o_ndc, d_ndc, rays.near, rays.far, rays.viewdirs)
             kw = {k: v for k, v in self.kw.items() if k not in ("ndc", "use_viewdirs")}
             ret = render_rays(rays, retraw=True, constant_init=constant_init, **kw)
             return ret['rgb_map'], ret

@@ -169,6 +169,29 @@ def test_select_view_rays(P):
     assert abs(float(many[:, 0].mean()) - 399.5) < 4.0 and abs(float(many[:, 1].mean()) - 399.5) < 4.0
 
 
+def test_ndc_rays_kernel_is_the_reference_expression(P):
+    """plnerf_ndc_rays (one launch) against the oracle's ndc_rays (run_nerf_helpers.py:184-201) on the host: the same
+    bits, for the LLFF geometry of BASELINE configs[3] and for a focal / near that are not fp32 numbers; rays that need
+    a gradient, or live on the host, take the expression."""
+    gen = torch.Generator().manual_seed(11)
+    for (H, W, focal, near, shape) in ((378, 504, 407.5658, 1.0, (4096,)), (60, 80, 1.0 / 3.0 + 50.0, 0.7, (13, 17))):
+        o = torch.randn(*shape, 3, generator=gen) * 0.3
+        d = torch.randn(*shape, 3, generator=gen) * 0.4
+        d[..., 2] = -(0.5 + torch.rand(*shape, generator=gen))
+        ref_o, ref_d = orc.ndc_rays(H, W, focal, near, o, d)
+        got_o, got_d = P.rays.ndc_rays(H, W, focal, near, g(o), g(d))
+        assert got_o.is_cuda and got_o.shape == o.shape
+        assert torch.equal(got_o.cpu(), ref_o) and torch.equal(got_d.cpu(), ref_d)
+        host_o, host_d = P.rays.ndc_rays(H, W, focal, near, o, d)                     # host tensors: the expression
+        assert torch.equal(host_o, ref_o) and torch.equal(host_d, ref_d)
+        og = g(o).requires_grad_(True)
+        with_grad, _ = P.rays.ndc_rays(H, W, focal, near, og, g(d))                   # a gradient is asked for: the expression
+        assert with_grad.requires_grad and maxdiff(with_grad, ref_o) <= 1e-6
+    from plnerf_amd import _lib as L
+    assert L.lib().plnerf_ndc_rays(0, 4, 1.0, 1.0, None, None, 4, None, None, None) == -1      # PLNERF_EINVAL
+    assert L.lib().plnerf_ndc_rays(4, 4, 1.0, 1.0, None, None, 0, None, None, None) == 0
+
+
 def test_image_loss_matches_torch(P):
     from plnerf_amd import functional as Fn
     gen = torch.Generator().manual_seed(2)
@@ -252,23 +275,32 @@ def test_render_is_invariant_to_sharding_of_the_batch(P):
     assert maxdiff(whole_n["rgb0"], whole["rgb0"]) > 1e-4
 
 
-def test_train_step_from_a_view(P):
+@pytest.mark.parametrize("dataset", ["blender", "llff"])
+def test_train_step_from_a_view(P, dataset):
     """TrainStep.step_view (device-side pixel choice -> columns -> render_rays -> fused loss -> backward -> Adam) equals
-    TrainStep.__call__ on the same rays and targets, and optimises."""
+    TrainStep.__call__ on the same rays and targets, and optimises.  "llff": a forward-facing view in normalised device
+    coordinates (create_nerf leaves ndc on, run_plnerf.py:490-493; near 0, far 1, :1008-1009) -- step_view warps the
+    selected columns itself, __call__ goes through render's own warp."""
     H = W = 100
     K = [[140.0, 0, W / 2], [0, 140.0, H / 2], [0, 0, 1]]
-    c2w = P.rays.pose_spherical(30.0, -30.0, 4.0)[:3, :4]
+    if dataset == "llff":
+        c2w = torch.tensor([[1.0, 0.0, 0.0, 0.1], [0.0, 1.0, 0.0, -0.05], [0.0, 0.0, 1.0, 0.2]])
+        near, far = 0.0, 1.0
+    else:
+        c2w = P.rays.pose_spherical(30.0, -30.0, 4.0)[:3, :4]
+        near, far = 2.0, 6.0
     yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
     image = g(torch.stack([xx, yy, 0.5 * (xx + yy)], -1))
-    args, kw, opt, opt_c = _nets(P)
+    args, kw, opt, opt_c = _nets(P, dataset=dataset)
+    assert bool(kw.get("ndc", True)) == (dataset == "llff")
     ts = P.TrainStep(args, kw, opt, opt_c, distributed=False, seed=5)
-    args2, kw2, opt2, opt_c2 = _nets(P)
+    args2, kw2, opt2, opt_c2 = _nets(P, dataset=dataset)
     ts2 = P.TrainStep(args2, kw2, opt2, opt_c2, distributed=False, seed=5)
     losses = []
     for step in range(6):
-        cols, target, _ = P.select_view_rays(H, W, K, c2w, image, 256, 2.0, 6.0, seed=5, step=step)
-        loss2, psnr2 = ts2(H, W, K, (cols.rays_o, cols.rays_d), target, near=2.0, far=6.0)
-        loss, psnr = ts.step_view(H, W, K, c2w, image, near=2.0, far=6.0, n_rand=256)
+        cols, target, _ = P.select_view_rays(H, W, K, c2w, image, 256, near, far, seed=5, step=step)
+        loss2, psnr2 = ts2(H, W, K, (cols.rays_o, cols.rays_d), target, near=near, far=far)
+        loss, psnr = ts.step_view(H, W, K, c2w, image, near=near, far=far, n_rand=256)
         losses.append(float(loss))
         assert abs(float(loss) - float(loss2)) <= 2e-6 * max(1.0, float(loss2)), (step, float(loss), float(loss2))
     assert np.isfinite(losses).all() and losses[-1] < losses[0]

@@ -88,13 +88,13 @@ def test_ctypes_signatures_match_the_header(built):
         if t.endswith("*") or t == "plnerf_stream_t":
             return "ptr"
         return {"int": "i32", "float": "f32", "uint64_t": "u64", "uint32_t": "u32", "int64_t": "i64", "size_t": "u64",
-                "unsigned": "u32"}[t]      # (size_t and uint64_t are one ctypes object on LP64)
+                "unsigned": "u32", "double": "f64"}[t]      # (size_t and uint64_t are one ctypes object on LP64)
 
     def ct_class(t):
         if t is ctypes.c_char_p or t is ctypes.c_void_p or (isinstance(t, type) and issubclass(t, ctypes._Pointer)):
             return "ptr"
         return {ctypes.c_int: "i32", ctypes.c_float: "f32", ctypes.c_uint64: "u64", ctypes.c_uint32: "u32",
-                ctypes.c_int64: "i64", ctypes.c_size_t: "u64"}[t]
+                ctypes.c_int64: "i64", ctypes.c_size_t: "u64", ctypes.c_double: "f64"}[t]
     protos = _header_prototypes()
     assert set(protos) == set(_lib.SIGNATURES)
     for name, (ret, params) in protos.items():
