@@ -115,17 +115,29 @@ class NeRF(nn.Module):
 
     # -- HIP plumbing ---------------------------------------------------------------
     def _skip_layout(self):
-        """How the reference module's skip list lands on the compiled trunk: "at4" -- the skip after layer 4 is live
-        (needs a sixth layer to consume it: D 6..8); "none" -- no entry of `skips` takes effect (run_nerf_helpers.py:
-        88-89, 109-112: entry k concatenates after layer k and widens layer k + 1, so k >= D does nothing); None --
-        anything else (another skip position; a skip after the LAST layer, which the reference's own head layers
-        cannot consume either)."""
+        """How the reference module's skip list lands on the compiled trunk (five layers, the concatenation, three
+        layers): ("at", k) -- ONE live skip, after layer k <= 4, with one to three layers behind it to consume it
+        (netdepth k + 2 .. k + 4; the shipped configurations are ("at", 4) with netdepth 8): layers 0..k sit in the
+        compiled slots 0..k, identities fill up to slot 4, layer k + 1 is the compiled skip layer; "none" -- no entry of
+        `skips` takes effect (run_nerf_helpers.py:88-89, 109-112: entry k concatenates after layer k and widens layer
+        k + 1, so k >= D does nothing); None -- anything else (two live skips; more than five layers before or three
+        behind the concatenation; a skip after the LAST layer, which the reference's own head layers cannot consume
+        either)."""
         live = sorted(set(k for k in self.skips if 0 <= k < self.D))
-        if live == SUPPORTED["skips"] and SUPPORTED["D"] - 2 <= self.D <= SUPPORTED["D"]:
-            return "at4"
+        if len(live) == 1 and live[0] <= SUPPORTED["skips"][0] and 1 <= self.D - live[0] - 1 <= SUPPORTED["D"] - 5:
+            return ("at", live[0])
         if not live and 1 <= self.D <= SUPPORTED["D"]:
             return "none"
         return None
+
+    def _slots(self):
+        """slot_layer[i]: the module's trunk layer that sits in the compiled network's layer i, or None (an identity)."""
+        layout = self._skip_layout()
+        if layout == "none":
+            return [i if i < self.D else None for i in range(SUPPORTED["D"])]
+        k = layout[1]
+        behind = list(range(k + 1, self.D))
+        return list(range(k + 1)) + [None] * (SUPPORTED["skips"][0] - k) + behind + [None] * (SUPPORTED["D"] - 5 - len(behind))
 
     def is_supported(self):
         # (narrower and shallower trunks, and trunks without a live skip, are padded into the compiled one: param_list)
@@ -152,8 +164,8 @@ class NeRF(nn.Module):
             raise NotImplementedError(
                 "plnerf_amd's HIP MLP is compiled for the reference's trunk "
                 f"(D={SUPPORTED['D']}, W={SUPPORTED['W']}, skips={SUPPORTED['skips']}) and runs what can be expressed exactly "
-                f"in it: netdepth {SUPPORTED['D'] - 2}..{SUPPORTED['D']} with skips=[4], netdepth 1..{SUPPORTED['D']} without a live "
-                f"skip, even netwidth 8..{SUPPORTED['W']}, input_ch <= "
+                f"in it: one live skip after layer k <= {SUPPORTED['skips'][0]} with netdepth k + 2 .. k + 4, netdepth "
+                f"1..{SUPPORTED['D']} without a live skip, even netwidth 8..{SUPPORTED['W']}, input_ch <= "
                 f"{MAX_INPUT_CH}, input_ch_views + input_ch_cam <= {MAX_VIEW_CH}, with or without view directions; got "
                 f"D={self.D}, W={self.W}, "
                 f"input_ch={self.input_ch}, input_ch_views={self.input_ch_views}, input_ch_cam={self.input_ch_cam}, "
@@ -181,6 +193,9 @@ class NeRF(nn.Module):
 
           * netwidth < 256: weights and biases zero-padded (the extra units compute relu(0) = 0 and feed nothing);
           * netdepth 6 or 7: the missing trunk layers as identities (their inputs are post-ReLU, so relu(I h) = h);
+          * one live skip after another layer k <= 4 with one to three layers behind it (skips=[2] with netdepth 4..6,
+            say): layers 0..k in the compiled slots 0..k, identities up to slot 4, layer k + 1 as the compiled skip layer
+            (_skip_layout, _slots);
           * no live skip (skips=[], or every entry >= netdepth, e.g. netdepth 4 with the default skips=[4]), netdepth
             1..8: the compiled skip layer's encoding columns are zero -- [0 | W_5], or [0 | I] when layer 5 itself is
             one of the identities;
@@ -188,7 +203,7 @@ class NeRF(nn.Module):
             0..2 = W_out[rgb], rows 3..5 = -W_out[rgb]; the view layer copies those six features (identity weights, zero
             direction columns); rgb = relu(F) - relu(-F) + b = F + b; sigma = the alpha row = W_out[3]."""
         layout = self._skip_layout()
-        if self.use_viewdirs and self.D == SUPPORTED["D"] and self.W == SUPPORTED["W"] and layout == "at4":
+        if self.use_viewdirs and self.D == SUPPORTED["D"] and self.W == SUPPORTED["W"] and layout == ("at", SUPPORTED["skips"][0]):
             # (the Parameter objects never change -- .to(), load_state_dict and optim.FlatAdam all work on their .data --
             # so the walk over the module tree, 24 generators deep, is done once: it was 100 us of every training step)
             plist = self.__dict__.get("_plist")
@@ -202,21 +217,22 @@ class NeRF(nn.Module):
         pad_rows = lambda t, n: F.pad(t, (0, 0, 0, n - t.shape[0])) if t.dim() == 2 else F.pad(t, (0, n - t.shape[0]))
         pad_cols = lambda t, n: F.pad(t, (0, n - t.shape[1]))
         out = []
-        for i in range(SUPPORTED["D"]):
-            if i < D:
-                w, b = self.pts_linears[i].weight, self.pts_linears[i].bias
+        skip_slot = SUPPORTED["skips"][0] + 1
+        for i, j in enumerate(self._slots()):
+            if j is not None:
+                w, b = self.pts_linears[j].weight, self.pts_linears[j].bias
                 if i == 0:
                     w = pad_rows(w, KW)
-                elif i == SUPPORTED["skips"][0] + 1 and layout == "at4":      # [encoding | hidden] columns
+                elif i == skip_slot and layout != "none":      # the layer behind the live skip: [encoding | hidden] columns
                     w = pad_rows(torch.cat([w[:, :cin], pad_cols(w[:, cin:], KW)], 1), KW)
-                elif i == SUPPORTED["skips"][0] + 1:      # no live skip: the compiled layer's encoding columns are zero
+                elif i == skip_slot:      # no live skip: the compiled layer's encoding columns are zero
                     w = pad_rows(torch.cat([z(w.shape[0], cin), pad_cols(w, KW)], 1), KW)
                 else:
                     w = pad_rows(pad_cols(w, KW), KW)
                 out += [w, pad_rows(b, KW)]
             else:
                 eye = torch.eye(KW, device=ref.device, dtype=ref.dtype)
-                out += [torch.cat([z(KW, cin), eye], 1) if i == SUPPORTED["skips"][0] + 1 else eye, z(KW)]
+                out += [torch.cat([z(KW, cin), eye], 1) if i == skip_slot else eye, z(KW)]
         HV, vch = KW // 2, self.hip_view_ch
         if self.use_viewdirs:
             vw = self.views_linears[0].weight                                  # [W/2, W + view_ch]: [feature | direction]

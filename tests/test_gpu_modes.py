@@ -547,15 +547,16 @@ def test_network_without_view_directions(P, precision, tmp_path):
 
 
 @pytest.mark.parametrize("shape", [(8, 128, True), (6, 256, True), (7, 64, False), (6, 32, True), (4, 128, True),
-                                   (2, 256, False)])
+                                   (2, 256, False), (6, 256, True, 2), (5, 96, True, 1), (4, 128, False, 0)])
 def test_narrower_and_shallower_networks(P, shape):
-    """netwidth < 256 and netdepth 6 / 7 are zero-padded / identity-extended into the compiled 8 x 256 network
-    (NeRF.param_list) -- exactly: fp32 mode against the same network in fp64 torch, forward and every real parameter's
-    gradient, fused entry and embedded entry."""
-    D, Wd, use_viewdirs = shape
+    """netwidth < 256, netdepth 6 / 7 and a skip after another layer (with one to three layers behind it) are zero-padded
+    / identity-extended into the compiled 8 x 256 network (NeRF.param_list) -- exactly: fp32 mode against the same
+    network in fp64 torch, forward and every real parameter's gradient, fused entry and embedded entry."""
+    D, Wd, use_viewdirs = shape[:3]
+    skip = shape[3] if len(shape) > 3 else 4
     F = torch.nn.functional
     torch.manual_seed(41)
-    net = P.NeRF(D=D, W=Wd, input_ch=63, input_ch_views=27 if use_viewdirs else 0, output_ch=5, skips=[4],
+    net = P.NeRF(D=D, W=Wd, input_ch=63, input_ch_views=27 if use_viewdirs else 0, output_ch=5, skips=[skip],
                  use_viewdirs=use_viewdirs, precision="fp32").to(dev())
     sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in net.state_dict().items()}
     gen = torch.Generator().manual_seed(43)
@@ -569,7 +570,7 @@ def test_narrower_and_shallower_networks(P, shape):
     h = x
     for i in range(D):
         h = F.relu(F.linear(h, sd[f"pts_linears.{i}.weight"], sd[f"pts_linears.{i}.bias"]))
-        if i == 4:      # (netdepth <= 4: the default skips=[4] never takes effect, run_nerf_helpers.py:109-112)
+        if i == skip:      # (netdepth <= 4: the default skips=[4] never takes effect, run_nerf_helpers.py:109-112)
             h = torch.cat([x, h], -1)
     if use_viewdirs:
         sigma = F.linear(h, sd["alpha_linear.weight"], sd["alpha_linear.bias"])
@@ -596,6 +597,8 @@ def test_narrower_and_shallower_networks(P, shape):
         worst = max(worst, float((got - r).abs().max()) / max(float(r.abs().max()), 1e-6))
     print(f"D={D} W={Wd} viewdirs={use_viewdirs}: forward {err:.2e} (embedded entry {err_e:.2e}), worst gradient error / max|g| {worst:.2e}")
     assert err <= 1e-5 and err_e <= 1e-5 and worst <= 2e-4
+    if len(shape) > 3:      # (create_nerf always builds skips=[4], run_plnerf.py:425-437: the route below has no other skip)
+        return
     # the reference's route with these arguments: create_nerf, render, backward, both Adams (f16x3, the default mode)
     args = _args(_ckdir(), "f16x3", netdepth=D, netwidth=Wd, netdepth_fine=D, netwidth_fine=Wd, use_viewdirs=use_viewdirs)
     kw, _, _, grad_vars, opt, opt_c = P.create_nerf(args, device=dev())

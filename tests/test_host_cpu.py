@@ -176,9 +176,11 @@ def test_network_without_view_directions_maps_onto_the_kernels_head(built):
 
 @pytest.mark.parametrize("shape", [(8, 128, True, [4]), (6, 256, True, [4]), (7, 64, False, [4]), (6, 32, True, [4]),
                                    (8, 256, True, []), (4, 256, True, [4]), (3, 64, False, []), (1, 128, True, [4]),
-                                   (5, 96, True, [7])])
+                                   (5, 96, True, [7]), (6, 256, True, [2]), (5, 128, True, [1]), (7, 64, True, [3]),
+                                   (4, 96, False, [0]), (6, 160, True, [2, 9]), (3, 256, True, [1])])
 def test_other_network_shapes_map_exactly_onto_the_compiled_network(built, shape):
-    """NeRF.param_list() for netwidth < 256 / netdepth 6, 7 / no view directions / no live skip with netdepth 1..8: the
+    """NeRF.param_list() for netwidth < 256 / netdepth 6, 7 / no view directions / no live skip with netdepth 1..8 / one
+    live skip after a layer k <= 4 with one to three layers behind it: the
     24 tensors of the compiled 8 x 256 network, evaluated here in plain fp64 torch, reproduce the real module's
     function exactly (the module's own forward, run_nerf_helpers.py:105-128, restated)."""
     import torch
@@ -196,6 +198,7 @@ def test_other_network_shapes_map_exactly_onto_the_compiled_network(built, shape
         h = F.relu(F.linear(h, sd[f"pts_linears.{i}.weight"], sd[f"pts_linears.{i}.bias"]))
         if i in skips:
             h = torch.cat([x, h], -1)
+    assert h.shape[-1] == Wd      # (the shapes here leave the head a plain W-wide input, as the reference's head needs)
     if use_viewdirs:
         sigma = F.linear(h, sd["alpha_linear.weight"], sd["alpha_linear.bias"])
         feat = F.linear(h, sd["feature_linear.weight"], sd["feature_linear.bias"])
@@ -219,11 +222,11 @@ def test_other_network_shapes_map_exactly_onto_the_compiled_network(built, shape
 
 def test_unsupported_network_shapes_are_refused(built):
     """What the compiled trunk cannot express is constructible (same state_dict as the reference) and refuses to run:
-    another skip position, a skip after the last layer (the reference's own head cannot consume that one either),
-    more than 8 layers, more than 256 units."""
+    more than three layers behind a skip or more than five before it, two live skips, a skip after the last layer (the
+    reference's own head cannot consume that one either), more than 8 layers, more than 256 units."""
     import plnerf_amd as P
     for kw in (dict(D=8, skips=[2]), dict(D=5, skips=[4]), dict(D=9, skips=[4]), dict(D=8, W=512, skips=[4]),
-               dict(D=8, skips=[4, 6])):
+               dict(D=8, skips=[4, 6]), dict(D=8, skips=[5]), dict(D=6, skips=[1, 3])):
         net = P.NeRF(input_ch=63, input_ch_views=27, output_ch=5, use_viewdirs=True, **kw)
         assert not net.is_supported(), kw
         with pytest.raises(NotImplementedError):
