@@ -538,6 +538,20 @@ def main(argv=None):
             del st, nets_w, sc, tm
             torch.cuda.empty_cache()
         extra["workloads"] = wl
+        # -- the same workload on the two-stream schedule (train.TrainStep pipeline=2: bit-identical steps, the coarse
+        #    chain beside the fine one and across step boundaries); the headline stays the one-stream schedule, whose
+        #    kernels run alone and can be priced against their rooflines
+        if a.pipeline == 0:
+            b = copy.copy(a)
+            b.pipeline = 2
+            st, nets_w = build_step(P, b, a.precision, scene, dev, rank, world, False)
+            dt2, loss2, _, ps2 = timed(st, 5, 20)
+            extra["two_stream_schedule"] = {"pipeline": 2, "ms_per_step": 1e3 * dt2 / 20, "rays_per_s": R * 20 / dt2,
+                                            "steps": 20, "warmup": 5, "step_ms": stats_ms(ps2), "final_loss": loss2,
+                                            "what": "the default workload with the coarse network's chain on a second HIP "
+                                                    "stream, also across steps; same arithmetic, same results"}
+            del st, nets_w
+            torch.cuda.empty_cache()
         # -- north_star's MLP benchmark, every precision
         extra["mlp_only_65536x192"] = leg_mlp_only(P, dev)
         # -- one full frame through render(c2w=...)
