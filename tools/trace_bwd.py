@@ -23,6 +23,9 @@ buf = np.zeros(64, dtype=np.uint64)
 assert lib.plnerf_debug_trace_f16(buf.ctypes.data) == 0
 t = buf.astype(np.int64)
 print(f"dgrad: total {t[42]-t[0]} clk;  views+feature+L7 part {t[1]-t[0]}")
+if t[43] and not os.environ.get("PLNERF_TRACE_PIPE"):
+    print(f"  head: mask requests + g_raw load + barrier {t[43]-t[0]}  dz_view + barrier {t[44]-t[43]}  mask commit + K(view, 8 steps) {t[45]-t[44]}  "
+          f"barrier + epilogue + barrier {t[46]-t[45]}  K(feature) {t[47]-t[46]}  barrier + epilogue(alpha) + barrier {t[1]-t[47]}")
 names = ("K(B) + epilogue(A)", "barrier", "K(A, next) + epilogue(B)", "barrier") if os.environ.get("PLNERF_TRACE_PIPE") else \
         ("K loop", "barrier", "store_dz", "barrier")
 for k in range(7):
