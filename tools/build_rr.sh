@@ -10,5 +10,5 @@ if [ -z "$name" ]; then
 else
   mkdir -p /tmp/rr/v $R/tools/_head
   cd $C && /opt/rocm/bin/hipcc $FLAGS "$@" -DRR_SINGLE_TU -c mlp_rr.hip -o /tmp/rr/v/mlp_rr_$name.o 2>&1 | grep -E "error" 
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/_head/librr_$name.so capi.o quad.o sampler.o epilogue.o step.o mlp_api.o mlp_f32.o mlp_bf16.o mlp_rr_kb_1_infer.o mlp_rr_kb_2_infer.o mlp_rr_kb_2_train.o mlp_rr_kb_2_infer_emb.o mlp_rr_kb_2_train_emb.o mlp_rr_kb_pack.o /tmp/rr/v/mlp_rr_$name.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/_head/librr_$name.so $(ls *.o | grep -v "^mlp_rr\.o$\|^mlp_rr_k_") /tmp/rr/v/mlp_rr_$name.o
 fi

@@ -8,10 +8,11 @@ from plnerf_amd import _lib
 dev = torch.device("cuda:0")
 for prec in sys.argv[1:] or ["f16x3", "f16"]:
     net = P.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True, precision=prec).to(dev)
-    R, S = 65536, 192
+    train = bool(os.environ.get("TRAIN"))      # TRAIN=1: the training forward (saves the backward's state), 4096 x 192 rows
+    R, S = (4096 if train else 65536), 192
     pts = (torch.rand(R, S, 3, device=dev) * 2 - 1) * 3
     vd = torch.nn.functional.normalize(torch.randn(R, 3, device=dev), dim=-1)
-    with torch.no_grad():
+    with torch.set_grad_enabled(train):
         for _ in range(3):
             net.query(pts, vd)
     torch.cuda.synchronize()
