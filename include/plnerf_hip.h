@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PLNERF_VERSION 401 /* major*10000 + minor*100 + patch */
+#define PLNERF_VERSION 402 /* major*10000 + minor*100 + patch */
 
 /* error codes */
 #define PLNERF_OK 0
@@ -376,6 +376,15 @@ int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, int in
                    int input_ch_views, int n_rows, const void* saved, int saved_layout,
                    const float* raw_out, float density_beta, void* workspace,
                    float* const* grads, float* status_out, plnerf_stream_t stream);
+
+/* Gradient of the same backward with respect to the network's INPUT rows (what autograd gives the reference when the
+ * rows handed to NeRF.forward, run_nerf_helpers.py:105-128, require a gradient -- no reference training path does,
+ * run_plnerf.py:728 detaches the samples): g_embedded [n_rows, input_ch + input_ch_views], the position channels
+ * through layer 0 and the skip layer, the direction channels through the view layer.  Call it after plnerf_mlp_bwd,
+ * on the same stream, with that call's workspace (it reads the pre-activation gradients left there) and the 24
+ * parameter tensors (device pointers, host table, as plnerf_mlp_pack_weights takes them). */
+int plnerf_mlp_input_grad(const float* const* params, int precision, int input_ch, int input_ch_views, int n_rows,
+                          const void* workspace, float* g_embedded, plnerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused Adam step over a flat parameter buffer (torch.optim.Adam semantics as used at

@@ -62,6 +62,7 @@ SIGNATURES = {
                                 c_f, c_s]),
     "plnerf_mlp_packed_bytes": (ctypes.c_size_t, [c_i]),
     "plnerf_mlp_pack_weights": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_i, c_i, c_i, c_f, c_s]),
+    "plnerf_mlp_input_grad": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_i, c_i, c_i, c_i, c_f, c_f, c_s]),
     "plnerf_mlp_saved_bytes": (ctypes.c_size_t, [c_i, c_i]),
     "plnerf_mlp_bwd_workspace_bytes": (ctypes.c_size_t, [c_i, c_i]),
     "plnerf_mlp_fwd": (c_i, [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_float, ctypes.c_float, c_f, c_f, c_i, c_s]),

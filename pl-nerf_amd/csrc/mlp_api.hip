@@ -176,3 +176,16 @@ extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_
     return impl::wgrad(g_raw, n_rows, saved, ws, gmax, partials, grads, input_ch, input_ch_views, true, saved_layout,
                        status_word(const_cast<void*>(packed), precision), status_out, st);
 }
+
+extern "C" int plnerf_mlp_input_grad(const float* const* params, int precision, int input_ch, int input_ch_views,
+                                     int n_rows, const void* workspace, float* g_embedded, plnerf_stream_t stream) {
+    if (!known(precision)) return PLNERF_ENOSYS;
+    if (!params || !workspace || !g_embedded || n_rows < 1 || !geometry_ok(input_ch, input_ch_views)) return PLNERF_EINVAL;
+    for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i)
+        if (!params[i]) return PLNERF_EINVAL;
+    if (precision == PLNERF_PREC_FP32)
+        return impl::input_grad(params, n_rows, workspace, nullptr, false, input_ch, input_ch_views, g_embedded, (hipStream_t)stream);
+    const unsigned char* ws = (const unsigned char*)workspace;      // [dz half planes][max |g_raw|] ... as plnerf_mlp_bwd laid them out
+    return impl::input_grad(params, n_rows, ws, (const unsigned*)(ws + impl::h16_dz_bytes(n_rows)), true, input_ch,
+                            input_ch_views, g_embedded, (hipStream_t)stream);
+}

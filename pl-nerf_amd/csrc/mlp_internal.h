@@ -28,6 +28,9 @@ int f32_dgrad(const void* packed, const float* g_raw, int n_rows, const float* s
 int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dz, const unsigned* gmax, float* partials,
           float* const* grads, int xyz_ch, int dir_ch, bool h16, int saved_layout, const unsigned* status,
           float* status_out, hipStream_t st);
+// gradient with respect to the embedded input rows, from the dz planes a finished plnerf_mlp_bwd left in its workspace
+int input_grad(const float* const* params, int n_rows, const void* dz, const unsigned* gmax, bool h16, int xyz_ch,
+               int dir_ch, float* g_emb, hipStream_t st);
 // g_eff [n_rows, 4] = g_raw with the sigma column times the density activation's derivative (from raw_out, the forward's
 // activated output); out (nullable): max |g_eff| as fp32 bits, like absmax
 int absmax_act(const float* g_raw, const float* raw_out, float beta, int n_rows, float* g_eff, unsigned* out, hipStream_t st);

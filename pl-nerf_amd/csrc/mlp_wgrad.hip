@@ -510,6 +510,120 @@ __global__ __launch_bounds__(256) void wgrad_head_kernel(HeadArgs<PT> a) {
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Gradient with respect to the network's (embedded) input rows -- off the training path (the reference's sample
+// positions carry no gradient, run_plnerf.py:728), kept simple: the three places an input enters,
+//   g_x[row, c]   = sum_k dz_0[row, k] W_0[k, c] + dz_5[row, k] W_5[k, c]        (c < xyz_ch: layer 0 and the skip layer)
+//   g_dir[row, c] = sum_k dz_view[row, k] W_view[k, 256 + c]                     (c < dir_ch: the view layer)
+// on the vector ALU from the dz planes the dgrad kernel of the mode left in the workspace (fp32 row-major, or IEEE half
+// in the tiled order of mlp_layout.h under the launch scale, which is divided back out here).  One workgroup per CU
+// walks 32-row tiles with the three weight blocks (fp32, [k][channel]) in LDS; thread = (row of the tile, channel
+// octet).
+// ------------------------------------------------------------------------------------
+struct InGradArgs {
+    const float* w0;        // [256][xyz_ch]              pts_linears.0.weight
+    const float* w5;        // [256][xyz_ch + 256]        pts_linears.5.weight (its first xyz_ch columns)
+    const float* wv;        // [128][256 + dir_ch]        views_linears.0.weight (its last dir_ch columns)
+    const void* dz0;
+    const void* dz5;
+    const void* dzv;
+    const unsigned* gmax;   // half planes: the launch scale's maximum (nullptr: fp32 planes)
+    int xyz_ch, dir_ch, n_rows;
+    float* g_emb;           // [n_rows][xyz_ch + dir_ch]
+};
+
+template <bool H16>
+__global__ __launch_bounds__(256) void input_grad_kernel(InGradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float ig_smem[];
+    float* W0t = ig_smem;                 // [256][64]
+    float* W5t = W0t + W * PE_K;          // [256][64]
+    float* Wvt = W5t + W * PE_K;          // [128][32]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < W * PE_K; i += 256) {
+        const int k = i >> 6, c = i & 63;
+        W0t[i] = c < a.xyz_ch ? a.w0[(size_t)k * a.xyz_ch + c] : 0.0f;
+        W5t[i] = c < a.xyz_ch ? a.w5[(size_t)k * (a.xyz_ch + W) + c] : 0.0f;
+    }
+    for (int i = tid; i < HV * DPE_K; i += 256) {
+        const int k = i >> 5, c = i & 31;
+        Wvt[i] = c < a.dir_ch ? a.wv[(size_t)k * (W + a.dir_ch) + W + c] : 0.0f;
+    }
+    __syncthreads();
+    float unscale = 1.0f;
+    if (H16 && a.gmax) {
+        const float gm = __uint_as_float(*a.gmax);
+        if (gm > 0.0f && gm < __builtin_inff()) {
+            int e;
+            (void)frexpf(gm, &e);
+            unscale = ldexpf(1.0f, e - (int)DZH_TARGET_EXP);
+        }
+    }
+    const int r = tid & 31, cg = tid >> 5;
+    const int n_tiles = (a.n_rows + 31) / 32;
+    const int out_ch = a.xyz_ch + a.dir_ch;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int row = tile * 32 + r;
+        float ax[8], ad[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ax[j] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ad[j] = 0.0f;
+        if (row < a.n_rows) {
+            for (int pb = 0; pb < 32; ++pb) {
+                float v0[8], v5[8];
+                int f[8];
+                if (H16) {
+                    const size_t off = (((size_t)tile * 32 + pb) * 32 + r) * 8;      // the tiled order: piece block pb of the tile
+                    const wh8 p0 = *reinterpret_cast<const wh8*>((const _Float16*)a.dz0 + off);
+                    const wh8 p5 = *reinterpret_cast<const wh8*>((const _Float16*)a.dz5 + off);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        v0[e] = (float)p0[e]; v5[e] = (float)p5[e];
+                        f[e] = 32 * (pb >> 2) + 16 * ((pb >> 1) & 1) + 4 * (pb & 1) + (e & 3) + 8 * (e >> 2);
+                    }
+                } else {
+                    const float* q0 = (const float*)a.dz0 + (size_t)row * W + 8 * pb;
+                    const float* q5 = (const float*)a.dz5 + (size_t)row * W + 8 * pb;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { v0[e] = q0[e]; v5[e] = q5[e]; f[e] = 8 * pb + e; }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float* w0r = W0t + f[e] * PE_K + cg * 8;
+                    const float* w5r = W5t + f[e] * PE_K + cg * 8;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ax[j] = fmaf(v5[e], w5r[j], fmaf(v0[e], w0r[j], ax[j]));
+                }
+            }
+            for (int c8 = 0; c8 < HV / 8; ++c8) {      // dz_view: row-major in every mode
+                float vv[8];
+                if (H16) {
+                    const wh8 pv = *reinterpret_cast<const wh8*>((const _Float16*)a.dzv + (size_t)row * HV + 8 * c8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vv[e] = (float)pv[e];
+                } else {
+                    const float* qv = (const float*)a.dzv + (size_t)row * HV + 8 * c8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vv[e] = qv[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float* wr = Wvt + (8 * c8 + e) * DPE_K + cg * 4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ad[j] = fmaf(vv[e], wr[j], ad[j]);
+                }
+            }
+            float* dst = a.g_emb + (size_t)row * out_ch;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (cg * 8 + j < a.xyz_ch) dst[cg * 8 + j] = ax[j] * unscale;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (cg * 4 + j < a.dir_ch) dst[a.xyz_ch + cg * 4 + j] = ad[j] * unscale;
+        }
+    }
+}
+
 constexpr int WG_SPLITS = PLNERF_WG_SPLITS;
 constexpr int HEAD_OUT = 644;   // dW_alpha 256, dW_rgb 384, b_alpha 1, b_rgb 3
 struct ReduceArgs {
@@ -815,6 +929,31 @@ int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, co
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a);
         PLNERF_CHECK_LAUNCH();
     }
+    return PLNERF_OK;
+}
+
+int input_grad(const float* const* params, int n_rows, const void* dzv, const unsigned* gmax, bool h16, int xyz_ch,
+               int dir_ch, float* g_emb, hipStream_t st) {
+    const size_t N = (size_t)n_rows;
+    const size_t es = h16 ? sizeof(_Float16) : sizeof(float);
+    const size_t ND = h16 ? dz_rows(N) : N;
+    const unsigned char* dz = (const unsigned char*)dzv;
+    InGradArgs a{};
+    a.w0 = params[0]; a.w5 = params[10]; a.wv = params[P_WV];
+    a.dz0 = dz; a.dz5 = dz + (size_t)5 * W * ND * es; a.dzv = dz + (size_t)DZ_V_OFF * ND * es;
+    a.gmax = h16 ? gmax : nullptr;
+    a.xyz_ch = xyz_ch; a.dir_ch = dir_ch; a.n_rows = n_rows; a.g_emb = g_emb;
+    const size_t lds = ((size_t)2 * W * PE_K + (size_t)HV * DPE_K) * sizeof(float);
+    const int n_tiles = (n_rows + 31) / 32;
+    const int grid = n_tiles < 256 ? n_tiles : 256;
+    if (h16) {
+        (void)hipFuncSetAttribute((const void*)input_grad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(input_grad_kernel<true>, dim3(grid), dim3(256), lds, st, a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)input_grad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(input_grad_kernel<false>, dim3(grid), dim3(256), lds, st, a);
+    }
+    PLNERF_CHECK_LAUNCH();
     return PLNERF_OK;
 }
 

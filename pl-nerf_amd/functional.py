@@ -439,8 +439,9 @@ def coarse_samples(rays_o, rays_d, near, far, t_vals, t_rand, lindisp, perturb, 
 
 class MlpFn(torch.autograd.Function):
     """Embedder + NeRF.forward (run_nerf_helpers.py:24-54, 105-128) -> plnerf_mlp_fwd /
-    plnerf_mlp_bwd.  Gradients flow to the 24 parameter tensors (the sample positions do not depend on parameters on
-    this path) and to `cam`: the depth-supervised script's per-image camera code, a vector the caller has repeated into
+    plnerf_mlp_bwd (+ plnerf_mlp_input_grad).  Gradients flow to the 24 parameter tensors, to the inputs when they ask
+    for one (pts / viewdirs through the in-kernel encoding's derivative, or the embedded rows; no reference training path
+    does: the sample positions are detached there) and to `cam`: the depth-supervised script's per-image camera code, a vector the caller has repeated into
     the LAST cam.numel() columns of every row of `embedded` (run_nerf_sample_based_depth.py:60-64, trained through the
     network input at :1091-1093, 1122-1123 and optimised alone at :311-345).  Because every row carries the same
     values, its gradient is the view layer's weight columns applied to the row-sum of dz_view -- which is the view
@@ -453,14 +454,10 @@ class MlpFn(torch.autograd.Function):
         # derivative on the backward's entry, from the activated output saved below
         beta = float(getattr(net, "density_beta", 0.0))
         prec = L.PRECISION[net.precision]
-        # The kernels produce parameter gradients only (the sample positions carry no gradient
-        # on the reference's path).  A gradient requested for an MLP *input* would be dropped silently by returning
-        # None from backward -- refuse instead.
-        if bool(want_grad) and any(ctx.needs_input_grad[0:3]):
-            raise NotImplementedError(
-                "plnerf_amd: the fused MLP has no input gradient (pts / viewdirs / embedded require grad); the HIP "
-                "path differentiates with respect to the network parameters only -- detach the inputs "
-                "(a trainable camera code goes in as `cam`: NeRF.forward(embedded, cam=...))")
+        # A gradient for an MLP *input* (pts / viewdirs, or the embedded rows) is off every reference training path (the
+        # samples are detached, run_plnerf.py:728) but is what autograd gives the reference module: plnerf_mlp_input_grad
+        # after the backward's dgrad, then the encoding's own derivative (backward below).
+        in_grad = bool(want_grad) and any(ctx.needs_input_grad[0:3])
         _expect(cam is None or (embedded is not None and cam.dim() == 1 and 0 < cam.numel() <= embedded.shape[-1]),
                 "cam must be a vector held in the last columns of `embedded`")
         packed = net.packed_weights()
@@ -474,7 +471,7 @@ class MlpFn(torch.autograd.Function):
             emb_c = None
         raw = torch.empty(n_rows, 4, device=dev)
         # grad mode is always off inside Function.forward: the caller samples torch.is_grad_enabled()
-        need_grad = bool(want_grad) and any(ctx.needs_input_grad[3:4] + ctx.needs_input_grad[7:])
+        need_grad = in_grad or (bool(want_grad) and any(ctx.needs_input_grad[3:4] + ctx.needs_input_grad[7:]))
         saved = None
         if need_grad and n_rows > 0:
             nbytes = L.lib().plnerf_mlp_saved_bytes(n_rows, prec)
@@ -498,6 +495,11 @@ class MlpFn(torch.autograd.Function):
         # (the view layer's weight, for the camera code's gradient: the packed copy is not in [out][in] order)
         ctx.view_weight = params[16].detach() if (ctx.n_cam and need_grad) else None
         ctx.beta = beta
+        ctx.in_grad = in_grad and n_rows > 0
+        if ctx.in_grad:      # (what the encoding's derivative needs; the 24 tensors the input-gradient kernel reads)
+            ctx.in_pts, ctx.in_vd, ctx.in_spr, ctx.in_scale = pts_c, vd_c, int(spr), pe_scale
+            ctx.in_params = [p.detach() for p in params]
+            ctx.in_emb_shape = None if embedded is None else embedded.shape
         if beta > 0.0 and saved is not None:
             ctx.save_for_backward(raw)      # (an output: autograd keeps it without a reference cycle)
         return raw
@@ -538,8 +540,33 @@ class MlpFn(torch.autograd.Function):
         if ctx.n_cam and ctx.view_weight is not None:
             # params: ..., views_linears.0.weight (16) [W/2, W + view_ch], views_linears.0.bias (17) [W/2]
             g_cam = torch.mv(ctx.view_weight[:, -ctx.n_cam:].t(), grads[17])
+        g_pts = g_vd = g_embedded = None
+        if ctx.in_grad:
+            xyz_ch, dir_ch = int(ctx.net.input_ch), int(ctx.net.hip_view_ch)
+            g_rows = torch.empty(n_rows, xyz_ch + dir_ch, device=dev, dtype=torch.float32)
+            L.check(L.lib().plnerf_mlp_input_grad(L.ptr_table(ctx.in_params, "params"), prec, xyz_ch, dir_ch, n_rows,
+                                                  L.dptr(ws), L.dptr(g_rows), L.stream()), "plnerf_mlp_input_grad")
+            if ctx.in_emb_shape is not None:
+                g_embedded = g_rows.view(ctx.in_emb_shape) if ctx.needs_input_grad[2] else None
+            else:
+                # the in-kernel encoding gamma(x) = [x, sin((x s) 2^k), cos((x s) 2^k)]_k (run_nerf_helpers.py:24-54; s =
+                # the call's input scale): its transposed Jacobian applied to the rows' gradient
+                def encoding_vjp(x, g, scale):
+                    out = g[:, 0:3].clone()
+                    for k in range((g.shape[1] - 3) // 6):
+                        f = 2.0 ** k
+                        arg = (x * scale) * f
+                        out += (scale * f) * (torch.cos(arg) * g[:, 3 + 6 * k:6 + 6 * k]
+                                              - torch.sin(arg) * g[:, 6 + 6 * k:9 + 6 * k])
+                    return out
+                if ctx.needs_input_grad[0]:
+                    g_pts = encoding_vjp(ctx.in_pts, g_rows[:, :xyz_ch], ctx.in_scale)
+                if ctx.needs_input_grad[1]:      # a ray's direction is encoded once for its spr samples: sum their rows first
+                    g_dir = g_rows[:, xyz_ch:].reshape(-1, ctx.in_spr, dir_ch).sum(1)
+                    g_vd = encoding_vjp(ctx.in_vd, g_dir, ctx.in_scale)
+            ctx.in_params = ctx.in_pts = ctx.in_vd = None
         ctx.saved_acts = None
-        return (None,) * 3 + (g_cam,) + (None,) * 3 + tuple(grads)
+        return (g_pts, g_vd, g_embedded, g_cam) + (None,) * 3 + tuple(grads)
 
 
 class SampleConstFn(torch.autograd.Function):

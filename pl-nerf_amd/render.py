@@ -172,11 +172,13 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_
     N_rays = ray_batch.shape[0]
     if torch.is_grad_enabled() and getattr(ray_batch, "requires_grad", False):
         # In the reference autograd would carry d(loss)/d(rays) through z_vals, the sample positions AND the MLP's
-        # inputs; the HIP path differentiates with respect to the network parameters only (the
-        # positions carry no gradient on the training path).  Returning a partial gradient would be silently wrong.
+        # inputs.  The MLP's inputs have their gradient here (NeRF.query / NeRF.forward: plnerf_mlp_input_grad); the
+        # quadrature's z_vals / ray-length inputs and the fused position kernels do not (nothing
+        # on the training path asks).  Returning a partial gradient would be silently wrong.
         raise NotImplementedError(
             "plnerf_amd: render_rays has no gradient with respect to the ray batch (origins / directions / bounds); "
-            "detach the rays -- the path differentiates with respect to the network parameters only")
+            "detach the rays -- the network itself is differentiable in its inputs (NeRF.query, NeRF.forward), the "
+            "quadrature and the samplers with respect to the ray geometry are not")
     if isinstance(ray_batch, RB.RayColumns):
         rays_o, rays_d, near, far, viewdirs = (ray_batch.rays_o, ray_batch.rays_d, ray_batch.near.reshape(-1, 1),
                                                ray_batch.far.reshape(-1, 1), ray_batch.viewdirs)

@@ -39,6 +39,7 @@ int main(void) {
     int (*p_mlp_saved_layout)(int, int, int) = plnerf_mlp_saved_layout;
     int (*p_mlp_fwd)(const void*, int, const float*, const float*, const float*, int, int, int, int, float, float, float*, void*, int, plnerf_stream_t) = plnerf_mlp_fwd;
     int (*p_mlp_bwd)(const void*, int, const float*, int, int, int, const void*, int, const float*, float, void*, float* const*, float*, plnerf_stream_t) = plnerf_mlp_bwd;
+    int (*p_mlp_input_grad)(const float* const*, int, int, int, int, const void*, float*, plnerf_stream_t) = plnerf_mlp_input_grad;
     int (*p_adam_step)(float*, const float*, float*, float*, int64_t, float, float, float, float, int, float, float, const uint32_t*, const uint32_t*, uint32_t*, plnerf_stream_t) = plnerf_adam_step;
     const void* entry[] = {
         (const void*)&p_version, (const void*)&p_build_flags, (const void*)&p_error_string, (const void*)&p_quad_fwd,
@@ -48,7 +49,7 @@ int main(void) {
         (const void*)&p_select_rays, (const void*)&p_ndc_rays, (const void*)&p_coarse_samples, (const void*)&p_image_loss, (const void*)&p_depth_loss,
         (const void*)&p_embed_rows, (const void*)&p_mlp_packed_bytes, (const void*)&p_mlp_status_offset, (const void*)&p_mlp_pack_weights,
         (const void*)&p_mlp_saved_bytes, (const void*)&p_mlp_bwd_workspace_bytes, (const void*)&p_mlp_saved_layout, (const void*)&p_mlp_fwd,
-        (const void*)&p_mlp_bwd, (const void*)&p_adam_step,
+        (const void*)&p_mlp_bwd, (const void*)&p_mlp_input_grad, (const void*)&p_adam_step,
     };
     size_t i, n = sizeof entry / sizeof entry[0];
     for (i = 0; i < n; ++i)

@@ -171,9 +171,10 @@ def test_camera_code_gradient_through_the_mlp(P, precision):
     (raw2 * g(cot)).sum().backward()
     rel2 = float((cam2.grad.cpu().double() - gr).abs().max()) / float(gr.abs().max())
     assert rel2 <= (2e-4 if precision == "fp32" else 6e-3)
-    # positions that require grad are still refused, loudly
-    with pytest.raises(NotImplementedError):
-        net(torch.zeros(4, 64, device=dev(), requires_grad=True))
+    # rows that require grad get one (plnerf_mlp_input_grad; checked against the oracle in test_gpu_modes.py)
+    x = torch.zeros(4, 64, device=dev(), requires_grad=True)
+    net(x).sum().backward()
+    assert x.grad is not None and x.grad.shape == (4, 64) and torch.isfinite(x.grad).all() and float(x.grad.abs().max()) > 0
 
 
 @pytest.mark.parametrize("precision", ["fp32", "f16x3"])

@@ -615,6 +615,58 @@ def test_narrower_and_shallower_networks(P, shape):
     assert torch.isfinite(rgb).all() and 0.0 < moved <= 5.5e-4
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "bf16x3"])
+def test_input_gradients_match_the_oracle(P, precision):
+    """What autograd gives the reference module when its inputs require a gradient (no reference training path asks: the
+    samples are detached, run_plnerf.py:728): d / d pts and d / d viewdirs through the fused entry (in-kernel encoding), and
+    d / d (embedded rows) through NeRF.forward -- plnerf_mlp_input_grad from the dgrad kernel's planes, then the
+    encoding's derivative -- against the oracle's autograd on the host; the parameter gradients of the same backward
+    are unchanged by the request."""
+    sd = orc.closed_form_state_dict(1, True)
+    gen = torch.Generator().manual_seed(77)
+    R, S = 70, 23                                  # (1610 rows: the last 32-row tile is ragged)
+    pts = (torch.rand(R, S, 3, generator=gen) * 2 - 1) * 1.5
+    vd = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
+    cot = torch.randn(R, S, 4, generator=gen)
+    # the reference in fp64: the encoding's derivative multiplies the rows' gradient by up to 2^9 and sums terms that
+    # cancel, so the oracle's own fp32 autograd is 1.2e-3 of max |g| from it on these inputs -- the kernel path is not
+    sd64 = {k: v.double() for k, v in sd.items()}
+    p_o, v_o = pts.double().requires_grad_(True), vd.double().requires_grad_(True)
+    (orc.query_network(sd64, p_o, v_o) * cot.double()).sum().backward()
+    tol = 2e-5 if precision == "fp32" else 4e-3      # (16-bit modes: half planes in the backward, DESIGN.md section 5)
+    net = make_net(P, sd, precision)
+    p_g, v_g = g(pts).requires_grad_(True), g(vd).requires_grad_(True)
+    (net.query(p_g, v_g) * g(cot)).sum().backward()
+    for got, ref, what in ((p_g.grad, p_o.grad, "pts"), (v_g.grad, v_o.grad, "viewdirs")):
+        row_err = (got.cpu().double() - ref).abs().reshape(-1, 3).max(-1).values / float(ref.abs().max())
+        n_bad = int((row_err > tol).sum())
+        print(f"{precision} d/d {what}: median row {float(row_err.median()):.2e}, worst {float(row_err.max()):.2e} of max |g|, "
+              f"{n_bad} rows beyond {tol:g}")
+        assert got.shape == ref.shape and n_bad <= 3 and float(row_err.max()) <= 5e-2, (what, float(row_err.max()))
+    w_with = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad()
+    (net.query(g(pts), g(vd)) * g(cot)).sum().backward()
+    assert all(torch.equal(a, p.grad) for a, p in zip(w_with, net.parameters()))
+    # only one of the two inputs asks
+    p_only = g(pts).requires_grad_(True)
+    (net.query(p_only, g(vd)) * g(cot)).sum().backward()
+    assert torch.equal(p_only.grad, p_g.grad)
+    # the embedded entry: rows of 63 + 27 channels
+    emb = torch.cat([orc.positional_encoding(pts.reshape(-1, 3), orc.XYZ_FREQS),
+                     orc.positional_encoding(vd[:, None, :].expand(R, S, 3).reshape(-1, 3), orc.DIR_FREQS)], -1)
+    e_o = emb.double().requires_grad_(True)
+    (orc.nerf_mlp(sd64, e_o) * cot.reshape(-1, 4).double()).sum().backward()
+    e_g = g(emb).requires_grad_(True)
+    (net(e_g) * g(cot.reshape(-1, 4))).sum().backward()
+    # (a pre-activation within fp32 rounding of zero takes the other side of its ReLU in fp64: such a row's gradient
+    # differs by that unit's whole contribution -- DESIGN.md section 6 -- so rows are counted, as in test_gpu_fullsize.py)
+    row_err = (e_g.grad.cpu().double() - e_o.grad).abs().max(-1).values / float(e_o.grad.abs().max())
+    n_bad = int((row_err > tol).sum())
+    print(f"{precision} d/d embedded: median row {float(row_err.median()):.2e}, worst {float(row_err.max()):.2e} of max |g|, "
+          f"{n_bad} of {row_err.numel()} rows beyond {tol:g}")
+    assert e_g.grad.shape == emb.shape and n_bad <= 3 and float(row_err.max()) <= 5e-2
+
+
 # ----------------------------------------------------------------------------- range of the half modes
 def test_half_modes_flag_range_overflow_and_withhold_the_step(P):
     """`f16x3` / `f16` clamp at the IEEE-half maximum (65,504).  A forward that gets there must not pass silently: the
