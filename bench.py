@@ -91,12 +91,6 @@ def parse(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--cpu-no-grid", action="store_true", help="cpu_baseline: only the workload's own cell")
     ap.add_argument("--views", type=int, default=4, help="synthetic views resident on the device")
-    ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2],
-                    help="train.TrainStep's schedule of the step's two independent chains: 0 = one stream, the reference's "
-                         "order (default); 1 = the coarse network's loss / backward / Adam on a second HIP stream next to "
-                         "the fine pass; 2 = additionally the next step's coarse pass next to this step's fine backward. "
-                         "Every step computes the same values in all three (tests/test_gpu_step.py); same-box A/B: "
-                         "profiles/r04_pipeline_ab.txt (+1.3 % / -0.8 %)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the bounded extra legs of the default single-GPU run (north_star's 65,536 x 192 MLP benchmark "
                          "in every precision, the other BASELINE workloads x 10 steps, one 800x800 frame, the 200-step "
@@ -202,7 +196,8 @@ def cpu_baseline(a):
 
 class Scene:
     """Synthetic views resident in HBM: poses on the NeRF-synthetic sphere (or near-identity forward-facing poses)
-    and random target images.  What the reference's loader would have put on the device."""
+    and their target images (the analytic sphere scene of tools/scene.py).  What the reference's loader would have put on
+    the device."""
 
     def __init__(self, P, workload, n_views, dev):
         gen = torch.Generator().manual_seed(1)
@@ -221,7 +216,15 @@ class Scene:
                      for i in range(n_views)]
         self.K = [[f, 0, self.W / 2], [0, f, self.H / 2], [0, 0, 1]]
         self.poses = poses
-        self.images = [torch.rand(self.H, self.W, 3, generator=gen).to(dev) for _ in range(n_views)]
+        if workload == "llff_ndc":      # (no analytic forward-facing scene: smooth colour ramps)
+            yy, xx = torch.meshgrid(torch.linspace(0, 1, self.H), torch.linspace(0, 1, self.W), indexing="ij")
+            self.images = [torch.stack([xx, yy, 0.5 * (xx + yy)], -1).roll(37 * i, 1).contiguous().to(dev)
+                           for i in range(n_views)]
+        else:
+            # targets a network can fit: the analytic sphere scene of tools/scene.py seen from each pose (round 5; until
+            # round 4 uniform noise, whose loss never fell -- same step time, profiles/r04_psnr_vs_fp32_2000steps.jsonl)
+            from tools.scene import analytic_image
+            self.images = [analytic_image(P, self.H, self.W, self.K, c2w, dev) for c2w in poses]
         self.hyp = None
         if workload == "depth_128_64":     # three depth hypotheses per pixel (target_h of the space-carving loss)
             self.hyp = [(2.0 + 4.0 * torch.rand(3, self.H, self.W, generator=gen)).to(dev) for _ in range(n_views)]
@@ -259,7 +262,7 @@ def build_step(P, a, precision, scene, dev, rank, world, force_dist):
     finally:
         sys.stdout = _stdout
     nets = [kw["network_fn"], kw["network_fine"]]
-    ts = P.TrainStep(args, kw, opt, opt_c, distributed=world > 1, seed=0, pipeline=a.pipeline)
+    ts = P.TrainStep(args, kw, opt, opt_c, distributed=world > 1, seed=0)
     if force_dist and world == 1:
         ts.bucket = dp.GradientBucket(nets)
     torch.manual_seed(1000 + rank)         # torch.randn density noise (llff): decorrelate the ranks
@@ -534,24 +537,10 @@ def main(argv=None):
             wl[w] = {"ms_per_step": 1e3 * dtw / 10, "rays_per_s": R * 10 / dtw, "steps": 10, "warmup": 3,
                      "step_ms": stats_ms(psw), "fine_fwd_launch_ms": fwd_w, "fine_fwd_rows": rows_w,
                      "fine_fwd_frac_of_mfma_peak": (tfw / peak_of(a.precision)) if tfw else None,
-                     "pipeline": a.pipeline if w != "depth_128_64" else 0, "what": WORKLOADS[w][2]}
+                     "what": WORKLOADS[w][2]}
             del st, nets_w, sc, tm
             torch.cuda.empty_cache()
         extra["workloads"] = wl
-        # -- the same workload on the two-stream schedule (train.TrainStep pipeline=2: bit-identical steps, the coarse
-        #    chain beside the fine one and across step boundaries); the headline stays the one-stream schedule, whose
-        #    kernels run alone and can be priced against their rooflines
-        if a.pipeline == 0:
-            b = copy.copy(a)
-            b.pipeline = 2
-            st, nets_w = build_step(P, b, a.precision, scene, dev, rank, world, False)
-            dt2, loss2, _, ps2 = timed(st, 5, 20)
-            extra["two_stream_schedule"] = {"pipeline": 2, "ms_per_step": 1e3 * dt2 / 20, "rays_per_s": R * 20 / dt2,
-                                            "steps": 20, "warmup": 5, "step_ms": stats_ms(ps2), "final_loss": loss2,
-                                            "what": "the default workload with the coarse network's chain on a second HIP "
-                                                    "stream, also across steps; same arithmetic, same results"}
-            del st, nets_w
-            torch.cuda.empty_cache()
         # -- north_star's MLP benchmark, every precision
         extra["mlp_only_65536x192"] = leg_mlp_only(P, dev)
         # -- one full frame through render(c2w=...)
@@ -559,7 +548,7 @@ def main(argv=None):
         # -- "PSNR vs ref" (BASELINE.json's metric, second half): the benchmarked arithmetic against the exact-fp32 kernels
         if a.precision != "fp32" and a.psnr_steps > 0:
             from tools.scene import psnr_vs_ref
-            extra["psnr_vs_ref"] = psnr_vs_ref(P, dev, a.psnr_steps, rays=R, precision=a.precision, pipeline=a.pipeline)
+            extra["psnr_vs_ref"] = psnr_vs_ref(P, dev, a.psnr_steps, rays=R, precision=a.precision)
             torch.cuda.empty_cache()
 
     # the all-reduce as the launch stream sees it: HIP events on that stream either side of GradientBucket.allreduce_mean
@@ -617,7 +606,6 @@ def main(argv=None):
                                    f"N_importance={a.n_importance}, mode=linear/midpoint; full step = device-side pixel "
                                    f"choice + ray generation + render + backward + per-network grad all-reduce + Adam",
                        "global_rays": R * world, "precision": a.precision, "parallelism": f"dp{world}",
-                       "pipeline": a.pipeline if a.workload != "depth_128_64" else 0,
                        "rccl_world_size": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
                        "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
                        "self_launched": bool(os.environ.get("PLNERF_BENCH_SELF_LAUNCHED")),

@@ -338,14 +338,16 @@ def render_rays(ray_batch, sd_coarse, sd_fine, N_samples, mode, color_mode, retr
     raw = query_network(sd_coarse, pts, viewdirs)
     rgb, disp, acc, w, depth, tau, T = raw2outputs(raw, z, near, far, rays_d, mode, color_mode,
                                                    raw_noise_std, pytest, white_bkgd, farcolorfix)
-    internals = {"z_coarse": z, "raw_coarse": raw, "weights_coarse": w}
+    internals = {"z_coarse": z, "raw_coarse": raw, "weights_coarse": w, "tau_coarse": tau, "T_coarse": T}
     ret = {}
     if N_importance > 0:
         coarse = (rgb, disp, acc, depth)
         if mode == "linear":
-            z_new = sample_pdf_reformulation(z, w, tau, T, near, far, N_importance,
-                                             det=(perturb == 0.0), pytest=pytest,
-                                             zero_threshold=zero_tol, epsilon_=epsilon, u=u)[0]
+            z_new, _, _, _, inds = sample_pdf_reformulation(z, w, tau, T, near, far, N_importance,
+                                                            det=(perturb == 0.0), pytest=pytest,
+                                                            zero_threshold=zero_tol, epsilon_=epsilon, u=u,
+                                                            return_inds=True)
+            internals["inds"] = inds
         else:
             z_mid = 0.5 * (z[..., 1:] + z[..., :-1])
             z_new = sample_pdf(z_mid, w[..., 1:-1], N_importance, det=(perturb == 0.0),
@@ -367,6 +369,23 @@ def render_rays(ray_batch, sd_coarse, sd_fine, N_samples, mode, color_mode, retr
     if return_internals:
         return ret, internals
     return ret
+
+
+def fine_stage(ray_batch, sd_fine, z_fine, mode="linear", color_mode="midpoint", white_bkgd=False,
+               raw_noise_std=0.0, pytest=False, farcolorfix=False, depth_variant=False):
+    """The second half of render_rays on GIVEN merged depths z_fine [R,S] (run_plnerf.py:735-752;
+    depth variant: run_nerf_sample_based_depth.py:907-921): positions, the fine network, raw2outputs.
+    For per-stage comparisons on identical samples.  Returns a dict with raw, the
+    maps, weights, tau, T."""
+    rays_o, rays_d = ray_batch[:, 0:3], ray_batch[:, 3:6]
+    viewdirs = ray_batch[:, 8:11]
+    near, far = ray_batch[:, 6:7], ray_batch[:, 7:8]
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z_fine[..., :, None]
+    raw = query_network_depth(sd_fine, pts, viewdirs) if depth_variant else query_network(sd_fine, pts, viewdirs)
+    rgb, disp, acc, w, depth, tau, T = raw2outputs(raw, z_fine, near, far, rays_d, mode, color_mode,
+                                                   raw_noise_std, pytest, white_bkgd, farcolorfix)
+    return {"raw": raw, "rgb_map": rgb, "disp_map": disp, "acc_map": acc, "depth_map": depth,
+            "weights": w, "tau": tau, "T": T}
 
 
 # ----------------------------------------------------------------------------
@@ -581,7 +600,7 @@ def _draw_u_depth(R, n, det, pytest, load_u):
 
 def render_rays_depth(ray_batch, sd_coarse, sd_fine, N_samples, mode, color_mode, perturb=0.0,
                       N_importance=0, white_bkgd=False, raw_noise_std=0.0, pytest=False, cached_u=None,
-                      bb_center=0.0, bb_scale=1.0, t_rand=None, u_fine=None):
+                      bb_center=0.0, bb_scale=1.0, t_rand=None, u_fine=None, return_internals=False):
     """run_nerf_sample_based_depth.py:792-958, is_joint False.  `pred_hyp` stays attached: to the final
     weights' tau and T in mode 'linear' (:923-934), to the final weights in mode 'constant'.  t_rand / u_fine
     inject the stratified draw and the importance draw for HIP-vs-oracle comparisons."""
@@ -594,7 +613,7 @@ def render_rays_depth(ray_batch, sd_coarse, sd_fine, N_samples, mode, color_mode
     rgb, disp, acc, w, depth, tau, T = raw2outputs(raw, z, near, far, rays_d, mode, color_mode, raw_noise_std,
                                                    pytest, white_bkgd)
     R = ray_batch.shape[0]
-    ret = {}
+    ret, internals = {}, {}
 
     def draw(z, w, tau, T, n, u=None, det=False, pyt=False):
         if mode == "linear":
@@ -605,6 +624,7 @@ def render_rays_depth(ray_batch, sd_coarse, sd_fine, N_samples, mode, color_mode
         hyp = draw(z, w, tau, T, N_samples, u=u)
     else:
         coarse = (rgb, disp, acc, depth, z, w)
+        internals = {"tau_coarse": tau, "T_coarse": T, "weights_coarse": w, "raw_coarse": raw}      # (for per-stage comparisons)
         z_new = draw(z, w, tau, T, N_importance, u=u_fine, det=(perturb == 0.0), pyt=pytest).detach()
         z_new = torch.clamp(z_new, near, far)
         z, _ = torch.sort(torch.cat([z, z_new], -1), -1)
@@ -619,6 +639,9 @@ def render_rays_depth(ray_batch, sd_coarse, sd_fine, N_samples, mode, color_mode
                     "z_std": torch.std(hyp, dim=-1, unbiased=False)})
     ret.update({"rgb_map": rgb, "disp_map": disp, "acc_map": acc, "depth_map": depth, "z_vals": z,
                 "weights": w[..., 1:] if mode == "linear" else w, "pred_hyp": hyp, "u": u, "raw": raw})
+    if return_internals:
+        internals.update({"z_samples": z_new, "tau": tau, "T": T, "weights_full": w} if N_importance > 0 else {})
+        return ret, internals
     return ret
 
 

@@ -94,8 +94,8 @@ def lib():
         flags = handle.plnerf_build_flags()
         if flags and os.environ.get("PLNERF_ALLOW_TOOLS_BUILD") != "1":
             raise ImportError(
-                f"{LIB_PATH} was built with tools-only switches (plnerf_build_flags() = {flags}: bit 0 = timing "
-                "ablations that make results WRONG, bit 1 = timing switches, bit 2 = trace hooks).  It is not the "
+                f"{LIB_PATH} was built with tools-only switches (plnerf_build_flags() = {flags}: bit 2 = trace hooks; "
+                "bits 0 / 1 = the timing ablations of builds before round 5).  It is not the "
                 "product library: rebuild with `make -C pl-nerf_amd/csrc` (no -D switches), or set "
                 "PLNERF_ALLOW_TOOLS_BUILD=1 for a measurement script under tools/.")
         _lib = handle

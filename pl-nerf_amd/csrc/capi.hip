@@ -14,9 +14,9 @@ extern "C" const char* plnerf_error_string(int code) {
     }
 }
 
-// Build hygiene: the MLP translation units carry timing-experiment switches (PLNERF_ABLATE, RR_ABLATE: results wrong
-// by construction) and trace hooks (PLNERF_TRACE, RR_TRACE) for tools/ builds.  A library built with any of them says
-// so here, and the Python binding refuses to load it as the product (pl-nerf_amd/_lib.py).
+// Build hygiene: the MLP translation units carry trace hooks (PLNERF_TRACE, RR_TRACE) for tools/ builds.  A library built
+// with them says so here (bit 2), and the Python binding refuses to load it as the product (pl-nerf_amd/_lib.py).  (The
+// results-wrong ablation switches of rounds 1-4 -- bits 0 and 1 -- left the product sources in round 5.)
 extern "C" int plnerf_build_flags_h16(void);
 extern "C" int plnerf_build_flags_rr(void);
 extern "C" int plnerf_build_flags(void) { return plnerf_build_flags_h16() | plnerf_build_flags_rr(); }

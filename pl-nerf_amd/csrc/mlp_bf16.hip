@@ -83,11 +83,10 @@ int bf16_dgrad(const void* packed, int ns, const float* g_raw, int n_rows, const
 }  // namespace impl
 }  // namespace plnerf
 
-// bit 0: results-wrong ablation switches compiled in; bit 1: results-right timing switches; bit 2: trace hooks
+// bit 2: trace hooks compiled in (tools/trace_fwd.py, tools/trace_bwd.py); the results-wrong ablation switches of rounds
+// 1-4 (bits 0 and 1) are gone from the product sources -- git history at a21e3cd has them
 extern "C" int plnerf_build_flags_h16(void) {
     int f = 0;
-    if (PLNERF_ABLATE & ~(64 | 128 | 256)) f |= 1;
-    if (PLNERF_ABLATE & (64 | 128 | 256)) f |= 2;
 #ifdef PLNERF_TRACE
     f |= 4;
 #endif

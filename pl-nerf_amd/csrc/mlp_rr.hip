@@ -1,6 +1,6 @@
 // Register-resident forward kernel of the 16-bit-operand MFMA MLP: packing, dispatch and the C++ entry points.  The
 // kernel itself is mlp_rr_body.inc; its six instantiations live in mlp_rr_k*.hip so that they compile in parallel
-// (-DRR_SINGLE_TU puts them all here: the trace / ablation builds of tools/build_rr.sh).
+// (-DRR_SINGLE_TU puts them all here: the trace builds of tools/build_rr.sh).
 #include "mlp_rr_body.inc"
 
 #ifdef RR_TRACE
@@ -10,7 +10,7 @@ extern "C" int plnerf_debug_rr_trace(unsigned long long* out8) {
 #endif
 
 extern "C" int plnerf_build_flags_rr(void) {
-    int f = RR_ABLATE ? 1 : 0;
+    int f = 0;
 #ifdef RR_TRACE
     f |= 4;
 #endif

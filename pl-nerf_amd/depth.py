@@ -24,7 +24,7 @@ from . import functional as Fn
 from . import raybatch as RB
 from .nerf import Embedder, NeRF
 from .optim import FlatAdam
-from .render import (MAX_ROWS_PER_LAUNCH, _draw_noise, _rgb_sigma, batchify, raw2outputs as _raw2outputs, sample_pdf,
+from .render import (MAX_ROWS_PER_LAUNCH, _draw_noise, _refuse_unsupported, _rgb_sigma, batchify, raw2outputs as _raw2outputs, sample_pdf,
                      sample_pdf_reformulation)
 
 _RENDER = sys.modules[__name__.rsplit(".", 1)[0] + ".render"]      # (the package attribute `render` is the function)
@@ -70,6 +70,10 @@ def _kernel_encoding(embed_fn, embeddirs_fn, viewdirs):
 
 
 FUSE_STAGES = True      # (tests switch it off to compare the one-launch stages with the separate launches, bit for bit)
+# Tests only (tests/test_gpu_fullsize.py), as render.STAGE_TAP: a dict that render_rays fills with its intermediate tensors
+# (coarse weights / tau / T and importance samples, final weights / tau / T and the hypotheses' search indices); while it
+# is set the stages run as their separate launches, which is where those tensors exist in HBM.
+STAGE_TAP = None
 _BOX_CACHE = {}
 
 
@@ -243,7 +247,8 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
     # The stages between and behind the two network evaluations as ONE launch each, like the NVS path's (piecewise-linear
     # mode): plnerf_coarse_epilogue (raw2outputs + importance sampling + clamp + sort + positions) and
     # plnerf_fine_epilogue (raw2outputs + the hypotheses' sampler + z_std); bit-identical to the separate calls below.
-    fused = FUSE_STAGES and fused_glue and mode == "linear" and color_mode in ("midpoint", "left")
+    tap = STAGE_TAP
+    fused = FUSE_STAGES and fused_glue and mode == "linear" and color_mode in ("midpoint", "left") and tap is None
     if fused_glue:
         # depths, jitter and positions in one launch (plnerf_coarse_samples: bit-identical to the expressions below,
         # which are :775-790 and run_plnerf.py:683-708 alike); the jitter from the reference's draw, or in the kernel
@@ -290,10 +295,14 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
             farcolorfix=farcolorfix)
 
     def hypotheses(z_vals, weights, tau, T, n, load_u):
-        if mode == "linear":
+        if mode == "linear" and tap is not None:
+            u = _draw_u(N_rays, n, perturb == 0., pytest, load_u, is_joint, dev).contiguous()
+            s, inds = Fn.sample_pl(z_vals, weights, tau, T, near, far, u, zero_tol, epsilon, want_inds=True)
+            tap.update(weights_full=weights, tau=tau, T=T, hyp_inds=inds)
+        elif mode == "linear":
             s, _, _, _, u = sample_pdf_reformulation_return_u(
                 z_vals, weights, tau, T, near, far, n, det=(perturb == 0.), pytest=pytest, load_u=load_u,
-                quad_solution_v2=quad_solution_v2, joint=is_joint)
+                quad_solution_v2=quad_solution_v2, zero_threshold=zero_tol, epsilon_=epsilon, joint=is_joint)
         elif mode == "constant":
             z_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
             s, u = sample_pdf_return_u(z_mid, weights[..., 1:-1], n, det=(perturb == 0.), pytest=pytest,
@@ -309,9 +318,14 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
     else:
         rgb_map_0, disp_map_0, acc_map_0, depth_map_0, z_vals_0, weights_0 = \
             rgb_map, disp_map, acc_map, depth_map, z_vals, weights
-        if mode == "linear":
+        if mode == "linear" and tap is not None:
+            u0 = _nvs_draw_u(z_vals.shape[:-1], N_importance, perturb == 0., pytest, dev)
+            z_samples, inds0 = Fn.sample_pl(z_vals, weights, tau, T, near, far, u0, zero_tol, epsilon, want_inds=True)
+            tap.update(weights0_full=weights, tau0=tau, T0=T, u0=u0, inds0=inds0, z_samples=z_samples)
+        elif mode == "linear":
             z_samples = sample_pdf_reformulation(z_vals, weights, tau, T, near, far, N_importance, det=(perturb == 0.),
-                                                 pytest=pytest, quad_solution_v2=quad_solution_v2)[0]
+                                                 pytest=pytest, quad_solution_v2=quad_solution_v2,
+                                                 zero_threshold=zero_tol, epsilon_=epsilon)[0]
         else:
             z_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
             z_samples = sample_pdf(z_mid, weights[..., 1:-1], N_importance, det=(perturb == 0.), pytest=pytest)
@@ -407,9 +421,10 @@ class _SpaceCarvingFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pred, target_h, mask, threshold, is_joint):
-        dummy = pred.new_zeros(pred.shape[0], 3)
+        # (a dummy image pair one apart: the discarded image term's psnr stays finite)
+        dummy, other = pred.new_zeros(pred.shape[0], 3), pred.new_ones(pred.shape[0], 3)
         # weight 1: loss5[3] is the unweighted term, g_hyp its gradient
-        loss5, _, _, g_hyp = Fn.depth_loss_and_grads(dummy, None, dummy, pred, target_h, 1.0, threshold=threshold, mask=mask,
+        loss5, _, _, g_hyp = Fn.depth_loss_and_grads(dummy, None, other, pred, target_h, 1.0, threshold=threshold, mask=mask,
                                                      is_joint=is_joint)
         ctx.g = g_hyp
         return loss5[3]
@@ -464,6 +479,7 @@ def create_nerf(args, scene_render_params=None, device=None):
                     density_activation="softplus", dense_layer_init=True).to(device)
     model = network(args.netdepth, args.netwidth)
     model_fine = network(args.netdepth_fine, args.netwidth_fine) if args.N_importance > 0 else None
+    _refuse_unsupported(model, model_fine)      # (at the boundary, not at the first query: render.create_nerf)
     grad_vars = list(model.parameters()) + (list(model_fine.parameters()) if model_fine is not None else [])
     box = (getattr(args, "bb_center", 0.0), getattr(args, "bb_scale", 1.0))
 

@@ -192,13 +192,42 @@ class GradientBucket:
                 self._tails[mi] = None
             self._fallback([self.modules[mi] for mi in rest], world)
             self.collectives += 1
+            self.collectives += self._sync_status(rest, group)
         return 1.0 / world if deferred else 1.0
+
+    def _sync_status(self, idx, group):
+        """The fallback exchange has no status tail (a batch split over several MlpFn calls, an optimizer that is not
+        FlatAdam, overlap disabled: `.grad` is not the one buffer whose tail the reduction kernel writes).  The range guard
+        is per network AND per rank, the averaged gradient is not: a rank whose forward clamped has contributed a wrong
+        gradient, so EVERY rank must withhold the step, and every rank must raise at the next check_range() -- not one
+        rank while the others block in the next collective.  One MAX all-reduce of the ranks' sticky status words (bit
+        masks: MAX keeps "non-zero" and exists on every backend), written back into each network's own word and handed out by
+        `tails()` as the optimizer's guards, exactly as on the overlapped path.  Returns the number of collectives used."""
+        owners = [mi for mi in idx if _guarded(self.modules[mi])]
+        if not owners:
+            return 0
+        words = [self.modules[mi].status_word() for mi in owners]
+        both = torch.cat(words)
+        dist.all_reduce(both, op=dist.ReduceOp.MAX, group=group)
+        for mi, w, v in zip(owners, words, both.split(1)):
+            w.copy_(v)      # (sticky on every rank: an optimizer guarded by the network itself, and check_range(), see it)
+            self._tails[mi] = v
+        return 1
 
     def allreduce_mean(self, group=None, force=False):
         """Average every gradient over the ranks (in place; `.grad` holds the mean afterwards).  Returns the number of
         collectives used."""
         self.finish(None, defer_scale=False, group=group, force=force)
         return self.collectives
+
+
+def _guarded(m):
+    """A network whose 16-bit kernels keep a range status word on the device (nerf.NeRF in a guarded precision)."""
+    try:
+        return (hasattr(m, "status_word") and getattr(m, "precision", None) in GUARDED_PRECISIONS and m.is_supported()
+                and next(m.parameters()).is_cuda)
+    except StopIteration:
+        return False
 
 
 def broadcast_optimizer_state(optimizers, src=0, group=None):

@@ -51,63 +51,6 @@ class KernelTimer:
 KERNEL_TIMER = None
 
 
-class CoarseChain:
-    """Two HIP streams for one optimisation step (train.TrainStep arms one per step; None = everything on one stream).
-
-    The reference's step has two independent sub-graphs once the fine pass's sample positions exist: z_samples is detached
-    (run_plnerf.py:728) and the loss is a sum of two image terms (:1287-1296), so the COARSE network's loss, backward,
-    gradient exchange and Adam step need nothing from the fine network -- and the fine chain needs only the positions.
-    render_rays therefore runs the coarse pass under `coarse()` (the chain's own stream), hands the fine pass its inputs
-    through `coarse_done` (which also launches the rest of the coarse chain: image loss, backward, Adam, on the same
-    stream) and runs the fine pass under `fine()` (the launch stream, which waits for the positions only).  The coarse
-    backward is HBM-bound and the fine forward MFMA-bound, so the two overlap on the chip; and because nothing on the
-    coarse stream waits for the launch stream, the NEXT step's coarse forward overlaps this step's fine backward.
-    Autograd runs a Function's backward on the stream of its forward: no stream switch inside any backward method."""
-
-    def __init__(self, device):
-        self.stream = torch.cuda.Stream(device=device)
-        self.main = None
-        self.on_coarse_done = None      # callable(rgb0): the rest of the coarse chain (set by the train step)
-        self.positions_ready = torch.cuda.Event()
-        self.calls = 0
-
-    def begin(self, wait_for_main):
-        """Start a step: the launch stream is the current one.  `wait_for_main`: the coarse stream first waits for
-        everything enqueued on the launch stream so far (a caller's own ray batch; the first step)."""
-        self.main = torch.cuda.current_stream()
-        self.calls = 0
-        if wait_for_main:
-            self.stream.wait_stream(self.main)
-
-    def coarse(self):
-        return torch.cuda.stream(self.stream)
-
-    def fine(self):
-        return torch.cuda.stream(self.main)
-
-    def hand_over(self, tensors):
-        """Tensors allocated on the coarse stream that the launch stream will read (the caching allocator must not hand
-        their blocks to the coarse stream's next step while the launch stream still uses them)."""
-        for t in tensors:
-            if isinstance(t, torch.Tensor) and t.is_cuda:
-                t.record_stream(self.main)
-
-    def coarse_done(self, rgb0, for_fine):
-        """Called on the coarse stream when the fine pass's inputs are enqueued."""
-        self.calls += 1
-        if self.calls > 1:
-            raise RuntimeError("plnerf_amd: a pipelined step renders its batch in ONE render_rays call "
-                               "(the batch was split into chunks: raise `chunk` or use pipeline=0)")
-        self.hand_over(for_fine)
-        self.positions_ready.record(self.stream)
-        if self.on_coarse_done is not None:
-            self.on_coarse_done(rgb0)
-
-    def begin_fine(self):
-        self.main.wait_event(self.positions_ready)
-
-
-CHAIN = None
 GRAD_TAIL = 4      # floats behind a network's flat gradient (16 bytes: [0] = range status, the rest unused)
 
 
@@ -414,7 +357,8 @@ def image_loss_and_grads(rgb, rgb0, target, coarse_loss=None):
     """plnerf_image_loss without the autograd wrapper, for a caller that back-propagates the two gradients itself
     (train.TrainStep: torch.autograd.backward((rgb, rgb0), (g_rgb, g_rgb0)) is loss.backward() minus three tiny
     launches).  Returns (loss4 = [total, fine, coarse, psnr], g_rgb, g_rgb0).  `coarse_loss` (with rgb0 None): the loss4
-    of an earlier call on the coarse image alone, whose [1] becomes this call's coarse term (functional.CoarseChain)."""
+    of an earlier call on the coarse image alone, whose [1] becomes this call's coarse term (a caller that starts the
+    coarse network's backward before the fine pass exists still gets the reference's total)."""
     return _image_loss(rgb, rgb0, target, coarse_loss)
 
 

@@ -5,8 +5,6 @@ function), so a caller of the reference's `create_nerf` / `render` / `render_ray
 switch to this module unchanged.  Everything numerical happens in libplnerf_hip.so via
 `functional.py`; torch is used for allocation, the random draws and the autograd tape.
 """
-import contextlib
-
 import numpy as np
 import torch
 
@@ -18,6 +16,11 @@ from .optim import FlatAdam
 from .rays import get_rays, ndc_rays
 
 DEBUG = False
+# Tests only (tests/test_gpu_fullsize.py): a dict that render_rays fills with its intermediate tensors -- coarse depths, raw,
+# weights, tau, T, the importance samples with their search indices, the merged depths, the final weights.  While it is set
+# the coarse pass's epilogue runs as its separate launches (bit-identical to the fused one:
+# test_fused_coarse_epilogue_equals_separate_launches), which is where those tensors exist in HBM.
+STAGE_TAP = None
 MAX_ROWS_PER_LAUNCH = 1 << 21   # MLP rows per kernel launch when activations are saved (~21 GB fp32)
 
 
@@ -189,107 +192,98 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_
         viewdirs = ray_batch[:, -3:].contiguous() if ray_batch.shape[-1] > 8 else None
         near, far = ray_batch[:, 6:7].contiguous(), ray_batch[:, 7:8].contiguous()
 
-    # Two-stream step (functional.CoarseChain, armed by train.TrainStep): the coarse pass -- and, from `coarse_done` on,
-    # the coarse network's loss, backward and optimizer step -- on the chain's own stream, the fine pass on the launch
-    # stream, which waits for the fine pass's inputs only.  Needs two distinct networks (with one network the fine pass
-    # must see the weights the coarse pass saw).
-    chain = Fn.CHAIN
-    if chain is not None and not (ray_batch.is_cuda and N_rays > 0 and N_importance > 0 and network_fine is not None and
-                                  network_fine is not network_fn):
-        chain = None
-    if chain is not None and torch.cuda.current_stream() != chain.stream:
-        # a ray batch prepared on the caller's stream (slices, NDC warp, ...): the coarse stream starts behind it
-        chain.stream.wait_stream(torch.cuda.current_stream())
-    with (chain.coarse() if chain is not None else contextlib.nullcontext()):
-        t_vals = Fn.cpu_linspace(N_samples, dev)
-        # The ray batch carries no gradient on this path (refused above), so the prologue's element-wise chain runs as
-        # ONE kernel (depths + positions, bit-identical to the torch expressions below, which remain for an empty batch).
-        fused_glue = ray_batch.is_cuda and N_rays > 0
-        # Random draws: pytest=True replays the reference's numpy draws; otherwise an installed functional.DrawSource
-        # supplies counter-based draws (inside the consuming kernels on the fused path), else torch.rand as the
-        # reference does.
-        draws = None if pytest else Fn.DRAWS
-        if draws is not None:
-            draws.noise_calls = 0      # (this call's coarse pass draws its density noise first, then the fine pass)
+    t_vals = Fn.cpu_linspace(N_samples, dev)
+    # The ray batch carries no gradient on this path (refused above), so the prologue's element-wise chain runs as
+    # ONE kernel (depths + positions, bit-identical to the torch expressions below, which remain for an empty batch).
+    fused_glue = ray_batch.is_cuda and N_rays > 0
+    # Random draws: pytest=True replays the reference's numpy draws; otherwise an installed functional.DrawSource
+    # supplies counter-based draws (inside the consuming kernels on the fused path), else torch.rand as the
+    # reference does.
+    draws = None if pytest else Fn.DRAWS
+    if draws is not None:
+        draws.noise_calls = 0      # (this call's coarse pass draws its density noise first, then the fine pass)
+    if fused_glue:
+        t_rand = None
+        if perturb > 0. and (pytest or draws is None):
+            shape = [N_rays, N_samples]
+            t_rand = Fn.numpy_uniform(shape, dev) if pytest else torch.rand(shape, device=dev)
+        z_vals, pts = Fn.coarse_samples(rays_o, rays_d, near, far, t_vals, t_rand, lindisp, perturb > 0., draws)
+    else:
+        if not lindisp:
+            z_vals = near * (1. - t_vals) + far * t_vals
+        else:
+            z_vals = 1. / (1. / near * (1. - t_vals) + 1. / far * t_vals)
+        z_vals = z_vals.expand([N_rays, N_samples])
+
+        if perturb > 0.:
+            mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+            upper = torch.cat([mids, z_vals[..., -1:]], -1)
+            lower = torch.cat([z_vals[..., :1], mids], -1)
+            if pytest:
+                t_rand = Fn.numpy_uniform(list(z_vals.shape), dev)
+            elif draws is not None:
+                t_rand = draws.uniform(N_rays, N_samples, Fn.DrawSource.T_RAND, dev)
+            else:
+                t_rand = torch.rand(z_vals.shape, device=dev)
+            z_vals = lower + (upper - lower) * t_rand
+
+        pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
+
+    if constant_init:   # run_plnerf.py:710-711: overrides the mode for the whole call
+        mode = "constant"
+
+    raw = network_query_fn(pts, viewdirs, network_fn)
+    tap = STAGE_TAP
+    fused_epilogue = fused_glue and N_importance > 0 and mode == "linear" and color_mode in ("midpoint", "left") \
+        and tap is None
+    if tap is not None:
+        tap.update(z_vals0=z_vals, raw0=raw)
+    if fused_epilogue:
+        # coarse raw2outputs + sampler + clamp + sort + fine positions + z_std: one launch (weights, tau, T and the
+        # cdf never reach HBM); identical values to the separate calls below
+        det = perturb == 0.
+        u = _draw_u([N_rays], N_importance, det, pytest, dev) if (pytest or det or draws is None) else None
+        rgb_map_0, disp_map_0, acc_map_0, depth_map_0, z_vals, pts, z_std = Fn.CoarseEpilogueFn.apply(
+            _rgb_sigma(raw), z_vals, near, far, rays_o, rays_d, _draw_noise(raw, raw_noise_std, pytest), u,
+            N_importance, color_mode, white_bkgd, farcolorfix, zero_tol, epsilon, draws, False)
+    else:
+        rgb_map, disp_map, acc_map, weights, depth_map, tau, T = raw2outputs(
+            raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std, pytest=pytest, white_bkgd=white_bkgd,
+            farcolorfix=farcolorfix)
+
+    if N_importance > 0 and not fused_epilogue:
+        rgb_map_0, disp_map_0, acc_map_0, depth_map_0 = rgb_map, disp_map, acc_map, depth_map
+        if mode == "linear" and tap is not None:
+            u = _draw_u(z_vals.shape[:-1], N_importance, perturb == 0., pytest, dev)
+            z_samples, inds = Fn.sample_pl(z_vals, weights, tau, T, near, far, u, zero_tol, epsilon, want_inds=True)
+            tap.update(weights0=weights, tau0=tau, T0=T, u=u, inds=inds)
+        elif mode == "linear":
+            z_samples, _, _, _ = sample_pdf_reformulation(
+                z_vals, weights, tau, T, near, far, N_importance, det=(perturb == 0.), pytest=pytest,
+                quad_solution_v2=quad_solution_v2, zero_threshold=zero_tol, epsilon_=epsilon)
+        elif mode == "constant":
+            z_vals_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+            z_samples = sample_pdf(z_vals_mid, weights[..., 1:-1], N_importance, det=(perturb == 0.),
+                                   pytest=pytest)
+        z_samples = z_samples.detach()
+        # clamp + cat + sort (run_plnerf.py:731-734) in one kernel; z_samples clamped for z_std
+        z_vals = Fn.merge_sort(z_vals, z_samples, near, far)
+        z_std = torch.std(torch.clamp(z_samples, near, far), dim=-1, unbiased=False)
         if fused_glue:
-            t_rand = None
-            if perturb > 0. and (pytest or draws is None):
-                shape = [N_rays, N_samples]
-                t_rand = Fn.numpy_uniform(shape, dev) if pytest else torch.rand(shape, device=dev)
-            z_vals, pts = Fn.coarse_samples(rays_o, rays_d, near, far, t_vals, t_rand, lindisp, perturb > 0., draws)
+            pts = Fn.ray_points(rays_o, rays_d, z_vals)
         else:
-            if not lindisp:
-                z_vals = near * (1. - t_vals) + far * t_vals
-            else:
-                z_vals = 1. / (1. / near * (1. - t_vals) + 1. / far * t_vals)
-            z_vals = z_vals.expand([N_rays, N_samples])
-
-            if perturb > 0.:
-                mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
-                upper = torch.cat([mids, z_vals[..., -1:]], -1)
-                lower = torch.cat([z_vals[..., :1], mids], -1)
-                if pytest:
-                    t_rand = Fn.numpy_uniform(list(z_vals.shape), dev)
-                elif draws is not None:
-                    t_rand = draws.uniform(N_rays, N_samples, Fn.DrawSource.T_RAND, dev)
-                else:
-                    t_rand = torch.rand(z_vals.shape, device=dev)
-                z_vals = lower + (upper - lower) * t_rand
-
             pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
-
-        if constant_init:   # run_plnerf.py:710-711: overrides the mode for the whole call
-            mode = "constant"
-
-        raw = network_query_fn(pts, viewdirs, network_fn)
-        fused_epilogue = fused_glue and N_importance > 0 and mode == "linear" and color_mode in ("midpoint", "left")
-        if fused_epilogue:
-            # coarse raw2outputs + sampler + clamp + sort + fine positions + z_std: one launch (weights, tau, T and the
-            # cdf never reach HBM); identical values to the separate calls below
-            det = perturb == 0.
-            u = _draw_u([N_rays], N_importance, det, pytest, dev) if (pytest or det or draws is None) else None
-            rgb_map_0, disp_map_0, acc_map_0, depth_map_0, z_vals, pts, z_std = Fn.CoarseEpilogueFn.apply(
-                _rgb_sigma(raw), z_vals, near, far, rays_o, rays_d, _draw_noise(raw, raw_noise_std, pytest), u,
-                N_importance, color_mode, white_bkgd, farcolorfix, zero_tol, epsilon, draws, False)
-        else:
-            rgb_map, disp_map, acc_map, weights, depth_map, tau, T = raw2outputs(
-                raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std, pytest=pytest, white_bkgd=white_bkgd,
-                farcolorfix=farcolorfix)
-
-        if N_importance > 0 and not fused_epilogue:
-            rgb_map_0, disp_map_0, acc_map_0, depth_map_0 = rgb_map, disp_map, acc_map, depth_map
-            if mode == "linear":
-                z_samples, _, _, _ = sample_pdf_reformulation(
-                    z_vals, weights, tau, T, near, far, N_importance, det=(perturb == 0.), pytest=pytest,
-                    quad_solution_v2=quad_solution_v2, zero_threshold=zero_tol, epsilon_=epsilon)
-            elif mode == "constant":
-                z_vals_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
-                z_samples = sample_pdf(z_vals_mid, weights[..., 1:-1], N_importance, det=(perturb == 0.),
-                                       pytest=pytest)
-            z_samples = z_samples.detach()
-            # clamp + cat + sort (run_plnerf.py:731-734) in one kernel; z_samples clamped for z_std
-            z_vals = Fn.merge_sort(z_vals, z_samples, near, far)
-            z_std = torch.std(torch.clamp(z_samples, near, far), dim=-1, unbiased=False)
-            if fused_glue:
-                pts = Fn.ray_points(rays_o, rays_d, z_vals)
-            else:
-                pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
-
-        if chain is not None:
-            # the fine pass's inputs are enqueued: the launch stream may go on as soon as THEY exist, while this stream
-            # continues with the coarse network's loss / backward / optimizer step (the callback the train step set)
-            chain.coarse_done(rgb_map_0, (z_vals, pts, rgb_map_0, disp_map_0, acc_map_0, depth_map_0, z_std, rays_o, rays_d,
-                                          near, far, viewdirs))
+        if tap is not None:
+            tap.update(z_samples=z_samples, z_fine=z_vals)
 
     if N_importance > 0:
-        with (chain.fine() if chain is not None else contextlib.nullcontext()):
-            if chain is not None:
-                chain.begin_fine()
-            run_fn = network_fn if network_fine is None else network_fine
-            raw = network_query_fn(pts, viewdirs, run_fn)
-            rgb_map, disp_map, acc_map, weights, depth_map, tau, T = raw2outputs(
-                raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std, pytest=pytest,
-                white_bkgd=white_bkgd, farcolorfix=farcolorfix)
+        run_fn = network_fn if network_fine is None else network_fine
+        raw = network_query_fn(pts, viewdirs, run_fn)
+        rgb_map, disp_map, acc_map, weights, depth_map, tau, T = raw2outputs(
+            raw, z_vals, near, far, rays_d, mode, color_mode, raw_noise_std, pytest=pytest,
+            white_bkgd=white_bkgd, farcolorfix=farcolorfix)
+        if tap is not None:
+            tap.update(weights=weights)
 
     ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map, 'depth_map': depth_map}
     if retraw:
@@ -360,6 +354,15 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
     return np.stack(rgbs, 0), np.stack(disps, 0)
 
 
+def _refuse_unsupported(*nets):
+    """create_nerf's boundary check: a flag combination the compiled trunk cannot express (netdepth > 8, netwidth > 256,
+    multires > 10, ... -- INTEGRATION.md has the table) raises HERE, before any data is loaded, not at the first network
+    query minutes into a reference-style run.  NeRF.__init__ itself stays permissive (same state_dict as the reference)."""
+    for net in nets:
+        if net is not None:
+            net._require_supported()
+
+
 def create_nerf(args, device=None):
     """run_plnerf.py:417-502: (render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer,
     optimizer_coarse).  `device` (extension) defaults to cuda:<current>; optional `args.precision` picks the MLP
@@ -379,6 +382,7 @@ def create_nerf(args, device=None):
                     input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs, precision=precision).to(device)
     model = network(args.netdepth, args.netwidth)
     model_fine = network(args.netdepth_fine, args.netwidth_fine) if args.N_importance > 0 else None
+    _refuse_unsupported(model, model_fine)
     coarse_vars = list(model.parameters())
     grad_vars = coarse_vars if model_fine is None else list(model_fine.parameters())
 

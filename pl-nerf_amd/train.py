@@ -9,7 +9,6 @@ ray shards per rank with one bucketed gradient all-reduce (dp.py).  Ray selectio
 device (only the N_rand selected pixels are turned into rays) instead of rebuilding the full
 H x W ray grid and choosing on the host every step (lines 1259, 1275).
 """
-import contextlib
 import ctypes
 import os
 
@@ -114,24 +113,12 @@ class TrainStep:
     renders it or N ranks render a shard each.  `counter_rng=False` restores torch.rand."""
 
     def __init__(self, args, render_kwargs_train, optimizer, optimizer_coarse, start=0, distributed=None, seed=0,
-                 counter_rng=True, range_check_every=100, pipeline=None):
-        """pipeline: how the step's two independent chains are scheduled (functional.CoarseChain).
-          0  (default; PLNERF_PIPELINE in the environment overrides) one stream, the reference's order: render, loss,
-             backward, both optimizers.
-          1  the coarse network's loss / backward / gradient exchange / optimizer step on a second HIP stream as soon as
-             the coarse pass is rendered, next to the fine pass on the launch stream (HBM-bound backward next to the
-             MFMA-bound forward); the second stream starts behind whatever the launch stream holds at the step's start.
-             When the step returns, everything it did is ordered before whatever the caller enqueues on the launch stream
-             next.
-          2  the same, and in `step_view` -- where the step owns its inputs from the pixel choice on -- the coarse stream
-             never waits for the launch stream: the next step's coarse pass (which needs the coarse weights only)
-             overlaps this step's fine backward.  Every step still computes exactly the reference's step, but the coarse
-             network's weights and optimizer state belong to the coarse stream between steps: read or write them from
-             outside (save / load a checkpoint, evaluate, ...) only after `drain()`.
-        Same-box A/B at BASELINE configs[1] (profiles/r04_pipeline_ab.txt): 1 is 1.3 % slower, 2 is 0.8 % faster than 0, all
-        three bit-identical -- both forward kernels and the weight-gradient kernel each fill a CU on their own (144 / 147
-        KB of LDS, 512 registers per SIMD), so two kernels "overlap" by taking CUs from each other, not by sharing them:
-        the fine forward's launch stretches from 2.16 to 3.09 ms by exactly the coarse backward's own 0.9 ms."""
+                 counter_rng=True, range_check_every=100):
+        """The step runs on ONE stream in the reference's order: render, loss, backward, both optimizers.  (Rounds 3-4
+        also carried two-stream schedules -- the coarse network's chain beside the fine pass, and across step boundaries;
+        bit-identical, measured +1.4 % / -0.8 % with twice the step jitter, profiles/r04_pipeline_ab.txt -- removed in
+        round 5: the forward kernels and the weight-gradient kernel each fill a CU on their own, so two kernels "overlap"
+        only by taking CUs from each other.)"""
         self.args = args
         self.kw = render_kwargs_train
         self.optimizer = optimizer
@@ -147,15 +134,6 @@ class TrainStep:
         # and raises.  0 = never look (the caller does).
         self.range_check_every = int(range_check_every)
         self.seed = seed
-        if pipeline is None:
-            pipeline = int(os.environ.get("PLNERF_PIPELINE", "0"))
-        fine = self.kw.get("network_fine")
-        coarse = self.kw["network_fn"]
-        two_nets = fine is not None and fine is not coarse and next(fine.parameters()).is_cuda and \
-            self.kw.get("N_importance", 0) > 0 and optimizer is not optimizer_coarse
-        self.pipeline = int(pipeline) if two_nets else 0
-        self.chain = Fn.CoarseChain(next(coarse.parameters()).device) if self.pipeline else None
-        self._chain_started = False
         self.bucket = None
         if distributed and self.world > 1:
             # replicas must start from the same weights (create_nerf initialises from each process's own RNG, and a
@@ -174,36 +152,13 @@ class TrainStep:
         """The loop body from the view on (run_plnerf.py:1259-1316): choose this rank's n_rand pixels of the view on
         the device, then the optimisation step.  `image` [H, W, 3] lives on the device."""
         n_rand = int(n_rand if n_rand is not None else self.args.N_rand)
-        chain = self._arm_chain(own_inputs=True)
-        with (chain.coarse() if chain is not None else contextlib.nullcontext()):
-            cols, target, _ = select_view_rays(H, W, K, c2w, image, n_rand, near, far, seed=self.seed,
-                                               step=self.global_step, ray_id0=self.rank * n_rand, precrop=precrop,
-                                               want_viewdirs=bool(self.kw.get("use_viewdirs", True)))
-        if chain is not None:
-            chain.hand_over((target,))
-        return self._step(H, W, K, cols, target, near, far, chain)
+        cols, target, _ = select_view_rays(H, W, K, c2w, image, n_rand, near, far, seed=self.seed,
+                                           step=self.global_step, ray_id0=self.rank * n_rand, precrop=precrop,
+                                           want_viewdirs=bool(self.kw.get("use_viewdirs", True)))
+        return self._step(H, W, K, cols, target, near, far)
 
     def __call__(self, H, W, K, batch_rays, target_s, near=0., far=1.):
-        return self._step(H, W, K, batch_rays, target_s, near, far, self._arm_chain(own_inputs=False))
-
-    def _arm_chain(self, own_inputs):
-        """The step's CoarseChain, or None for the one-stream order (pipeline 0).  render_rays decides itself whether a
-        call takes the two-stream path (two distinct networks, a non-empty GPU batch; `constant_init` steps do) and
-        leaves the chain unused otherwise -- _step then joins the streams.  The coarse stream waits for the launch stream
-        unless the step owns its inputs (pipeline 2)."""
-        if self.chain is None:
-            return None
-        cross_step = self.pipeline >= 2 and own_inputs and self._chain_started
-        self.chain.begin(wait_for_main=not cross_step)
-        self._chain_started = True
-        return self.chain
-
-    def drain(self):
-        """Both streams wait for each other (host does not block): after this, work enqueued on the launch stream sees
-        every step so far, and the next step starts behind it."""
-        if self.chain is not None and self._chain_started:
-            torch.cuda.current_stream().wait_stream(self.chain.stream)
-            self._chain_started = False
+        return self._step(H, W, K, batch_rays, target_s, near, far)
 
     def _render(self, H, W, K, rays, near, far, constant_init):
         chunk = getattr(self.args, "chunk", 1024 * 32)
@@ -223,19 +178,6 @@ class TrainStep:
                                         constant_init=constant_init, **self.kw)
         return rgb, extras
 
-    def _coarse_tail(self, chain, target_s, rgb0):
-        """The rest of the coarse chain, on the coarse stream (functional.CoarseChain.coarse_done calls this right after
-        the fine pass's inputs are enqueued): img2mse(rgb0) and its gradient (:1293-1296), the coarse network's
-        backward, its gradient exchange, its Adam step (:1303)."""
-        chain.loss_c, g_rgb0, _ = Fn.image_loss_and_grads(rgb0, None, target_s)
-        chain.hand_over((chain.loss_c,))
-        self.optimizer_coarse.zero_grad()
-        torch.autograd.backward((rgb0,), (g_rgb0,))
-        self._exchange_and_step([self.optimizer_coarse], [self.nets[0]], [[self.nets[0]]])
-        if self.bucket is not None:
-            chain.hand_over(self.bucket.tails([self.nets[0]]))      # (the fine optimizer's guard reads it on the launch stream)
-        chain.coarse_stepped.record(chain.stream)
-
     def _exchange_and_step(self, opts, exchange, guarded_by):
         """Finish the gradient exchange of the networks `exchange` (data parallel only) and step the optimizers `opts`,
         opts[k] guarded by the networks guarded_by[k].  With optim.FlatAdam the 1 / world factor and the guard -- the
@@ -254,55 +196,34 @@ class TrainStep:
             tails = self.bucket.tails(nets)
             opt.step(grad_scale=scale, guards=tails if len(tails) == len(nets) else None)
 
-    def _step(self, H, W, K, rays, target_s, near, far, chain=None):
+    def _step(self, H, W, K, rays, target_s, near, far):
         i = self.global_step + 1                      # the reference iterates i = start+1 .. N_iters
         n_local = rays.shape[0] if isinstance(rays, RB.RayColumns) else rays[0].reshape(-1, 3).shape[0]
         prev = Fn.DRAWS
         if self.draws is not None:
             self.draws.step, self.draws.ray_id0 = self.global_step, self.rank * n_local
             Fn.set_draw_source(self.draws)
-        if chain is not None:
-            chain.on_coarse_done = lambda rgb0: self._coarse_tail(chain, target_s, rgb0)
-            chain.coarse_stepped = torch.cuda.Event()
-            Fn.CHAIN = chain
         try:
-            # (chain: the ray batch's preparation -- slices, the NDC warp -- belongs to the coarse stream as well)
-            with (chain.coarse() if chain is not None else contextlib.nullcontext()):
-                rgb, extras = self._render(H, W, K, rays, near, far, i < getattr(self.args, "constant_init", 0))
+            rgb, extras = self._render(H, W, K, rays, near, far, i < getattr(self.args, "constant_init", 0))
         finally:
             Fn.set_draw_source(prev)
-            Fn.CHAIN = None
         rgb0 = extras.get('rgb0')
-        chained = chain is not None and chain.calls == 1
-        if chain is not None and not chained:
-            # render_rays did not take the two-stream path (an empty batch, ...): whatever it enqueued on the coarse
-            # stream comes before the one-stream tail below
-            chain.main.wait_stream(chain.stream)
         self.optimizer.zero_grad()
-        if chained:
-            # the coarse network's part of the step is already enqueued (and maybe done) on the coarse stream; here the
-            # fine network's: img2mse(rgb) (+ the coarse term for the total, :1296), backward, exchange, Adam (:1302)
-            chain.main.wait_event(chain.coarse_stepped)      # (the coarse loss value; and the coarse network's range word: optim guard)
-            loss4, g_rgb, _ = Fn.image_loss_and_grads(rgb, None, target_s, coarse_loss=chain.loss_c)
+        self.optimizer_coarse.zero_grad()
+        if rgb.is_cuda and rgb.dim() == 2 and rgb.shape == target_s.shape:
+            # img2mse(rgb) + img2mse(rgb0), the psnr and both image gradients in one launch (:1287-1300);
+            # backward((rgb, rgb0), (d loss / d rgb, d loss / d rgb0)) is loss.backward()
+            loss4, g_rgb, g_rgb0 = Fn.image_loss_and_grads(rgb, rgb0, target_s)
             loss, psnr = loss4[0], loss4[3]
-            torch.autograd.backward((rgb,), (g_rgb,))
-            self._exchange_and_step([self.optimizer], [self.nets[1]], [self.nets])
+            torch.autograd.backward((rgb,) if rgb0 is None else (rgb, rgb0),
+                                    (g_rgb,) if rgb0 is None else (g_rgb, g_rgb0))
         else:
-            self.optimizer_coarse.zero_grad()
-            if rgb.is_cuda and rgb.dim() == 2 and rgb.shape == target_s.shape:
-                # img2mse(rgb) + img2mse(rgb0), the psnr and both image gradients in one launch (:1287-1300);
-                # backward((rgb, rgb0), (d loss / d rgb, d loss / d rgb0)) is loss.backward()
-                loss4, g_rgb, g_rgb0 = Fn.image_loss_and_grads(rgb, rgb0, target_s)
-                loss, psnr = loss4[0], loss4[3]
-                torch.autograd.backward((rgb,) if rgb0 is None else (rgb, rgb0),
-                                        (g_rgb,) if rgb0 is None else (g_rgb, g_rgb0))
-            else:
-                img_loss = img2mse(rgb, target_s)
-                loss = img_loss if rgb0 is None else img_loss + img2mse(rgb0, target_s)
-                psnr = mse2psnr(img_loss.detach())
-                loss.backward()
-            # (fine optimizer first, as the reference does; with ONE network both optimizers step the same weights, :438-447)
-            self._exchange_and_step([self.optimizer, self.optimizer_coarse], self.nets, [self.nets, self.nets[:1]])
+            img_loss = img2mse(rgb, target_s)
+            loss = img_loss if rgb0 is None else img_loss + img2mse(rgb0, target_s)
+            psnr = mse2psnr(img_loss.detach())
+            loss.backward()
+        # (fine optimizer first, as the reference does; with ONE network both optimizers step the same weights, :438-447)
+        self._exchange_and_step([self.optimizer, self.optimizer_coarse], self.nets, [self.nets, self.nets[:1]])
         new_lrate = self.learning_rate()
         for group in self.optimizer.param_groups:
             group['lr'] = new_lrate
@@ -318,8 +239,6 @@ class TrainStep:
         first taken back out of the optimizers' step counts; a set word raises FloatingPointError -- on every rank of a
         data-parallel job at the same step: the ranks' words travel with the gradients (dp.GradientBucket.tails), so a
         rank whose own words are clear still sees the withheld steps."""
-        if self.chain is not None:
-            torch.cuda.current_stream().wait_stream(self.chain.stream)      # (the coarse stream's steps count as well)
         withheld = 0
         for opt in (self.optimizer, self.optimizer_coarse):
             if hasattr(opt, "withheld_steps"):

@@ -6,19 +6,28 @@ grid-size or padded-plane bug of a 6,144-workgroup launch; these can.
 
 Stated tolerances:
   * coarse maps (continuous in the network output): 1e-5 abs+rel on EVERY ray -- the contract;
-  * final maps pass through the sampler, which is discontinuous (a fine sample hops a cdf bin when the
-    coarse network's output moves by an ulp): the NUMBER of rays beyond 1e-5 is asserted and printed per map --
-    0 on rgb; acc, depth and z_std may have a handful of hopping rays out of 4096 (bounds below; the exact-fp32 kernels
-    show the same handful -- measured: fp32 64+128 depth 5 rays, 128+64 depth 1 / z_std 2; f16x3 64+128 acc 1 / depth 9, 128+64 depth 1 / z_std 2);
-  * one full-size training step: loss to 1e-5; every parameter tensor's gradient within the bound of the small-fixture
-    tests (fp32: 2e-4 coarse / 2e-3 fine of max|g|; f16x3: 6e-3 / 3e-3, the half-plane backward).
+  * round 5, per stage on IDENTICAL inputs (test_stages_at_baseline_size_vs_oracle and its depth twin): the HIP
+    path's own intermediate tensors are handed to the oracle stage by stage -- coarse quadrature on the HIP raw, the
+    sampler on the HIP weights / tau / T and draws (search indices BIT-EXACT; sample values 1e-5 on >= 99.99 %, 1e-3 on
+    all: the closed form's conditioning), clamp + sort bit-exact, and the FINE stage (fine network +
+    raw2outputs) on the HIP path's own merged depths at 1e-5 on EVERY ray for rgb / acc / depth / disp / weights;
+  * final maps end to end pass through the sampler, which is discontinuous in the coarse output: the NUMBER of rays
+    beyond 1e-5 is asserted per map, and every such ray is shown to be one whose importance samples differ from the
+    oracle's own (a search index that differs = the sample hopped a cdf bin; or the same bins with a sample moved by more
+    than 1e-6 = the closed form amplified the coarse pass's rounding) -- given the per-stage results above nothing else can
+    move a final map;
+  * one full-size training step per single-GPU workload of BASELINE.json: loss to 1e-5; every parameter tensor's
+    gradient within the bound of the small-fixture tests (fp32: 2e-4 coarse / 2e-3 fine of max|g|; f16x3: 6e-3 / 3e-3,
+    the half-plane backward); the depth-supervised step against the fp64 oracle (its loss runs
+    through the sampler's ill-conditioned closed form: bound = twice the fp32 oracle's own distance + 5e-4, cosine).
 
-Round 4 adds the two other single-GPU workloads of BASELINE.json at full size against the oracle: configs[3] (LLFF:
+Round 4 added the two other single-GPU workloads of BASELINE.json at full size against the oracle: configs[3] (LLFF:
 4096 NDC rays in [near 0, far 1], raw_noise_std = 1 with the reference's `pytest` noise draw, no white background) and
 configs[4]'s render (the depth-supervised variant: 57|3-channel network with the pi-scaled encoding, softplus density,
-128 + 64 samples, pred_hyp) -- same structure: coarse maps at 1e-5 on every ray, final maps by count.
+128 + 64 samples, pred_hyp).
 
-Host cost: four oracle renders (about 5 s each on 16 threads) and one oracle training step (about 20 s).
+Host cost: five oracle renders and as many fine stages (about 5 s each on 16 threads), four oracle training steps
+(about 20 s each) and one in fp64.
 """
 import os
 
@@ -228,3 +237,320 @@ def test_depth_variant_render_at_baseline_size_vs_oracle(P, golden, precision):
     print(f"{precision} depth_128_64 x {R_FULL} rays: coarse rgb0 {maxdiff(got['rgb0'], ref['rgb0']):.2e}, depth0 "
           f"{maxdiff(got['depth0'], ref['depth0']):.2e}; final " + ", ".join(report))
     assert not over, f"{precision} depth_128_64: " + "; ".join(over)
+
+
+# =====================================================================================================================
+# Round 5: per stage, per ray.  The HIP path's OWN intermediate tensors -- taken where they exist in HBM,
+# on the separate-launch route that test_fused_coarse_epilogue_equals_separate_launches holds bit-equal to the fused
+# one; the final maps of the two routes are compared bit for bit here as well, at full size -- go into the oracle's
+# stages one at a time.
+# =====================================================================================================================
+def _llff_batch():
+    """BASELINE configs[3] per GPU: 4096 rays of a 378 x 504 forward-facing view warped to NDC (as the test above)."""
+    H, W, f = 378, 504, 407.0
+    K = [[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]]
+    c2w = torch.eye(4)[:3, :4].clone()
+    c2w[:, 3] = torch.tensor([0.05, -0.02, 0.1])
+    o, d = orc.get_rays(H, W, K, c2w)
+    pix = torch.randperm(H * W, generator=torch.Generator().manual_seed(31))[:R_FULL]
+    o, d = o.reshape(-1, 3)[pix], d.reshape(-1, 3)[pix]
+    vd = d / torch.norm(d, dim=-1, keepdim=True)
+    o_ndc, d_ndc = orc.ndc_rays(H, W, f, 1.0, o, d)
+    return torch.cat([o_ndc, d_ndc, torch.zeros(R_FULL, 1), torch.ones(R_FULL, 1), vd], -1).float()
+
+
+# name -> (N_samples, N_importance, white_bkgd, raw_noise_std, ray batch seed or "llff")
+NVS_WORKLOADS = {"blender_64_128": (64, 128, True, 0.0, 11), "blender_128_64": (128, 64, True, 0.0, 11),
+                 "llff_ndc": (64, 128, False, 1.0, "llff")}
+
+
+@pytest.fixture(scope="module")
+def oracle_cases():
+    """The oracle's end-to-end render of each workload WITH its internals, once (shared by the precision legs)."""
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            ns, ni, white, noise, src = NVS_WORKLOADS[name]
+            batch = _llff_batch() if src == "llff" else orc.synthetic_blender_rays(R_FULL, seed=src)[0]
+            sd_c, sd_f = orc.closed_form_state_dict(0, True), orc.closed_form_state_dict(1, True)
+            kw = dict(retraw=True, perturb=1.0, N_importance=ni, white_bkgd=white, raw_noise_std=noise, pytest=True)
+            with torch.no_grad():
+                ref, internals = orc.render_rays(batch, sd_c, sd_f, ns, "linear", "midpoint", return_internals=True, **kw)
+            cache[name] = (batch, sd_c, sd_f, ns, ni, kw, ref, internals)
+        return cache[name]
+    return get
+
+
+def _beyond(got, ref, tol=1e-5):
+    """Per-ray mask: some element of the ray's row is beyond tol (abs + rel)."""
+    d = (got.detach().cpu().double() - ref.double()).abs()
+    bad = d > tol * (1.0 + ref.double().abs())
+    return bad.reshape(bad.shape[0], -1).any(-1), float(d.max())
+
+
+def _sampler_stage(z0, w0, tau0, T0, near, far, n, u, inds_hip, samples_hip, what):
+    """The oracle's sampler on the HIP path's own weights / tau / T / draws: search indices bit-exact; values 1e-5 on at
+    least 99.99 % and 1e-3 on all (the closed form cancels catastrophically on a few draws in a million -- an ulp of
+    logf / sqrtf becomes 1e-4, oracle and HIP both fp32: DESIGN.md section 6)."""
+    s_o, _, _, _, inds_o = orc.sample_pdf_reformulation(z0, w0, tau0, T0, near, far, n, u=u, return_inds=True)
+    assert torch.equal(inds_o, inds_hip), f"{what}: {int((inds_o != inds_hip).sum())} search indices differ on identical inputs"
+    d = (samples_hip.double() - s_o.double()).abs()
+    n_bad = int((d > 1e-5 * (1.0 + s_o.double().abs())).sum())
+    assert n_bad <= 1e-4 * d.numel() and float(d.max()) <= 1e-3, f"{what}: {n_bad} of {d.numel()} samples beyond 1e-5, max {float(d.max()):.2e}"
+    return n_bad, float(d.max())
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+@pytest.mark.parametrize("workload", sorted(NVS_WORKLOADS))
+def test_stages_at_baseline_size_vs_oracle(P, oracle_cases, workload, precision):
+    import sys
+    R_ = sys.modules[P.render_rays.__module__]      # (the package attribute `render` is the function, not the module)
+    batch, sd_c, sd_f, ns, ni, kw, ref, oi = oracle_cases(workload)
+    near, far, rays_d = batch[:, 6:7], batch[:, 7:8], batch[:, 3:6]
+    emb_fn, _ = P.get_embedder(10, 0)
+    embd_fn, _ = P.get_embedder(4, 0)
+    qfn = lambda inputs, viewdirs, fn: P.run_network(inputs, viewdirs, fn, emb_fn, embd_fn)
+    net_c, net_f = make_net(P, sd_c, precision), make_net(P, sd_f, precision)
+    with torch.no_grad():
+        got = P.render_rays(g(batch), net_c, qfn, ns, "linear", "midpoint", network_fine=net_f, **kw)
+        tap = {}
+        R_.STAGE_TAP = tap
+        try:
+            got_t = P.render_rays(g(batch), net_c, qfn, ns, "linear", "midpoint", network_fine=net_f, **kw)
+        finally:
+            R_.STAGE_TAP = None
+    torch.cuda.synchronize()
+    t = {k: v.detach().cpu() for k, v in tap.items()}
+    tag = f"{precision} {workload}"
+    # 0. the tapped route IS the shipped route: every map bit for bit (z_std: torch.std vs the kernel's own reduction)
+    for k in ("rgb_map", "disp_map", "acc_map", "depth_map", "raw", "rgb0", "disp0", "acc0", "depth0"):
+        assert torch.equal(got[k], got_t[k]), f"{tag}: fused and separate-launch routes differ in {k}"
+    assert_close(got_t["z_std"], got["z_std"].cpu(), atol=2e-6, rtol=1e-5, what=f"{tag} z_std of the two routes")
+    # 1. coarse stage: depths (same draws), the network on them, the quadrature on the HIP raw
+    z_bits = torch.equal(t["z_vals0"], oi["z_coarse"])
+    assert maxdiff(t["z_vals0"], oi["z_coarse"]) <= 1e-6, f"{tag}: coarse depths"
+    assert_close(t["raw0"], oi["raw_coarse"], what=f"{tag} coarse raw")
+    with torch.no_grad():
+        q = orc.raw2outputs(t["raw0"], t["z_vals0"], near, far, rays_d, "linear", "midpoint", kw["raw_noise_std"], True,
+                            kw["white_bkgd"])
+    for k, v in zip(("rgb0", "disp0", "acc0", "weights0", "depth0", "tau0", "T0"), q):
+        assert_close(got_t[k] if k in got_t else t[k], v, what=f"{tag} coarse quadrature on the HIP raw: {k}")
+    # 2. the sampler on the HIP path's own weights / tau / T / draws; clamp + sort
+    u = t["u"] if t["u"].dim() == 2 else t["u"].expand(R_FULL, ni).contiguous()
+    n_bad_s, worst_s = _sampler_stage(t["z_vals0"], t["weights0"], t["tau0"], t["T0"], near, far, ni, u, t["inds"],
+                                      t["z_samples"], f"{tag} importance sampler")
+    z_cl = torch.clamp(t["z_samples"], near, far)
+    assert torch.equal(torch.sort(torch.cat([t["z_vals0"], z_cl], -1), -1)[0], t["z_fine"]), f"{tag}: clamp + cat + sort"
+    assert_close(got["z_std"], torch.std(z_cl, dim=-1, unbiased=False), atol=2e-6, rtol=1e-5, what=f"{tag} z_std")
+    # 3. the FINE stage on the HIP path's own merged depths: every ray, every map, 1e-5
+    with torch.no_grad():
+        fs = orc.fine_stage(batch, sd_f, t["z_fine"], "linear", "midpoint", kw["white_bkgd"], kw["raw_noise_std"], True)
+    assert_close(got["raw"], fs["raw"], what=f"{tag} fine raw on identical samples")
+    worst = {}
+    for k in ("rgb_map", "disp_map", "acc_map", "depth_map"):
+        assert_close(got[k], fs[k], what=f"{tag} fine stage on identical samples: {k}")
+        worst[k] = maxdiff(got[k], fs[k])
+    assert_close(t["weights"], fs["weights"], what=f"{tag} fine stage on identical samples: weights")
+    # 4. end to end: every ray beyond 1e-5 is a ray whose importance samples differ from the oracle's own
+    hop = (oi["inds"] != t["inds"]).any(-1)
+    moved = ((oi["z_samples"] - z_cl).abs() > 1e-6).any(-1) & ~hop
+    counted, unexplained = {}, {}
+    for k in ("rgb_map", "acc_map", "depth_map", "disp_map", "z_std"):
+        bad, _ = _beyond(got[k], ref[k])
+        counted[k] = int(bad.sum())
+        unexplained[k] = int((bad & ~(hop | moved)).sum())
+    print(f"{tag} x {R_FULL} rays: coarse depths bit-equal {z_bits}; sampler on identical inputs: {n_bad_s} samples beyond "
+          f"1e-5 (max {worst_s:.1e}); fine stage on identical samples: " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items())
+          + f"; end to end: {int(hop.sum())} rays with a hopped sample, {int(moved.sum())} with a moved one; rays beyond 1e-5 "
+          + ", ".join(f"{k} {v}" for k, v in counted.items()))
+    assert not any(unexplained.values()), f"{tag}: rays beyond 1e-5 whose samples equal the oracle's: {unexplained}"
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+def test_depth_stages_at_baseline_size_vs_oracle(P, golden, precision):
+    """The same per-stage structure for BASELINE configs[4]'s render (the depth-supervised variant, 128 + 64 samples):
+    coarse quadrature, importance sampler, fine stage on identical samples at 1e-5 on every ray, the hypotheses' sampler
+    on the HIP path's own final weights / tau / T and draws (indices bit-exact), and the end-to-end counts explained."""
+    import sys
+    from test_gpu_modes import _depth_setup
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    gd = golden("g8b_depth_variant_128_64")
+    Dp, kw, _, _ = _depth_setup(gd, precision)
+    dmod = sys.modules[Dp.render_rays.__module__]
+    batch, _ = orc.synthetic_blender_rays(R_FULL, seed=13)
+    near, far, rays_d = batch[:, 6:7], batch[:, 7:8], batch[:, 3:6]
+    sd_c, sd_f = orc.closed_form_state_dict_depth(0, True), orc.closed_form_state_dict_depth(1, True)
+    ns, ni = 128, 64
+    with torch.no_grad():
+        ref, oi = orc.render_rays_depth(batch, sd_c, sd_f, ns, "linear", "midpoint", perturb=1.0, N_importance=ni,
+                                        white_bkgd=True, pytest=True, return_internals=True)
+        got = Dp.render_rays(g(batch), retraw=True, pytest=True, **kw)
+        tap = {}
+        dmod.STAGE_TAP = tap
+        try:
+            got_t = Dp.render_rays(g(batch), retraw=True, pytest=True, **kw)
+        finally:
+            dmod.STAGE_TAP = None
+    torch.cuda.synchronize()
+    t = {k: v.detach().cpu() for k, v in tap.items()}
+    tag = f"{precision} depth_128_64"
+    for k in ("rgb_map", "disp_map", "acc_map", "depth_map", "raw", "rgb0", "disp0", "acc0", "depth0", "z_vals", "weights",
+              "pred_hyp", "weights0", "z_vals0", "u"):
+        assert torch.equal(got[k], got_t[k]), f"{tag}: one-launch and separate-launch stages differ in {k}"
+    # 1. coarse quadrature on the HIP raw -- the coarse raw is not in the dict: the oracle's own coarse pass stands in for
+    #    the network check (coarse maps at 1e-5 on every ray, test above); weights / tau / T against the oracle's
+    assert_close(t["weights0_full"], oi["weights_coarse"], what=f"{tag} coarse weights")
+    # 2. importance sampler on the HIP path's own weights / tau / T and draws; clamp + sort
+    z0 = got["z_vals0"].cpu()
+    n_bad_s, worst_s = _sampler_stage(z0, t["weights0_full"], t["tau0"], t["T0"], near, far, ni, t["u0"], t["inds0"],
+                                      t["z_samples"], f"{tag} importance sampler")
+    z_cl = torch.clamp(t["z_samples"], near, far)
+    assert torch.equal(torch.sort(torch.cat([z0, z_cl], -1), -1)[0], got["z_vals"].cpu()), f"{tag}: clamp + cat + sort"
+    # 3. the fine stage on the HIP path's own merged depths
+    with torch.no_grad():
+        fs = orc.fine_stage(batch, sd_f, got["z_vals"].cpu(), "linear", "midpoint", True, 0.0, True, depth_variant=True)
+    assert_close(got["raw"], fs["raw"], what=f"{tag} fine raw on identical samples")
+    worst = {}
+    for k in ("rgb_map", "disp_map", "acc_map", "depth_map"):
+        assert_close(got[k], fs[k], what=f"{tag} fine stage on identical samples: {k}")
+        worst[k] = maxdiff(got[k], fs[k])
+    assert_close(got["weights"], fs["weights"][..., 1:], what=f"{tag} fine stage on identical samples: weights")
+    assert_close(t["tau"], fs["tau"], what=f"{tag} fine stage on identical samples: tau")
+    assert_close(t["T"], fs["T"], what=f"{tag} fine stage on identical samples: T")
+    # 4. the hypotheses on identical final weights / tau / T / u
+    n_bad_h, worst_h = _sampler_stage(got["z_vals"].cpu(), t["weights_full"], t["tau"], t["T"], near, far, ni, got["u"].cpu(),
+                                      t["hyp_inds"], got["pred_hyp"].cpu(), f"{tag} hypotheses' sampler")
+    assert_close(got["z_std"], torch.std(got["pred_hyp"].cpu(), dim=-1, unbiased=False), atol=2e-6, rtol=1e-5,
+                 what=f"{tag} z_std")
+    # 5. end to end: every ray beyond the bound has importance samples (or, for pred_hyp / z_std, hypotheses) that differ
+    #    from the oracle's own
+    with torch.no_grad():
+        _, _, _, _, inds_o = orc.sample_pdf_reformulation(ref["z_vals0"], oi["weights_coarse"], oi["tau_coarse"],
+                                                          oi["T_coarse"], near, far, ni, u=t["u0"], return_inds=True)
+    hop = (inds_o != t["inds0"]).any(-1)
+    moved = ((oi["z_samples"] - z_cl).abs() > 1e-6).any(-1) & ~hop
+    counted, unexplained = {}, {}
+    for k in ("rgb_map", "acc_map", "depth_map", "disp_map", "pred_hyp", "z_std"):
+        bad, _ = _beyond(got[k], ref[k], 2e-4 if k == "pred_hyp" else 1e-5)
+        counted[k] = int(bad.sum())
+        unexplained[k] = int((bad & ~(hop | moved)).sum())
+    print(f"{tag} x {R_FULL} rays: samplers on identical inputs: {n_bad_s} / {n_bad_h} values beyond 1e-5 (max {worst_s:.1e} / "
+          f"{worst_h:.1e}); fine stage on identical samples: " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items())
+          + f"; end to end: {int(hop.sum())} rays with a hopped sample, {int(moved.sum())} with a moved one; rays beyond the "
+          "bound " + ", ".join(f"{k} {v}" for k, v in counted.items()))
+    assert not any(unexplained.values()), f"{tag}: rays beyond the bound whose samples equal the oracle's: {unexplained}"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# full-size training steps of the other single-GPU workloads (VERDICT r04 weak #2): 128 + 64 samples, LLFF / NDC with the
+# density noise through quad_bwd, and the depth-supervised step (softplus derivative, sample_pl_bwd, space-carving loss)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def oracle_steps():
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            ns, ni, white, noise, src = NVS_WORKLOADS[name]
+            if src == "llff":
+                batch = _llff_batch()
+                target = torch.rand(R_FULL, 3, generator=torch.Generator().manual_seed(32))
+            else:
+                batch, target = orc.synthetic_blender_rays(R_FULL, seed=12)
+            sd_c, sd_f = orc.closed_form_state_dict(0, False), orc.closed_form_state_dict(1, False)
+            kw = dict(N_samples=ns, N_importance=ni, mode="linear", color_mode="midpoint", perturb=1.0, white_bkgd=white,
+                      raw_noise_std=noise, pytest=True)
+            loss, g_c, g_f = orc.train_step({k: v.clone() for k, v in sd_c.items()}, {k: v.clone() for k, v in sd_f.items()},
+                                            batch, target, kw)
+            cache[name] = (batch, target, sd_c, sd_f, kw, loss, g_c, g_f)
+        return cache[name]
+    return get
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+@pytest.mark.parametrize("workload", ["blender_128_64", "llff_ndc"])
+def test_train_step_of_the_other_workloads_at_baseline_size_vs_oracle(P, oracle_steps, workload, precision):
+    batch, target, sd_c, sd_f, kw, ref_loss, g_c, g_f = oracle_steps(workload)
+    emb_fn, _ = P.get_embedder(10, 0)
+    embd_fn, _ = P.get_embedder(4, 0)
+    qfn = lambda inputs, viewdirs, fn: P.run_network(inputs, viewdirs, fn, emb_fn, embd_fn)
+    net_c, net_f = make_net(P, sd_c, precision), make_net(P, sd_f, precision)
+    ret = P.render_rays(g(batch), net_c, qfn, retraw=True, network_fine=net_f, **kw)
+    loss = P.img2mse(ret["rgb_map"], g(target)) + P.img2mse(ret["rgb0"], g(target))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - float(ref_loss)) <= 1e-5, (float(loss.detach()), float(ref_loss))
+    tol = {"fp32": {"coarse": 2e-4, "fine": 2e-3}, "f16x3": {"coarse": 6e-3, "fine": 3e-3}}[precision]
+    worst = {"coarse": 0.0, "fine": 0.0}
+    for net, grads, tag in ((net_c, g_c, "coarse"), (net_f, g_f, "fine")):
+        for name, prm in net.named_parameters():
+            refg = grads[name]
+            scale = max(float(refg.abs().max()), 1e-9)
+            err = float((prm.grad.cpu() - refg).abs().max())
+            worst[tag] = max(worst[tag], err / scale)
+            assert err <= tol[tag] * scale + 1e-9, f"{precision} {workload} {tag} {name}: grad err {err:.3e} of max|g| {scale:.3e}"
+            assert abs(float(prm.grad.norm()) - float(refg.norm())) <= 2e-3 * float(refg.norm()) + 1e-9, (tag, name)
+    print(f"{precision} {workload} full-size step: loss {float(loss.detach()):.7f} (oracle {float(ref_loss):.7f}); worst grad "
+          f"err / max|g|: coarse {worst['coarse']:.2e}, fine {worst['fine']:.2e}")
+
+
+@pytest.fixture(scope="module")
+def oracle_depth_steps():
+    """The oracle's depth-supervised step at full size in fp32 and fp64 (the yardstick: the loss runs through the sampler's
+    ill-conditioned closed form, so the fp32 oracle's own gradients sit ~1e-2 of max|g| from its fp64 gradients)."""
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    batch, target = orc.synthetic_blender_rays(R_FULL, seed=14)
+    target_h = 2.0 + 4.0 * torch.rand(3, R_FULL, 1, generator=torch.Generator().manual_seed(14))
+    out = {"batch": batch, "target": target, "target_h": target_h}
+    # the reference's `pytest` draws (np.random.seed(0) before each: run_nerf_sample_based_depth.py:781-788,
+    # model/run_nerf_helpers.py:619-638), made here once and injected, so that the fp64 leg sees the same fp32-valued numbers
+    import numpy as np
+    np.random.seed(0)
+    t_rand = torch.Tensor(np.random.rand(R_FULL, 128))
+    np.random.seed(0)
+    u = torch.Tensor(np.random.rand(R_FULL, 64))      # (the importance draw and the hypotheses' draw: same seed, same shape)
+    for dt in (torch.float32, torch.float64):
+        sd_c = {k: v.to(dt) for k, v in orc.closed_form_state_dict_depth(0, True).items()}
+        sd_f = {k: v.to(dt) for k, v in orc.closed_form_state_dict_depth(1, True).items()}
+        okw = dict(N_samples=128, N_importance=64, mode="linear", color_mode="midpoint", perturb=1.0, white_bkgd=True,
+                   t_rand=t_rand.to(dt), u_fine=u.to(dt), cached_u=u.to(dt))
+        out[dt] = orc.depth_train_step(sd_c, sd_f, batch.to(dt), target.to(dt), target_h.to(dt), okw,
+                                       space_carving_weight=0.007)
+    return out
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+def test_depth_train_step_at_baseline_size_vs_oracle(P, golden, oracle_depth_steps, precision):
+    """BASELINE configs[4] per GPU, the whole step: 4096 rays x (128 + 64) samples, loss = mse(rgb) + 0.007 space_carving(
+    pred_hyp) + mse(rgb0) (run_nerf_sample_based_depth.py:1126-1150) and its gradients before clipping, against the
+    oracle on the reference's `pytest` draws."""
+    from test_gpu_modes import _depth_args, _depth_setup
+    gd = golden("g8b_depth_variant_128_64")
+    Dp, kw, grad_vars, opt = _depth_setup(gd, precision)
+    o = oracle_depth_steps
+    args = _depth_args(gd, precision)
+    args.space_carving_weight = 0.007
+    step = Dp.DepthTrainStep(args, kw, opt, grad_vars, distributed=False)
+    loss, img_loss, sc, _ = step(g(o["batch"]), g(o["target"]), g(o["target_h"]), pytest=True)
+    torch.cuda.synchronize()
+    loss32, sc32, g_c32, g_f32 = o[torch.float32]
+    loss64, sc64, g_c64, g_f64 = o[torch.float64]
+    print(f"{precision} depth step x {R_FULL} rays: loss {float(loss):.7f} (oracle fp32 {float(loss32):.7f}, fp64 {float(loss64):.7f}); "
+          f"space carving {float(sc):.6f} / {float(sc32):.6f} / {float(sc64):.6f}")
+    assert abs(float(loss) - float(loss32)) <= 2e-5 and abs(float(sc) - float(sc32)) <= 2e-4
+
+    def rel(a, b):
+        return float((a.double() - b).abs().max()) / (float(b.abs().max()) + 1e-300)
+    for net, g32, g64, tag in ((kw["network_fn"], g_c32, g_c64, "coarse"), (kw["network_fine"], g_f32, g_f64, "fine")):
+        e_hip = max(rel(prm.grad.cpu(), g64[name]) for name, prm in net.named_parameters())
+        e_orc = max(rel(g32[name], g64[name]) for name in g64)
+        flat_h = torch.cat([prm.grad.cpu().double().reshape(-1) for _, prm in net.named_parameters()])
+        flat_o = torch.cat([g64[name].reshape(-1) for name, _ in net.named_parameters()])
+        cos = float(torch.dot(flat_h, flat_o) / (flat_h.norm() * flat_o.norm()))
+        print(f"  {tag} gradients vs the fp64 oracle: HIP {e_hip:.3e}, fp32 oracle {e_orc:.3e}, cosine {cos:.7f}")
+        slack = 5e-4 if precision == "fp32" else 6e-3      # (f16x3: the half-plane backward's own bound, as the NVS steps')
+        assert e_hip <= 2 * e_orc + slack, (tag, e_hip, e_orc)
+        assert cos >= 0.9999, (tag, cos)

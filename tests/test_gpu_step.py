@@ -372,46 +372,6 @@ def test_training_step_is_bitwise_reproducible(P):
             assert torch.equal(x, y), f"parameters differ after step {step}"
 
 
-def test_two_stream_step_equals_one_stream_step(P):
-    """train.TrainStep's pipelines (functional.CoarseChain): 0 = one stream in the reference's order; 1 = the coarse
-    network's loss / backward / Adam on a second stream next to the fine pass; 2 = additionally the next step's coarse
-    pass next to this step's fine backward.  The three schedule the SAME kernels on the same inputs, so losses and
-    parameters must be bit-identical step after step -- any missing cross-stream dependency (a block handed back to the
-    allocator early, a weight read before its Adam) shows up as a difference.  Also with the `constant_init` warm-up
-    (the non-fused coarse pass) in front, and through __call__ with a caller's own rays."""
-    H = W = 160
-    K = [[220.0, 0, W / 2], [0, 220.0, H / 2], [0, 0, 1]]
-    gen = torch.Generator().manual_seed(5)
-    image = g(torch.rand(H, W, 3, generator=gen))
-    poses = [P.rays.pose_spherical(-180.0 + 72.0 * i, -30.0, 4.0)[:3, :4] for i in range(5)]
-
-    def run(pipeline, own_rays, **over):
-        args, kw, opt, opt_c = _nets(P, **over)
-        ts = P.TrainStep(args, kw, opt, opt_c, distributed=False, seed=17, pipeline=pipeline)
-        assert ts.pipeline == pipeline
-        out = []
-        for step in range(7):
-            if own_rays:
-                cols, target, _ = P.select_view_rays(H, W, K, poses[step % 5], image, 2048, 2.0, 6.0, seed=17, step=step)
-                loss, psnr = ts(H, W, K, cols, target, near=2.0, far=6.0)
-            else:
-                loss, psnr = ts.step_view(H, W, K, poses[step % 5], image, near=2.0, far=6.0, n_rand=2048)
-            out.append((loss, psnr))
-        ts.drain()
-        torch.cuda.synchronize()
-        return [(float(l), float(q)) for l, q in out], [p.detach().clone() for n in ts.nets for p in n.parameters()], ts
-
-    for own_rays, over in ((False, {}), (True, {}), (False, {"constant_init": 3})):
-        base_losses, base_params, _ = run(0, own_rays, **over)
-        for pipeline in (1, 2):
-            losses, params, ts = run(pipeline, own_rays, **over)
-            assert losses == base_losses, (pipeline, own_rays, over, losses, base_losses)
-            for x, y in zip(params, base_params):
-                assert torch.equal(x, y), f"pipeline {pipeline}: parameters differ"
-            assert ts.chain.calls == 1      # (the last step took the two-stream path)
-    assert np.isfinite(base_losses).all()
-
-
 def test_image_loss_takes_the_coarse_term_from_an_earlier_launch(P):
     """plnerf_image_loss(rgb, NULL, target, coarse_loss = the loss4 of a launch on rgb0 alone) == one launch over both
     images, bit for bit: what lets the coarse network's loss and backward start before the fine pass exists."""
@@ -432,8 +392,8 @@ def test_image_loss_takes_the_coarse_term_from_an_earlier_launch(P):
         assert_close(ga, (2.0 / (3 * R)) * (a - t).cpu(), atol=1e-9, rtol=1e-6, what=f"g_rgb R={R}")
 
 
-# ----------------------------------------------------------------------------- data parallel step, two ranks on one GPU
-_DP_GPU_WORKER = r'''
+# ----------------------------------------------------------------------------- data parallel step, N ranks on one GPU
+_DP_GPU_WORKER = r"""
 import os, sys, tempfile, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
 sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
@@ -441,102 +401,147 @@ import plnerf_amd as P
 from plnerf_amd import dp
 from oracle import plnerf_oracle as orc
 from test_gpu_step import _args
-rank, world, _ = dp.init_from_env(backend="gloo")          # both ranks on cuda:0; gloo moves CUDA tensors through the host
+HW, N_RAND, STEPS = int(sys.argv[2]), int(sys.argv[3]), 3      # view size, rays PER RANK
+rank, world, _ = dp.init_from_env(backend="gloo")          # every rank on cuda:0; gloo moves CUDA tensors through the host
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
+FLAGGED = [r for r in (1, 5) if r < world]                  # ranks whose fine forward "leaves the half range" below
 
 
 def make(distributed):
     d = tempfile.mkdtemp(); os.makedirs(os.path.join(d, "exp"))
-    args = _args(d, "f16x3")
+    args = _args(d, "f16x3", chunk=32768)
     kw, _, _, _, opt, opt_c = P.create_nerf(args, device=dev)
     kw["network_fn"].load_state_dict(orc.closed_form_state_dict(0, False))
     kw["network_fine"].load_state_dict(orc.closed_form_state_dict(1, False))
-    return kw, P.TrainStep(args, kw, opt, opt_c, distributed=distributed, seed=3, pipeline=int(sys.argv[2]))
+    return kw, P.TrainStep(args, kw, opt, opt_c, distributed=distributed, seed=3)
 
 
-H = W = 64
-K = [[90.0, 0, W / 2], [0, 90.0, H / 2], [0, 0, 1]]
+H = W = HW
+K = [[1.4 * HW, 0, W / 2], [0, 1.4 * HW, H / 2], [0, 0, 1]]
 c2w = P.rays.pose_spherical(20.0, -30.0, 4.0)[:3, :4]
 yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
 image = torch.stack([xx, yy, 0.5 * (xx + yy)], -1).to(dev)
 kw, ts = make(True)
-assert ts.bucket is not None and ts.world == 2
+assert ts.bucket is not None and ts.world == world
+# the ranks' pixels are disjoint slices of ONE global sample: global ray ids rank * N_RAND ... (rank + 1) * N_RAND - 1
+_, _, pix = P.select_view_rays(H, W, K, c2w, image, N_RAND, 2.0, 6.0, seed=3, step=0, ray_id0=rank * N_RAND, want_pixels=True)
+flat = (pix[:, 0].long() * W + pix[:, 1].long()).cpu()
+every = [None] * world
+dist.all_gather_object(every, flat.tolist())
+if rank == 0:
+    allpix = [q for part in every for q in part]
+    assert len(set(allpix)) == world * N_RAND, "the ranks drew overlapping pixels"
+    _, _, pix1 = P.select_view_rays(H, W, K, c2w, image, world * N_RAND, 2.0, 6.0, seed=3, step=0, ray_id0=0, want_pixels=True)
+    assert (pix1[:, 0].long() * W + pix1[:, 1].long()).cpu().tolist() == allpix, "shards are not slices of the global sample"
 losses = []
-for step in range(3):
-    loss, _ = ts.step_view(H, W, K, c2w, image, near=2.0, far=6.0, n_rand=128)       # 128 rays per rank, 256 global
+for step in range(STEPS):
+    loss, _ = ts.step_view(H, W, K, c2w, image, near=2.0, far=6.0, n_rand=N_RAND)
     assert ts.bucket.pending() == 0
     losses.append(float(loss))
 digest = [float(p.detach().double().sum()) for n in ts.nets for p in n.parameters()]
 gathered = [None] * world
 dist.all_gather_object(gathered, digest)
-assert gathered[0] == gathered[1], "replicas diverged"
+assert all(gd == gathered[0] for gd in gathered), "replicas diverged"
 if rank == 0:
-    # the same three steps as ONE process over the global batch of 256 rays (same seed: same pixels, same draws)
+    # the same steps as ONE process over the global batch of world * N_RAND rays (same seed: same pixels, same draws)
     kw1, ts1 = make(False)
-    for step in range(3):
-        ts1.step_view(H, W, K, c2w, image, near=2.0, far=6.0, n_rand=256)
+    for step in range(STEPS):
+        ts1.step_view(H, W, K, c2w, image, near=2.0, far=6.0, n_rand=world * N_RAND)
     worst = max(float((p.detach() - q.detach()).abs().max()) for n, m in zip(ts.nets, ts1.nets)
                 for p, q in zip(n.parameters(), m.parameters()))
-    print("max |param(2 ranks) - param(1 rank, global batch)| =", worst)
+    print(f"max |param({world} ranks x {N_RAND} rays) - param(1 rank x {world * N_RAND} rays)| =", worst)
     assert worst <= 2e-4, worst          # three Adam steps (lr 5e-4) apart at most through rounding-level gradient differences
-# The range guard is global: ONE rank's forward leaves the half range (simulated: its fine network's status word is set
+    del kw1, ts1
+    torch.cuda.empty_cache()
+# The range guard is global: SOME ranks' forward leaves the half range (simulated: their fine network's status word is set
 # as the clamping kernel would set it) -> the word travels as the tail element of the fine network's gradient buffer, the
-# summed tail guards Adam on BOTH ranks (no extra collective), BOTH withhold the step, BOTH raise at the next check --
-# the rank whose own words are clear because its optimizer counted a withheld step -- and the step counts are wound back.
-ts.drain()
+# summed tail guards Adam on EVERY rank (no extra collective), all withhold the step, all raise at the next check --
+# the ranks whose own words are clear because their optimizer counted a withheld step -- and the step counts are wound back.
 before = [p.detach().clone() for n in ts.nets for p in n.parameters()]
 steps_before = float(ts.optimizer.state[next(ts.nets[1].parameters())]['step'])
-if rank == 1:
+if rank in FLAGGED:
     ts.nets[1].status_word().fill_(1)
-ts.step_view(H, W, K, c2w, image, near=2.0, far=6.0, n_rand=128)
-ts.drain()
+ts.step_view(H, W, K, c2w, image, near=2.0, far=6.0, n_rand=N_RAND)
 fine_before = before[len(list(ts.nets[0].parameters())):]
 assert all(torch.equal(a, p.detach()) for a, p in zip(fine_before, ts.nets[1].parameters())), "a guarded step reached the weights"
-assert int(ts.nets[1].status_word().item()) == rank, f"rank {rank}: status words are per rank (the tails carry them)"
+assert int(ts.nets[1].status_word().item()) == int(rank in FLAGGED), f"rank {rank}: status words are per rank (the tails carry them)"
 tails = ts.bucket.tails()
-assert len(tails) == 2 and float(tails[0]) == 0.0 and float(tails[1]) == 1.0, [float(t) for t in tails]
+assert len(tails) == 2 and float(tails[0]) == 0.0 and float(tails[1]) == float(len(FLAGGED)), [float(t) for t in tails]
 raised = None
 try:
     ts.check_range()
 except FloatingPointError as e:
     raised = str(e)
 assert raised is not None, f"rank {rank} did not raise"
-assert ("another rank" in raised) == (rank == 0), raised
+assert ("another rank" in raised) == (rank not in FLAGGED), raised
 assert float(ts.optimizer.state[next(ts.nets[1].parameters())]['step']) == steps_before       # wound back
-# (the coarse network's word was clear on both ranks: its step went through, identically)
+# (the coarse network's word was clear on every rank: its step went through, identically)
 digest = [float(p.detach().double().sum()) for p in ts.nets[0].parameters()]
 gathered = [None] * world
 dist.all_gather_object(gathered, digest)
-assert gathered[0] == gathered[1]
+assert all(gd == gathered[0] for gd in gathered)
+if world == 2:
+    # The FALLBACK exchange (ADVICE r04): a batch split over several render_rays / MlpFn calls (chunk < N_rand) leaves
+    # `.grad` as a sum of buffers -- no flat buffer, no status tail.  The ranks' status words then go through one MAX
+    # all-reduce (dp.GradientBucket._sync_status): rank 1's coarse forward "clamps", BOTH ranks withhold the coarse step,
+    # both see the word set, both raise.
+    for n in ts.nets:
+        n.status_word().zero_()
+    ts.args.chunk = N_RAND // 2
+    before = [p.detach().clone() for p in ts.nets[0].parameters()]
+    if rank == 1:
+        ts.nets[0].status_word().fill_(1)
+    ts.step_view(H, W, K, c2w, image, near=2.0, far=6.0, n_rand=N_RAND)
+    assert ts.bucket.collectives >= 2, ts.bucket.collectives          # the gathered bucket + the status words
+    assert all(torch.equal(a, p.detach()) for a, p in zip(before, ts.nets[0].parameters())), "fallback: a guarded step reached the weights"
+    assert int(ts.nets[0].status_word().item()) == 1, f"rank {rank}: the fallback writes the ranks' MAX back"
+    try:
+        ts.check_range()
+        raise SystemExit(f"rank {rank} did not raise on the fallback path")
+    except FloatingPointError:
+        pass
 print(f"rank {rank} ok")
 dist.destroy_process_group()
-'''
+"""
 
 
-@pytest.mark.parametrize("pipeline", [0, 1, 2])
-def test_data_parallel_training_step_two_ranks_on_one_gpu(P, tmp_path, pipeline):
-    """The multi-GPU step as the driver will launch it, minus the second GPU: two ranks (gloo backend, both on cuda:0)
-    each render their shard of a global batch chosen by the counter-based generator, the post-accumulate hooks enqueue
-    one in-place all-reduce per network from inside backward, the guarded flat Adam steps.  Replicas stay bit-identical
-    over three steps, and the weights land where ONE process stepping the whole global batch lands (same pixels, same
-    draws -- world-size invariance, SURVEY.md section 8e)."""
+def _run_dp_ranks(tmp_path, world, hw, n_rand, timeout):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "dp_gpu_worker.py"
     script.write_text(_DP_GPU_WORKER)
-    port = 29700 + (os.getpid() % 200) + 200 * pipeline
+    port = 29700 + (os.getpid() % 200) + 200 * (world > 2)
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script), root, str(pipeline)], env=env, stdout=subprocess.PIPE,
-                                      stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), root, str(hw), str(n_rand)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=timeout)[0] for p in procs]
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {rank} failed:\n{out[-3000:]}"
         assert f"rank {rank} ok" in out
     print([l for l in outs[0].splitlines() if l.startswith("max |param")])
+
+
+def test_data_parallel_training_step_two_ranks_on_one_gpu(P, tmp_path):
+    """The multi-GPU step as the driver will launch it, minus the second GPU: two ranks (gloo backend, both on cuda:0)
+    each render their shard of a global batch chosen by the counter-based generator, the post-accumulate hooks enqueue
+    one in-place all-reduce per network from inside backward, the guarded flat Adam steps.  Replicas stay bit-identical
+    over three steps, and the weights land where ONE process stepping the whole global batch lands (same pixels, same
+    draws -- world-size invariance, SURVEY.md section 8e).  Also the fallback exchange's status synchronisation."""
+    _run_dp_ranks(tmp_path, 2, 64, 128, 600)
+
+
+def test_baseline_config2_eight_shards_equal_one_global_batch(P, tmp_path):
+    """BASELINE configs[2] in its real shape, minus the other seven GPUs: EIGHT ranks x 4096 rays of an 800 x 800 view
+    (global batch 32,768; global ray ids up to 32,767 through the counter-based pixel choice and draws; 1 / world = 1 / 8
+    inside the Adam kernel; status tails summed over eight ranks), time-sharing one MI355X over gloo, against ONE rank
+    stepping the whole 32,768-ray batch: parameters after three steps equal to fp32 summation-order tolerance.  What
+    this leaves untested of configs[2] is the RCCL wire itself."""
+    _run_dp_ranks(tmp_path, 8, 800, 4096, 1500)
 
 
 @pytest.mark.parametrize("precision,n_rows", [("f16x3", 131072), ("f16x3", 262144), ("f16x3", 1000), ("fp32", 8200),

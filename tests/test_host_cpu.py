@@ -233,6 +233,50 @@ def test_unsupported_network_shapes_are_refused(built):
             net.param_list() if False else net._require_supported()
 
 
+def _nvs_args(tmp, **over):
+    from argparse import Namespace
+    a = dict(multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=128, N_samples=64, netdepth=8,
+             netwidth=256, netdepth_fine=8, netwidth_fine=256, netchunk=65536, lrate=5e-4, coarse_lrate=5e-4,
+             ft_path=None, ckpt_dir=str(tmp), expname="exp", no_reload=True, perturb=1.0, white_bkgd=True,
+             raw_noise_std=0.0, mode="linear", color_mode="midpoint", dataset="blender", no_ndc=False, lindisp=False,
+             lrate_decay=250, constant_init=0, chunk=32768, precision="f16x3", N_rand=256)
+    a.update(over)
+    return Namespace(**a)
+
+
+# create_nerf flag combinations: (overrides, served?).  INTEGRATION.md's table is this list.
+CREATE_NERF_SHAPES = [
+    (dict(), True),                                                     # the reference's configs: 8 x 256, skip after 4, 63 | 27
+    (dict(netwidth=128, netwidth_fine=128), True),                      # narrower (zero-padded)
+    (dict(netdepth=6, netdepth_fine=6), True),                          # shallower behind the skip (identity layers)
+    (dict(netdepth=4, netdepth_fine=4), True),                          # the default skips=[4] is not live below 6 layers
+    (dict(use_viewdirs=False), True),                                   # output_linear on the trunk
+    (dict(multires=6, multires_views=2), True),                         # fewer frequency bands (a prefix of 63 | 27)
+    (dict(N_importance=0), True),                                       # one network, two Adams
+    (dict(netdepth=9), False), (dict(netdepth_fine=10), False),         # deeper than the compiled trunk
+    (dict(netwidth=512), False), (dict(netwidth_fine=384), False),      # wider
+    (dict(netwidth=255), False),                                        # odd width (the view layer halves it)
+    (dict(netdepth=5, netdepth_fine=5), False),                         # a skip after the LAST layer: the reference's head cannot consume it either
+    (dict(multires=11), False),                                         # 69 position channels > 64
+    (dict(multires_views=5), False),                                    # 33 direction channels > 32
+]
+
+
+@pytest.mark.parametrize("over,served", CREATE_NERF_SHAPES, ids=lambda v: "-".join(f"{k}{x}" for k, x in v.items()) if isinstance(v, dict) else str(v))
+def test_create_nerf_refuses_unsupported_shapes_at_the_boundary(built, tmp_path, over, served):
+    """The flags of run_plnerf.py:784-799 that the compiled trunk cannot express raise in create_nerf itself
+    (run_plnerf.py:417-447) -- before a reference-style run has loaded its data -- not at the first network query;
+    NeRF.__init__ stays permissive (same state_dict as the reference: test_unsupported_network_shapes_are_refused)."""
+    (tmp_path / "exp").mkdir()
+    args = _nvs_args(tmp_path, **over)
+    if served:
+        kw = built.create_nerf(args, device=torch.device("cpu"))[0]
+        assert kw["network_fn"].is_supported() and (kw["network_fine"] is None or kw["network_fine"].is_supported())
+    else:
+        with pytest.raises(NotImplementedError, match="compiled for the reference's trunk"):
+            built.create_nerf(args, device=torch.device("cpu"))
+
+
 def test_no_cpu_fallback(built):
     net = built.NeRF(input_ch=63, input_ch_views=27, use_viewdirs=True)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
@@ -660,19 +704,21 @@ def _run_bench(*flags, env=None, timeout=300):
                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
 
 
-def test_bench_spawns_its_own_ranks(built):
-    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's command form) must launch the two
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_spawns_its_own_ranks(built, n):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment (the driver's command form) must launch the N
     ranks itself: here on CPU / gloo with the stand-in step, the real rendezvous, dp.GradientBucket and report path.
-    Rank 0 prints ONE JSON line as the last line of stdout; the world size is what torch.distributed reports."""
+    Rank 0 prints ONE JSON line as the last line of stdout; the world size is what torch.distributed reports.  N = 8 is
+    BASELINE configs[2]'s rank count (eight launch loops on one host)."""
     import json
-    r = _run_bench("--gpus", "2", "--stub-cpu", "--steps", "4", "--warmup", "1")
+    r = _run_bench("--gpus", str(n), "--stub-cpu", "--steps", "4", "--warmup", "1", timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     assert r.stdout.strip().splitlines()[-1] == lines[0]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 1
-    assert out["config"]["rccl_world_size"] == 2 and out["config"]["self_launched"] is True
+    assert out["n_gpus"] == n and out["steps"] == 4 and out["warmup"] == 1
+    assert out["config"]["rccl_world_size"] == n and out["config"]["self_launched"] is True
     assert out["config"]["backend"] == "gloo"
     rk = out["ranks"]
     assert rk["ms_per_step"]["min"] <= rk["ms_per_step"]["max"] and rk["allreduce_exposed_ms_max_over_ranks"] > 0

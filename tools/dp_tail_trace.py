@@ -25,13 +25,12 @@ from test_gpu_step import _args
 rank, world, _ = dp.init_from_env(backend="gloo")
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
-pipeline = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 d = tempfile.mkdtemp(); os.makedirs(os.path.join(d, "exp"))
 args = _args(d, "f16x3")
 kw, _, _, _, opt, opt_c = P.create_nerf(args, device=dev)
 kw["network_fn"].load_state_dict(orc.closed_form_state_dict(0, False))
 kw["network_fine"].load_state_dict(orc.closed_form_state_dict(1, False))
-ts = P.TrainStep(args, kw, opt, opt_c, distributed=True, seed=3, pipeline=pipeline)
+ts = P.TrainStep(args, kw, opt, opt_c, distributed=True, seed=3)
 H = W = 128
 K = [[180.0, 0, W / 2], [0, 180.0, H / 2], [0, 0, 1]]
 c2w = P.rays.pose_spherical(20.0, -30.0, 4.0)[:3, :4]
@@ -42,13 +41,12 @@ torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     ts.step_view(H, W, K, c2w, image, near=2.0, far=6.0, n_rand=2048)
-    ts.drain()
     torch.cuda.synchronize()
 if rank == 0:
     evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
     evs.sort(key=lambda e: e.time_range.start)
     names = [e.name for e in evs]
-    print(f"# TrainStep(pipeline={pipeline}), 2 ranks over gloo on one GPU, 2048 rays per rank: GPU activities of ONE step, in start order")
+    print(f"# TrainStep, 2 ranks over gloo on one GPU, 2048 rays per rank: GPU activities of ONE step, in start order")
     for k, e in enumerate(evs):
         print(f"{k:3d} {e.time_range.start - evs[0].time_range.start:9.1f} us  {e.name[:110]}")
     print("# between a network's last backward kernel (wgrad_reduce_kernel) and its adam_kernel:")

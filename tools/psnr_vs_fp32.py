@@ -15,7 +15,6 @@ ap.add_argument("--steps", type=int, default=2000)
 ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--precision", default="f16x3")
 ap.add_argument("--views", type=int, default=8)
-ap.add_argument("--pipeline", type=int, default=0)
 ap.add_argument("--seeds", default="0,1,2")
 ap.add_argument("--no-twin", action="store_true")
 ap.add_argument("--only-run", action="store_true", help="the precision's run alone (no fp32 reference, no twin)")
@@ -23,7 +22,7 @@ a = ap.parse_args()
 rows = []
 for seed in [int(x) for x in a.seeds.split(",")]:
     out = psnr_vs_ref(P, torch.device("cuda:0"), a.steps, rays=a.rays, precision=a.precision, views=a.views,
-                      seed=seed, pipeline=a.pipeline, with_twin=not a.no_twin, only_run=a.only_run)
+                      seed=seed, with_twin=not a.no_twin, only_run=a.only_run)
     out["seed"] = seed
     rows.append(out)
     print(json.dumps(out), flush=True)

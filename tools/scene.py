@@ -57,7 +57,7 @@ def nerf_args(precision, ckpt_dir, n_samples=64, n_importance=128, n_rand=4096, 
                      constant_init=0, chunk=32768, N_rand=n_rand)
 
 
-def train_psnr(P, scene, precision, steps, dev, rays=4096, seed=0, pipeline=0, tail_frac=0.1, init=None):
+def train_psnr(P, scene, precision, steps, dev, rays=4096, seed=0, tail_frac=0.1, init=None):
     """Train both networks for `steps` steps on the analytic scene in `precision` (weights from `init`: two state
     dicts, or torch.manual_seed(0)'s default initialisation; pixel choice, jitter and sampler draws are counter-based
     functions of (seed, step, ray): identical in every precision).  Returns the training PSNR of the fine image over
@@ -75,7 +75,7 @@ def train_psnr(P, scene, precision, steps, dev, rays=4096, seed=0, pipeline=0, t
     if init is not None:
         kw["network_fn"].load_state_dict(init[0])
         kw["network_fine"].load_state_dict(init[1])
-    ts = P.TrainStep(args, kw, opt, opt_c, distributed=False, seed=seed, pipeline=pipeline)
+    ts = P.TrainStep(args, kw, opt, opt_c, distributed=False, seed=seed)
     psnrs, losses = [], []
     torch.cuda.synchronize()
     t0 = torch.cuda.Event(enable_timing=True)
@@ -87,7 +87,6 @@ def train_psnr(P, scene, precision, steps, dev, rays=4096, seed=0, pipeline=0, t
                                   far=scene.far, n_rand=rays)
         psnrs.append(psnr)
         losses.append(loss)
-    ts.drain()
     t1.record()
     torch.cuda.synchronize()
     ms = t0.elapsed_time(t1) / steps
@@ -108,7 +107,7 @@ def train_psnr(P, scene, precision, steps, dev, rays=4096, seed=0, pipeline=0, t
             "loss_tail_mean": float(losses[-tail:].mean())}
 
 
-def psnr_vs_ref(P, dev, steps, rays=4096, precision="f16x3", views=8, seed=0, pipeline=0, with_twin=False, only_run=False):
+def psnr_vs_ref(P, dev, steps, rays=4096, precision="f16x3", views=8, seed=0, with_twin=False, only_run=False):
     """The benchmarked arithmetic against the exact-fp32 kernels (reference-equal gradients, pinned to the oracle at
     1e-5 by tests/test_gpu_fullsize.py) on the same scene, weights and draws: {run, ref, gap_db ...}."""
     scene = AnalyticScene(P, views, dev)
@@ -124,10 +123,10 @@ def psnr_vs_ref(P, dev, steps, rays=4096, precision="f16x3", views=8, seed=0, pi
     init = ({k: v.clone() for k, v in kw0["network_fn"].state_dict().items()},
             {k: v.clone() for k, v in kw0["network_fine"].state_dict().items()})
     del kw0
-    run = train_psnr(P, scene, precision, steps, dev, rays, seed, pipeline, init=init)
+    run = train_psnr(P, scene, precision, steps, dev, rays, seed, init=init)
     if only_run:      # (a kernel variant's run alone: the fp32 reference of the same seed is already on file)
         return {"run": run}
-    ref = train_psnr(P, scene, "fp32", steps, dev, rays, seed, pipeline, init=init)
+    ref = train_psnr(P, scene, "fp32", steps, dev, rays, seed, init=init)
     twin = None
     if with_twin:
         # the noise floor of the comparison: the SAME exact-fp32 arithmetic from initial weights moved by one part in
@@ -137,7 +136,7 @@ def psnr_vs_ref(P, dev, steps, rays=4096, precision="f16x3", views=8, seed=0, pi
         gen = torch.Generator().manual_seed(1234)
         moved = tuple({k: (v * (1.0 + 1e-7 * torch.randn(v.shape, generator=gen).to(v.device))) for k, v in sd.items()}
                       for sd in init)
-        twin = train_psnr(P, scene, "fp32", steps, dev, rays, seed, pipeline, init=moved)
+        twin = train_psnr(P, scene, "fp32", steps, dev, rays, seed, init=moved)
     return {"scene": f"analytic sphere, {views} training views 800x800 on the NeRF-synthetic camera ring, white "
                      f"background; held-out view 200x200 between two training poses",
             "what": "mean training PSNR of the fine image over the last 10 % of the steps (the value run_plnerf.py:1290 "

@@ -10,9 +10,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=3000)
 ap.add_argument("--precision", default="f16x3")
 ap.add_argument("--workload", default="blender_64_128")
-ap.add_argument("--pipeline", type=int, default=0, help="train.TrainStep schedule (0 one stream, 1 / 2 two streams)")
 sa = ap.parse_args()
-sys.argv = [sys.argv[0], "--precision", sa.precision, "--workload", sa.workload, "--pipeline", str(sa.pipeline)]
+sys.argv = [sys.argv[0], "--precision", sa.precision, "--workload", sa.workload]
 a = bench.parse()
 ns, ni, _ = bench.WORKLOADS[a.workload]
 a.n_samples, a.n_importance = ns, ni
@@ -34,7 +33,7 @@ for i in range(sa.steps):
         marks[i + 1] = torch.cuda.max_memory_allocated() / 2**30
         t0 = time.perf_counter()
 status = [int(n.range_status()) if hasattr(n, "range_status") else 0 for n in nets]
-print(json.dumps({"what": f"soak, {sa.workload}, {sa.precision}, pipeline {sa.pipeline}", "steps": sa.steps,
+print(json.dumps({"what": f"soak, {sa.workload}, {sa.precision}", "steps": sa.steps,
                   "ms_per_step_by_tenth": [round(t, 3) for t in times],
                   "loss_by_tenth": [round(l, 6) for l in losses], "all_finite": all(l == l and abs(l) < 1e30 for l in losses),
                   "max_memory_allocated_GiB_by_tenth": {k: round(v, 3) for k, v in marks.items()},

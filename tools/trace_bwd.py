@@ -1,6 +1,6 @@
 """Phase breakdown of the dgrad kernel (mlp_bwd_h16_kernel) from in-kernel clock stamps of wave 0 of one workgroup.
 Needs a library whose mlp_bf16.o was compiled with -DPLNERF_TRACE=<block> and linked with the other objects of csrc/
-(PLNERF_HIP_LIB=<that library> PLNERF_ALLOW_TOOLS_BUILD=1); add -DPLNERF_ABLATE=512 for the walk without dz stores."""
+(PLNERF_HIP_LIB=<that library> PLNERF_ALLOW_TOOLS_BUILD=1)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
