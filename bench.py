@@ -576,7 +576,9 @@ def main(argv=None):
     elif rank == 0:
         ms = 1e3 * dt / a.steps
         fwd_ms = timer.mean_ms(f"mlp_fwd[{rows_fine}]")
-        bwd_ms = timer.mean_ms(f"mlp_bwd[{rows_fine}]")
+        bwd_ms = timer.mean_ms(f"mlp_bwd[{rows_fine}]")      # (autograd order: the fine network's backward on its own)
+        rows_coarse = R * a.n_samples
+        bwd_both_ms = timer.mean_ms(f"mlp_bwd[{rows_coarse}+{rows_fine}]")      # (merged: both networks, one launch sequence)
         peak = PEAK_TFLOPS[a.precision]
         traffic, traffic_source = None, None
         fwd_kernel = FWD_KERNEL[a.precision]
@@ -609,6 +611,7 @@ def main(argv=None):
                        "rccl_world_size": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
                        "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
                        "self_launched": bool(os.environ.get("PLNERF_BENCH_SELF_LAUNCHED")),
+                       "merged_backward": os.environ.get("PLNERF_MERGED_BWD", "1") != "0" and a.workload != "depth_128_64",
                        "final_loss": final_loss},
             # the K timed steps one by one (rank 0's launch stream, one HIP event per step boundary), and the ranks'
             # own wall-clock times for the K steps: the spread is what diagnoses a slow rank / an exposed collective
@@ -630,6 +633,7 @@ def main(argv=None):
                 "hbm_view": {"bytes_per_row": bytes_per_row, "achieved_gbs": ach_gbs, "peak_gbs": HBM_PEAK_GBS,
                              "frac": (ach_gbs / HBM_PEAK_GBS) if ach_gbs else None},
                 "mlp_bwd_launch_ms": bwd_ms,
+                "mlp_bwd_both_networks_ms": bwd_both_ms,
                 "train_mlp_tflops": (rows_fine * TRAIN_FLOP_PER_ROW / ((fwd_ms + bwd_ms) * 1e-3) / 1e12)
                 if (fwd_ms and bwd_ms) else None,
                 "step_tflops": (R * (2 * a.n_samples + a.n_importance) * TRAIN_FLOP_PER_ROW / (ms * 1e-3) / 1e12),

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PLNERF_VERSION 402 /* major*10000 + minor*100 + patch */
+#define PLNERF_VERSION 500 /* major*10000 + minor*100 + patch */
 
 /* error codes */
 #define PLNERF_OK 0
@@ -107,12 +107,19 @@ int plnerf_quad_fwd(const float* raw, const float* z, const float* near, const f
  * callers that differentiate through the sampler
  * (depth_supervised_exps/run_nerf_sample_based_depth.py:923-934) -- g_tau, g_T [R,S+2]
  * (each may be NULL = zero).  disp_map's gradient is folded into g_depth/g_acc by the
- * caller.  g_raw [R,S,4]. */
+ * caller.  g_raw [R,S,4].
+ * absmax_out (may be NULL; ABI 500): max |g_raw| of this launch as a by-product, for the consumer that scales by it
+ * (plnerf_mlp_bwd's g_absmax: the half dz planes' launch scale) -- one device uint64 that the kernel raises with
+ * atomicMax to (absmax_tag << 32 | fp32 bits of the maximum).  The caller passes a tag larger than any it used on this
+ * word before (a step counter): the word then needs no zeroing between launches, and its LOW 32 bits -- what
+ * (const uint32_t*)absmax_out points at on this little-endian target -- are the maximum once the launch has finished
+ * (0 if every element is zero; a NaN gives 0x7fc00000-class bits, which order above every finite value). */
 int plnerf_quad_bwd(const float* raw, const float* z, const float* near, const float* far,
                     const float* rays_d, const float* noise, int R, int S, int mode,
                     int color_mode, int white_bkgd, int farcolorfix, const float* g_rgb,
                     const float* g_depth, const float* g_acc, const float* g_weights,
-                    const float* g_tau, const float* g_T, float* g_raw, plnerf_stream_t stream);
+                    const float* g_tau, const float* g_T, float* g_raw, uint64_t* absmax_out,
+                    uint32_t absmax_tag, plnerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Hierarchical samplers.  `u` holds the uniform draws: [R,N] when u_row_stride == N, or
@@ -371,11 +378,29 @@ int plnerf_mlp_fwd(const void* packed, int precision, const float* pts, const fl
  * g_raw itself is not written).  status_out (may be NULL): one float, set to 1 if the network's range status word
  * (plnerf_mlp_status_offset) is non-zero when the gradients are complete, else 0 -- a data-parallel caller puts it
  * behind the gradients in the buffer it all-reduces (SUM), so "some rank's forward left the half range" reaches
- * every rank with the gradient itself and can guard plnerf_adam_step there. */
-int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, int input_ch,
+ * every rank with the gradient itself and can guard plnerf_adam_step there.
+ * g_absmax (may be NULL; ABI 500; 16-bit modes without a density activation): one device uint32 that already holds
+ * max |g_raw| as fp32 bits (plnerf_quad_bwd's absmax_out) -- the call then skips its own pass over g_raw. */
+int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, const uint32_t* g_absmax, int input_ch,
                    int input_ch_views, int n_rows, const void* saved, int saved_layout,
                    const float* raw_out, float density_beta, void* workspace,
                    float* const* grads, float* status_out, plnerf_stream_t stream);
+
+/* The backward of SEVERAL networks that share precision, input widths and density activation -- the coarse and the fine
+ * network of one optimisation step, whose upstream gradients both exist before either backward starts (the samples are
+ * detached, run_plnerf.py:728; the loss is a sum of two image terms, :1287-1296) -- as ONE launch sequence: one
+ * gradient-chain grid and one launch of each weight-gradient kernel cover every job (16-bit modes; the exact-fp32 mode
+ * runs the jobs one after the other).  Separate calls end each kernel on a partial round of the 256 CUs and pay every
+ * launch ramp twice: 0.14-0.16 ms of a 6.4 ms step (profiles/r05_merged_bwd_bound.txt).  Every array has n_jobs entries
+ * (host memory, read during the call) and means what the argument of the same name means to plnerf_mlp_bwd; grads holds
+ * n_jobs x 24 device pointers, job after job; g_absmax, raw_out and status_out may be NULL as a whole or per entry.
+ * plnerf_mlp_bwd(...) is plnerf_mlp_bwd_multi(1, ...), bit for bit. */
+#define PLNERF_MAX_BWD_JOBS 2
+int plnerf_mlp_bwd_multi(int n_jobs, const void* const* packed, int precision, const float* const* g_raw,
+                         const uint32_t* const* g_absmax, int input_ch, int input_ch_views, const int* n_rows,
+                         const void* const* saved, const int* saved_layout, const float* const* raw_out,
+                         float density_beta, void* const* workspace, float* const* grads,
+                         float* const* status_out, plnerf_stream_t stream);
 
 /* Gradient of the same backward with respect to the network's INPUT rows (what autograd gives the reference when the
  * rows handed to NeRF.forward, run_nerf_helpers.py:105-128, require a gradient -- no reference training path does,

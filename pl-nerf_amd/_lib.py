@@ -37,7 +37,7 @@ SIGNATURES = {
     "plnerf_build_flags": (c_i, []),
     "plnerf_error_string": (ctypes.c_char_p, [c_i]),
     "plnerf_quad_fwd": (c_i, [c_f] * 6 + [c_i] * 6 + [c_f] * 7 + [c_s]),
-    "plnerf_quad_bwd": (c_i, [c_f] * 6 + [c_i] * 6 + [c_f] * 7 + [c_s]),
+    "plnerf_quad_bwd": (c_i, [c_f] * 6 + [c_i] * 6 + [c_f] * 7 + [c_f, ctypes.c_uint32, c_s]),
     "plnerf_sample_const": (c_i, [c_f] * 3 + [c_i] * 4 + [c_f] * 2 + [c_s]),
     "plnerf_sample_const_bwd": (c_i, [c_f] * 3 + [c_i] + [c_f] * 2 + [c_i] * 3 + [c_f] + [c_s]),
     "plnerf_sample_pl": (c_i, [c_f] * 7 + [c_i] * 4 + [ctypes.c_float] * 2 + [c_f] * 5 + [c_s]),
@@ -66,8 +66,13 @@ SIGNATURES = {
     "plnerf_mlp_saved_bytes": (ctypes.c_size_t, [c_i, c_i]),
     "plnerf_mlp_bwd_workspace_bytes": (ctypes.c_size_t, [c_i, c_i]),
     "plnerf_mlp_fwd": (c_i, [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_float, ctypes.c_float, c_f, c_f, c_i, c_s]),
-    "plnerf_mlp_bwd": (c_i, [c_f, c_i, c_f, c_i, c_i, c_i, c_f, c_i, c_f, ctypes.c_float, c_f, ctypes.POINTER(ctypes.c_void_p), c_f,
-                             c_s]),
+    "plnerf_mlp_bwd": (c_i, [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_f, c_i, c_f, ctypes.c_float, c_f, ctypes.POINTER(ctypes.c_void_p),
+                             c_f, c_s]),
+    "plnerf_mlp_bwd_multi": (c_i, [c_i, ctypes.POINTER(ctypes.c_void_p), c_i, ctypes.POINTER(ctypes.c_void_p),
+                                   ctypes.POINTER(ctypes.c_void_p), c_i, c_i, ctypes.POINTER(ctypes.c_int),
+                                   ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int),
+                                   ctypes.POINTER(ctypes.c_void_p), ctypes.c_float, ctypes.POINTER(ctypes.c_void_p),
+                                   ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_s]),
     "plnerf_mlp_saved_layout": (c_i, [c_i, c_i, c_i]),
     "plnerf_adam_step": (c_i, [c_f, c_f, c_f, c_f, ctypes.c_int64] + [ctypes.c_float] * 4 + [c_i, ctypes.c_float, ctypes.c_float,
                                 c_f, c_f, c_f, c_s]),

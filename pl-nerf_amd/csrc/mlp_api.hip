@@ -129,52 +129,86 @@ extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pt
                           status_word(const_cast<void*>(packed), precision), (hipStream_t)stream);
 }
 
-extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, int input_ch,
+// The backward of up to PLNERF_MAX_BWD_JOBS networks that share precision, input widths and density activation (the
+// coarse and the fine network of one training step) in ONE launch sequence: one dgrad grid and one main / thin / head /
+// reduce launch of the weight-gradient stage cover every job (16-bit modes; the exact-fp32 mode runs the jobs one after
+// the other).  plnerf_mlp_bwd is the one-job case.
+extern "C" int plnerf_mlp_bwd_multi(int n_jobs, const void* const* packed, int precision, const float* const* g_raw,
+                                    const uint32_t* const* g_absmax, int input_ch, int input_ch_views,
+                                    const int* n_rows, const void* const* saved, const int* saved_layout,
+                                    const float* const* raw_out, float density_beta, void* const* workspace,
+                                    float* const* grads, float* const* status_out, plnerf_stream_t stream) {
+    if (n_jobs < 1 || n_jobs > PLNERF_MAX_BWD_JOBS) return PLNERF_EINVAL;
+    if (!known(precision)) return PLNERF_ENOSYS;
+    if (!packed || !g_raw || !n_rows || !saved || !saved_layout || !workspace || !grads) return PLNERF_EINVAL;
+    if (!geometry_ok(input_ch, input_ch_views)) return PLNERF_EINVAL;
+    if (!(density_beta >= 0.0f) || !(density_beta < 1e6f)) return PLNERF_EINVAL;
+    const bool act = density_beta > 0.0f;
+    for (int j = 0; j < n_jobs; ++j) {
+        if (saved_layout[j] != lay::SV_LAYOUT_ROWS && saved_layout[j] != lay::SV_LAYOUT_TILED) return PLNERF_EINVAL;
+        if (saved_layout[j] == lay::SV_LAYOUT_TILED && !ns_of(precision)) return PLNERF_EINVAL;
+        if (!packed[j] || !g_raw[j] || !saved[j] || !workspace[j] || n_rows[j] < 1) return PLNERF_EINVAL;
+        if (act && (!raw_out || !raw_out[j])) return PLNERF_EINVAL;
+        for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i)
+            if (!grads[j * PLNERF_N_PARAM_TENSORS + i]) return PLNERF_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t part_bytes = ((size_t)lay::MAX_SPLITS * lay::PART_PER_SPLIT + (size_t)lay::MAX_HEAD_WGS * lay::HEAD_PART) * sizeof(float);
+    if (precision == PLNERF_PREC_FP32) {
+        for (int j = 0; j < n_jobs; ++j) {
+            float* dz = (float*)workspace[j];
+            float* partials = dz + (size_t)lay::DZ_PER_ROW * (size_t)n_rows[j];
+            const float* g = g_raw[j];
+            if (act) {      // the activation's derivative first: every kernel below reads the effective gradient
+                float* g_eff = (float*)((unsigned char*)partials + part_bytes);
+                const int rc0 = impl::absmax_act(g, raw_out[j], density_beta, n_rows[j], g_eff, nullptr, st);
+                if (rc0) return rc0;
+                g = g_eff;
+            }
+            int rc = impl::f32_dgrad(packed[j], g, n_rows[j], (const float*)saved[j], dz, st);
+            if (rc) return rc;
+            rc = impl::wgrad(g, n_rows[j], saved[j], dz, nullptr, partials, grads + j * PLNERF_N_PARAM_TENSORS, input_ch,
+                             input_ch_views, false, lay::SV_LAYOUT_ROWS, nullptr, status_out ? status_out[j] : nullptr, st);
+            if (rc) return rc;
+        }
+        return PLNERF_OK;
+    }
+    // 16-bit modes: [dz half planes][max |g_raw|][partials][g_eff]
+    impl::DgradJob dj[PLNERF_MAX_BWD_JOBS];
+    impl::WgradJob wj[PLNERF_MAX_BWD_JOBS];
+    for (int j = 0; j < n_jobs; ++j) {
+        unsigned char* ws = (unsigned char*)workspace[j];
+        const unsigned* gmax = (unsigned*)(ws + impl::h16_dz_bytes(n_rows[j]));
+        float* partials = (float*)(ws + impl::h16_dz_bytes(n_rows[j]) + lay::WSH_SCALARS_BYTES);
+        const float* g = g_raw[j];
+        int rc = PLNERF_OK;
+        if (act) {      // one pass: the activation's derivative and the launch scale's maximum
+            float* g_eff = (float*)((unsigned char*)partials + part_bytes);
+            rc = impl::absmax_act(g, raw_out[j], density_beta, n_rows[j], g_eff, const_cast<unsigned*>(gmax), st);
+            g = g_eff;
+        } else if (g_absmax && g_absmax[j]) {
+            gmax = g_absmax[j];      // the caller's producer kernel left it (plnerf_quad_bwd's absmax_out): no pass, no memset
+        } else {
+            rc = impl::absmax(g, (size_t)n_rows[j] * 4, const_cast<unsigned*>(gmax), st);
+        }
+        if (rc) return rc;
+        dj[j] = impl::DgradJob{packed[j], ns_of(precision), g, n_rows[j], saved[j], ws, gmax};
+        wj[j] = impl::WgradJob{g, n_rows[j], saved[j], ws, gmax, partials, grads + j * PLNERF_N_PARAM_TENSORS, input_ch,
+                               input_ch_views, saved_layout[j], status_word(const_cast<void*>(packed[j]), precision),
+                               status_out ? status_out[j] : nullptr};
+    }
+    const int rc = impl::bf16_dgrad(n_jobs, dj, st);
+    if (rc) return rc;
+    return impl::wgrad_h16_multi(n_jobs, wj, st);
+}
+
+extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, const uint32_t* g_absmax, int input_ch,
                               int input_ch_views, int n_rows, const void* saved, int saved_layout,
                               const float* raw_out, float density_beta, void* workspace,
                               float* const* grads, float* status_out, plnerf_stream_t stream) {
-    if (saved_layout != lay::SV_LAYOUT_ROWS && saved_layout != lay::SV_LAYOUT_TILED) return PLNERF_EINVAL;
-    if (saved_layout == lay::SV_LAYOUT_TILED && !ns_of(precision)) return PLNERF_EINVAL;
-    if (!known(precision)) return PLNERF_ENOSYS;
-    if (!packed || !g_raw || !saved || !workspace || !grads || n_rows < 1) return PLNERF_EINVAL;
-    if (!geometry_ok(input_ch, input_ch_views)) return PLNERF_EINVAL;
-    if (!(density_beta >= 0.0f) || !(density_beta < 1e6f) || (density_beta > 0.0f && !raw_out)) return PLNERF_EINVAL;
-    for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i)
-        if (!grads[i]) return PLNERF_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    const bool act = density_beta > 0.0f;
-    const size_t part_bytes = ((size_t)lay::MAX_SPLITS * lay::PART_PER_SPLIT + (size_t)lay::MAX_HEAD_WGS * lay::HEAD_PART) * sizeof(float);
-    if (precision == PLNERF_PREC_FP32) {
-        float* dz = (float*)workspace;
-        float* partials = dz + (size_t)lay::DZ_PER_ROW * (size_t)n_rows;
-        if (act) {      // the activation's derivative first: every kernel below reads the effective gradient
-            float* g_eff = (float*)((unsigned char*)partials + part_bytes);
-            const int rc0 = impl::absmax_act(g_raw, raw_out, density_beta, n_rows, g_eff, nullptr, st);
-            if (rc0) return rc0;
-            g_raw = g_eff;
-        }
-        const int rc = impl::f32_dgrad(packed, g_raw, n_rows, (const float*)saved, dz, st);
-        if (rc) return rc;
-        return impl::wgrad(g_raw, n_rows, saved, dz, nullptr, partials, grads,
-                           input_ch, input_ch_views, false, lay::SV_LAYOUT_ROWS, nullptr, status_out, st);
-    }
-    // 16-bit modes: [dz half planes][max |g_raw|][partials]
-    unsigned char* ws = (unsigned char*)workspace;
-    unsigned* gmax = (unsigned*)(ws + impl::h16_dz_bytes(n_rows));
-    float* partials = (float*)(ws + impl::h16_dz_bytes(n_rows) + lay::WSH_SCALARS_BYTES);
-    int rc;
-    if (act) {      // one pass: the activation's derivative and the launch scale's maximum
-        float* g_eff = (float*)((unsigned char*)partials + part_bytes);
-        rc = impl::absmax_act(g_raw, raw_out, density_beta, n_rows, g_eff, gmax, st);
-        g_raw = g_eff;
-    } else {
-        rc = impl::absmax(g_raw, (size_t)n_rows * 4, gmax, st);
-    }
-    if (rc) return rc;
-    rc = impl::bf16_dgrad(packed, ns_of(precision), g_raw, n_rows, saved, ws, gmax, st);
-    if (rc) return rc;
-    return impl::wgrad(g_raw, n_rows, saved, ws, gmax, partials, grads, input_ch, input_ch_views, true, saved_layout,
-                       status_word(const_cast<void*>(packed), precision), status_out, st);
+    if (!grads) return PLNERF_EINVAL;
+    return plnerf_mlp_bwd_multi(1, &packed, precision, &g_raw, &g_absmax, input_ch, input_ch_views, &n_rows, &saved,
+                                &saved_layout, &raw_out, density_beta, &workspace, grads, &status_out, stream);
 }
 
 extern "C" int plnerf_mlp_input_grad(const float* const* params, int precision, int input_ch, int input_ch_views,

@@ -75,9 +75,9 @@ int bf16_fwd(const void* packed, int ns, int f16, const float* pts, const float*
                                           opt, raw_out, saved, status, st);      // (bf16 elements: PLNERF_RANGE_SAVED only)
 }
 
-int bf16_dgrad(const void* packed, int ns, const float* g_raw, int n_rows, const void* saved, void* dz,
-               const unsigned* gmax, hipStream_t st) {
-    return plnerf_h16_f16::h16_dgrad(packed, ns, g_raw, n_rows, saved, dz, gmax, st);
+int bf16_dgrad(int n, const DgradJob* jobs, hipStream_t st) {
+    if (n < 1 || n > MAX_BWD_JOBS) return PLNERF_EINVAL;
+    return plnerf_h16_f16::h16_dgrad(n, jobs, st);
 }
 
 }  // namespace impl

@@ -28,6 +28,33 @@ int f32_dgrad(const void* packed, const float* g_raw, int n_rows, const float* s
 int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dz, const unsigned* gmax, float* partials,
           float* const* grads, int xyz_ch, int dir_ch, bool h16, int saved_layout, const unsigned* status,
           float* status_out, hipStream_t st);
+// The weight-gradient stage of the 16-bit modes for up to MAX_BWD_JOBS networks at once (plnerf_mlp_bwd_multi): the
+// main / thin / head / reduce launches each cover every job -- the one round of 252 (255) workgroups is dealt out over
+// the jobs in proportion to their rows -- instead of running once per network.  One job = what wgrad() takes.
+constexpr int MAX_BWD_JOBS = 2;
+struct WgradJob {
+    const float* g_raw;
+    int n_rows;
+    const void* saved;
+    const void* dz;
+    const unsigned* gmax;
+    float* partials;
+    float* const* grads;
+    int xyz_ch, dir_ch, saved_layout;
+    const unsigned* status;
+    float* status_out;
+};
+int wgrad_h16_multi(int n, const WgradJob* jobs, hipStream_t st);
+// one network's share of the dgrad grid (mlp_bwd_h16_kernel, two networks per grid)
+struct DgradJob {
+    const void* packed;
+    int fwd_ns;
+    const float* g_raw;
+    int n_rows;
+    const void* saved;
+    void* dz;
+    const unsigned* gmax;
+};
 // gradient with respect to the embedded input rows, from the dz planes a finished plnerf_mlp_bwd left in its workspace
 int input_grad(const float* const* params, int n_rows, const void* dz, const unsigned* gmax, bool h16, int xyz_ch,
                int dir_ch, float* g_emb, hipStream_t st);
@@ -52,8 +79,7 @@ int bf16_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, int f1
 int bf16_fwd(const void* packed, int ns, int f16, const float* pts, const float* viewdirs, const float* embedded,
              int xyz_ch, int dir_ch, int n_rows, int samples_per_ray, FwdOpt opt, float* raw_out, void* saved,
              unsigned* status, hipStream_t st);
-int bf16_dgrad(const void* packed, int ns, const float* g_raw, int n_rows, const void* saved, void* dz,
-               const unsigned* gmax, hipStream_t st);
+int bf16_dgrad(int n, const DgradJob* jobs, hipStream_t st);
 
 // Register-resident forward kernel (mlp_rr.hip; IEEE-half elements): its own weight section (k order permuted to the
 // accumulator layout) appended to the packed buffer of the half modes.

@@ -53,6 +53,14 @@ struct WgradArgs {
     int n_rows, rows_per_split;
     float* part;      // [splits][PART_PER_SPLIT]
 };
+// The half kernels take up to two networks per grid (round 5: plnerf_mlp_bwd_multi): row ranges [0, splits0) of the
+// grid's y extent belong to n[0], the rest to n[1] -- the ONE round of workgroups is dealt out over the networks in
+// proportion to their rows, so that a training step's coarse and fine networks share a launch instead of each paying its
+// ramp and its tail (profiles/r05_merged_bwd_bound.txt).
+struct WgradArgs2 {
+    WgradArgs n[2];
+    int splits0;
+};
 
 // Waves are arranged WO x WI over the workgroup tile; each owns NO x NI 32x32 MFMA tiles.
 // KS k-steps (2 rows each) are loaded per iteration, one iteration ahead of the MFMAs.
@@ -192,7 +200,7 @@ __device__ __forceinline__ wh8 tr_frag_tiled(const _Float16* stage, int srows, i
 // kernel measured +-0 for exactly that reason).  O and I are therefore template parameters (slot counts static),
 // rows past the range are loaded from the clamped last row and zeroed by a select.
 template <int O, int I, int NI, bool DEEP, bool TILED = false>
-__device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& job, unsigned char* smem_raw) {
+__device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& job, const int split, unsigned char* smem_raw) {
     static_assert(!TILED || I == W, "the tiled layout exists for the 256-wide planes");
     // the A operand: a half dz plane -- TILED too when it is 256 wide (written by the dgrad kernel's MFMA epilogues,
     // mlp_layout.h); dz_view (O = 128) is row-major
@@ -214,7 +222,6 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
     const int wo = wave / WI, wi = wave % WI;
     const int o_base = wo * NO * 32, i_base = wi * NI * 32;
     const bool live = o_base < O && i_base < I;
-    const int split = blockIdx.y;
     const int m_begin = split * a.rows_per_split;
     const int m_end = min(a.n_rows, m_begin + a.rows_per_split);
     int a_row[SA], a_col[SA];        // ATILED: row of the stage | piece block of the chunk (as b_row / b_col below)
@@ -383,24 +390,30 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
     }
 }
 
-__global__ __launch_bounds__(512) void wgrad_thin_kernel(WgradArgs a) {
+__global__ __launch_bounds__(512) void wgrad_thin_kernel(WgradArgs2 p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const bool second = (int)blockIdx.y >= p.splits0;      // (uniform)
+    const WgradArgs& a = p.n[second ? 1 : 0];
+    const int split = (int)blockIdx.y - (second ? p.splits0 : 0);
     const int j = a.tile_job[blockIdx.x];
     const WJob job = a.jobs[j];
-    if (job.O == W) wgrad_half_body<W, PE_K, 1, true>(a, job, smem_raw);      // encoding columns of L0 / L5
-    else wgrad_half_body<HV, DPE_K, 1, true>(a, job, smem_raw);               // direction columns of the view layer
+    if (job.O == W) wgrad_half_body<W, PE_K, 1, true>(a, job, split, smem_raw);      // encoding columns of L0 / L5
+    else wgrad_half_body<HV, DPE_K, 1, true>(a, job, split, smem_raw);               // direction columns of the view layer
 }
 
 // the 256-wide jobs on the same body (256 x 256 layers, 128 x 256 feature columns of the view layer)
-__global__ __launch_bounds__(512) void wgrad_main_kernel(WgradArgs a) {
+__global__ __launch_bounds__(512) void wgrad_main_kernel(WgradArgs2 p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const bool second = (int)blockIdx.y >= p.splits0;      // (uniform)
+    const WgradArgs& a = p.n[second ? 1 : 0];
+    const int split = (int)blockIdx.y - (second ? p.splits0 : 0);
     const WJob job = a.jobs[a.tile_job[blockIdx.x]];
     if (job.b_tiled) {      // (uniform per workgroup)
-        if (job.O == W) wgrad_half_body<W, W, 4, false, true>(a, job, smem_raw);
-        else wgrad_half_body<HV, W, 4, false, true>(a, job, smem_raw);
+        if (job.O == W) wgrad_half_body<W, W, 4, false, true>(a, job, split, smem_raw);
+        else wgrad_half_body<HV, W, 4, false, true>(a, job, split, smem_raw);
     } else {
-        if (job.O == W) wgrad_half_body<W, W, 4, false>(a, job, smem_raw);
-        else wgrad_half_body<HV, W, 4, false>(a, job, smem_raw);
+        if (job.O == W) wgrad_half_body<W, W, 4, false>(a, job, split, smem_raw);
+        else wgrad_half_body<HV, W, 4, false>(a, job, split, smem_raw);
     }
 }
 
@@ -416,7 +429,16 @@ struct HeadArgs {
 };
 
 template <typename PT>
-__global__ __launch_bounds__(256) void wgrad_head_kernel(HeadArgs<PT> a) {
+struct HeadArgs2 {      // workgroups [0, wgs0) belong to n[0], the rest to n[1]
+    HeadArgs<PT> n[2];
+    int wgs0;
+};
+
+template <typename PT>
+__global__ __launch_bounds__(256) void wgrad_head_kernel(HeadArgs2<PT> p) {
+    const bool second = (int)blockIdx.x >= p.wgs0;      // (uniform)
+    const HeadArgs<PT>& a = p.n[second ? 1 : 0];
+    const int wg = (int)blockIdx.x - (second ? p.wgs0 : 0);
     // 16-byte loads: VEC plane elements per thread, so a row of h7 (hv) is read by T7 (TV) neighbouring threads and
     // the workgroup covers R7 (RV) rows per pass; the row classes are summed through LDS at the end
     constexpr int VEC = 16 / (int)sizeof(PT);
@@ -427,7 +449,7 @@ __global__ __launch_bounds__(256) void wgrad_head_kernel(HeadArgs<PT> a) {
     __shared__ float accv[RV][3][HV];
     __shared__ float red[4][4];
     const int tid = threadIdx.x;
-    const int m_begin = blockIdx.x * a.rows_per_wg;
+    const int m_begin = wg * a.rows_per_wg;
     const int m_end = min(a.n_rows, m_begin + a.rows_per_wg);
     const float4* g4 = reinterpret_cast<const float4*>(a.g_raw);
     // Tiled half planes (mlp_layout.h): a 16-byte piece = 8 features {4 g + 0..3, 8 + 4 g + 0..3} + 32 j + 16 f of one row,
@@ -489,7 +511,7 @@ __global__ __launch_bounds__(256) void wgrad_head_kernel(HeadArgs<PT> a) {
     s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
     if ((tid & 63) == 0) { red[tid >> 6][0] = s0; red[tid >> 6][1] = s1; red[tid >> 6][2] = s2; red[tid >> 6][3] = s3; }
     __syncthreads();
-    float* part = a.part + (size_t)blockIdx.x * HEAD_PART;
+    float* part = a.part + (size_t)wg * HEAD_PART;
     {
         float wa = 0.0f;
 #pragma unroll
@@ -636,7 +658,12 @@ struct ReduceArgs {
     GradPtrs G;
 };
 
-__global__ void wgrad_reduce_kernel(ReduceArgs a) {
+struct ReduceArgs2 {      // blockIdx.y = network
+    ReduceArgs n[2];
+};
+
+__global__ void wgrad_reduce_kernel(ReduceArgs2 p) {
+    const ReduceArgs& a = p.n[blockIdx.y];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= PART_PER_SPLIT + HEAD_OUT * 64) return;
     // the range status travels with the gradient it qualifies (dp.GradientBucket sums this element over the ranks; a
@@ -810,15 +837,27 @@ int absmax_act(const float* g_raw, const float* raw_out, float beta, int n_rows,
     return PLNERF_OK;
 }
 
-int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, const unsigned* gmax, float* part,
-          float* const* grads, int xyz_ch, int dir_ch, bool h16, int saved_layout, const unsigned* status,
-          float* status_out, hipStream_t st) {
+namespace {
+// Everything the stage's launches need for ONE network, with the number of row ranges it may use in the main / thin
+// launches (`cap_main`, `cap_thin`: the whole round for a single network, its share of it when two networks share a grid).
+struct WgradPlan {
+    WgradArgs main_args, thin_args;
+    int nt;                           // tiles (jobs) of the main launch
+    int splits, splits_thin, n_head, rows_per_head_wg;
+    float* head_part;
+    ReduceArgs red;
+};
+
+int plan_job(const plnerf::impl::WgradJob& jb, bool h16, int cap_main, int cap_thin, WgradPlan& P) {
+    const int n_rows = jb.n_rows;
     const size_t N = (size_t)n_rows;
     const size_t NS_ = h16 ? sv_rows(N) : N;       // row stride of the saved half state (padded, mlp_layout.h)
-    const int tiled = h16 && saved_layout == SV_LAYOUT_TILED;
+    const int tiled = h16 && jb.saved_layout == SV_LAYOUT_TILED;
     const size_t es = h16 ? sizeof(_Float16) : sizeof(float);        // plane element size
-    float* head_part = part + (size_t)MAX_SPLITS * PART_PER_SPLIT;
-    int splits = splits_for(n_rows, h16);
+    float* part = jb.partials;
+    P.head_part = part + (size_t)MAX_SPLITS * PART_PER_SPLIT;
+    int splits = (n_rows + 1023) / 1024;
+    splits = splits < 1 ? 1 : (splits > cap_main ? cap_main : splits);
     int rps = (n_rows + splits - 1) / splits;
     rps = h16 ? (rps + 63) & ~63 : (rps + 15) & ~15;      // half kernels: whole 64-row stages (two tiles of the tiled layout)
     // Rounding the range length up can leave the LAST ranges without a row (131,072 rows over 85 ranges of 1,600: ranges
@@ -827,16 +866,15 @@ int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, co
     // that hold a row are launched and summed.
     splits = (n_rows + rps - 1) / rps;
     int splits_thin = splits;
-    if (h16) { splits_thin = (n_rows + 1023) / 1024; splits_thin = splits_thin < 1 ? 1 : (splits_thin > 85 ? 85 : splits_thin); }
+    if (h16) { splits_thin = (n_rows + 1023) / 1024; splits_thin = splits_thin < 1 ? 1 : (splits_thin > cap_thin ? cap_thin : splits_thin); }
     int rps_thin = (n_rows + splits_thin - 1) / splits_thin;
     rps_thin = h16 ? (rps_thin + 63) & ~63 : (rps_thin + 15) & ~15;      // (half: whole tiles of the tiled dz planes)
     splits_thin = (n_rows + rps_thin - 1) / rps_thin;
-    const unsigned char* sv = (const unsigned char*)saved;
-    const unsigned char* dz = (const unsigned char*)dzv;
+    const unsigned char* sv = (const unsigned char*)jb.saved;
+    const unsigned char* dz = (const unsigned char*)jb.dz;
     auto splane = [&](int p) { return (const void*)(sv + (size_t)p * W * NS_ * es); };
     const size_t ND = h16 ? dz_rows(N) : N;        // row stride of the dz planes (half: padded to the dgrad kernel's tiles)
     auto dplane = [&](int p) { return (const void*)(dz + (size_t)p * W * ND * es); };
-    const void* hv_plane = sv + (size_t)SV_HV_OFF * NS_ * es;
     const void* pe_plane = sv + (size_t)SV_PE_OFF * NS_ * es;
     const void* dpe_plane = sv + (size_t)SV_DPE_OFF * NS_ * es;
     const void* dzv_plane = dz + (size_t)DZ_V_OFF * ND * es;
@@ -846,20 +884,20 @@ int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, co
         const int layer_of_job[8] = {1, 2, 3, 4, 5, 6, 7, -1};
         int nt = 0;
         for (int j = 0; j < 8; ++j) {
-            WJob& jb = a.jobs[j];
+            WJob& jw = a.jobs[j];
             if (j < 7) {
                 const int l = layer_of_job[j];
-                jb.A = dplane(l);
-                jb.B = splane(l - 1);
-                jb.bias_off = PART_BIAS + l * W;
+                jw.A = dplane(l);
+                jw.B = splane(l - 1);
+                jw.bias_off = PART_BIAS + l * W;
             } else {
-                jb.A = dplane(DZ_FEAT);
-                jb.B = splane(7);
-                jb.bias_off = PART_BIAS + 8 * W;
+                jw.A = dplane(DZ_FEAT);
+                jw.B = splane(7);
+                jw.bias_off = PART_BIAS + 8 * W;
             }
-            jb.lda = W; jb.ldb = W; jb.O = W; jb.I = W;
-            jb.b_tiled = tiled;
-            jb.part_off = PART_MAIN + j * W * W;
+            jw.lda = W; jw.ldb = W; jw.O = W; jw.I = W;
+            jw.b_tiled = tiled;
+            jw.part_off = PART_MAIN + j * W * W;
             a.tile_job[nt] = j; a.tile_o0[nt++] = 0;
             if (!h16) { a.tile_job[nt] = j; a.tile_o0[nt++] = 128; }   // f32 kernel: 128-row o tiles
         }
@@ -868,13 +906,7 @@ int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, co
         jv.part_off = PART_VMAIN; jv.bias_off = PART_BIAS + 9 * W; jv.b_tiled = tiled;
         a.tile_job[nt] = 8; a.tile_o0[nt++] = 0;
         a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
-        if (!h16) hipLaunchKernelGGL((wgrad_f32_kernel<2, 2, 2, 4, 4>), dim3(nt, splits), dim3(256), 0, st, a);
-        else {
-            const size_t lds = (size_t)2 * 2 * TR_STEPS * TR_PLANE * sizeof(_Float16);
-            (void)hipFuncSetAttribute((const void*)wgrad_main_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(wgrad_main_kernel, dim3(nt, splits), dim3(512), lds, st, a);
-        }
-        PLNERF_CHECK_LAUNCH();
+        P.main_args = a; P.nt = nt;
     }
     {
         // the three thin jobs: encoding columns of L0 / L5 (256 x 64), direction columns of the view layer (128 x 32)
@@ -884,52 +916,121 @@ int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, co
         a.jobs[1] = WJob{dplane(5), pe_plane, W, PE_K, W, PE_K, PART_PE5, -1, 0};
         a.jobs[2] = WJob{dzv_plane, dpe_plane, HV, DPE_K, HV, DPE_K, PART_VDIR, -1, 0};
         for (int t = 0; t < 3; ++t) { a.tile_job[t] = t; a.tile_o0[t] = 0; }
-        a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
-        if (h16) {
-            // three tiles only: more row ranges than the main launch, to cover the 256 CUs (3 x 85 = 255).
-            // (Equal ROW counts per workgroup, not equal bytes: a stage costs its latency whatever its width, so
-            // giving the 128 x 32 job half as many, twice as long ranges measured 0.27 ms slower per step.)
-            a.rows_per_split = rps_thin;
-            const size_t lds = (size_t)2 * 2 * TR_STEPS * TR_PLANE * sizeof(_Float16);
-            (void)hipFuncSetAttribute((const void*)wgrad_thin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(wgrad_thin_kernel, dim3(3, splits_thin), dim3(512), lds, st, a);
-        } else {
-            hipLaunchKernelGGL((wgrad_f32_kernel<4, 1, 2, 2, 4>), dim3(2, splits), dim3(256), 0, st, a);
-            PLNERF_CHECK_LAUNCH();
-            WgradArgs v{};
-            v.jobs[0] = a.jobs[2];
-            v.tile_job[0] = 0; v.tile_o0[0] = 0;
-            v.n_rows = n_rows; v.rows_per_split = rps; v.part = part;
-            hipLaunchKernelGGL((wgrad_f32_kernel<4, 1, 1, 1, 8>), dim3(1, splits), dim3(256), 0, st, v);
-        }
-        PLNERF_CHECK_LAUNCH();
+        // half: three tiles only, so more row ranges than the main launch to cover the 256 CUs (3 x 85 = 255).
+        // (Equal ROW counts per workgroup, not equal bytes: a stage costs its latency whatever its width, so
+        // giving the 128 x 32 job half as many, twice as long ranges measured 0.27 ms slower per step.)
+        a.n_rows = n_rows; a.rows_per_split = h16 ? rps_thin : rps; a.part = part;
+        P.thin_args = a;
     }
-    const int n_head = head_wgs_for(n_rows);
-    if (h16) {
-        HeadArgs<_Float16> a{g_raw, (const _Float16*)splane(7), (const _Float16*)hv_plane, n_rows,
-                             (((n_rows + n_head - 1) / n_head) + 31) & ~31, head_part, tiled};
-        hipLaunchKernelGGL(wgrad_head_kernel<_Float16>, dim3(n_head), dim3(256), 0, st, a);
-    } else {
-        HeadArgs<float> a{g_raw, (const float*)splane(7), (const float*)hv_plane, n_rows,
-                          (n_rows + n_head - 1) / n_head, head_part, 0};
-        hipLaunchKernelGGL(wgrad_head_kernel<float>, dim3(n_head), dim3(256), 0, st, a);
-    }
-    PLNERF_CHECK_LAUNCH();
+    P.splits = splits; P.splits_thin = splits_thin;
+    P.n_head = head_wgs_for(n_rows);
+    P.rows_per_head_wg = h16 ? ((((n_rows + P.n_head - 1) / P.n_head) + 31) & ~31) : (n_rows + P.n_head - 1) / P.n_head;
     {
         ReduceArgs a{};
-        a.part = part; a.head_part = head_part; a.splits = splits; a.splits_thin = splits_thin; a.n_head = n_head;
-        a.gmax = h16 ? gmax : nullptr;
-        a.status = status; a.status_out = status_out;
-        a.G.xyz_ch = xyz_ch; a.G.dir_ch = dir_ch;
+        a.part = part; a.head_part = P.head_part; a.splits = splits; a.splits_thin = splits_thin; a.n_head = P.n_head;
+        a.gmax = h16 ? jb.gmax : nullptr;
+        a.status = jb.status; a.status_out = jb.status_out;
+        a.G.xyz_ch = jb.xyz_ch; a.G.dir_ch = jb.dir_ch;
         for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i) {
-            if (!grads[i]) return PLNERF_EINVAL;
-            a.G.p[i] = grads[i];
+            if (!jb.grads[i]) return PLNERF_EINVAL;
+            a.G.p[i] = jb.grads[i];
         }
-        const int total = PART_PER_SPLIT + HEAD_OUT * 64;   // PART_PER_SPLIT is a multiple of 64: head waves stay whole
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a);
-        PLNERF_CHECK_LAUNCH();
+        P.red = a;
     }
     return PLNERF_OK;
+}
+
+int launch_reduce(const WgradPlan* P, int n, hipStream_t st) {
+    ReduceArgs2 r{};
+    for (int j = 0; j < 2; ++j) r.n[j] = P[j < n ? j : 0].red;
+    const int total = PART_PER_SPLIT + HEAD_OUT * 64;   // PART_PER_SPLIT is a multiple of 64: head waves stay whole
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256, n), dim3(256), 0, st, r);
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}
+}  // namespace
+
+// fp32 mode (and the single-network entry of the 16-bit modes)
+int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, const unsigned* gmax, float* part,
+          float* const* grads, int xyz_ch, int dir_ch, bool h16, int saved_layout, const unsigned* status,
+          float* status_out, hipStream_t st) {
+    const WgradJob jb{g_raw, n_rows, saved, dzv, gmax, part, grads, xyz_ch, dir_ch, saved_layout, status, status_out};
+    if (h16) return wgrad_h16_multi(1, &jb, st);
+    WgradPlan P;
+    const int rc = plan_job(jb, false, PLNERF_WG_SPLITS_F32, PLNERF_WG_SPLITS_F32, P);
+    if (rc) return rc;
+    hipLaunchKernelGGL((wgrad_f32_kernel<2, 2, 2, 4, 4>), dim3(P.nt, P.splits), dim3(256), 0, st, P.main_args);
+    PLNERF_CHECK_LAUNCH();
+    hipLaunchKernelGGL((wgrad_f32_kernel<4, 1, 2, 2, 4>), dim3(2, P.splits), dim3(256), 0, st, P.thin_args);
+    PLNERF_CHECK_LAUNCH();
+    WgradArgs v{};
+    v.jobs[0] = P.thin_args.jobs[2];
+    v.tile_job[0] = 0; v.tile_o0[0] = 0;
+    v.n_rows = n_rows; v.rows_per_split = P.thin_args.rows_per_split; v.part = part;
+    hipLaunchKernelGGL((wgrad_f32_kernel<4, 1, 1, 1, 8>), dim3(1, P.splits), dim3(256), 0, st, v);
+    PLNERF_CHECK_LAUNCH();
+    HeadArgs2<float> h{};
+    h.n[0] = h.n[1] = HeadArgs<float>{g_raw, (const float*)P.main_args.jobs[7].B, (const float*)((const unsigned char*)saved + (size_t)SV_HV_OFF * (size_t)n_rows * sizeof(float)),
+                                      n_rows, P.rows_per_head_wg, P.head_part, 0};
+    h.wgs0 = P.n_head;
+    hipLaunchKernelGGL(wgrad_head_kernel<float>, dim3(P.n_head), dim3(256), 0, st, h);
+    PLNERF_CHECK_LAUNCH();
+    return launch_reduce(&P, 1, st);
+}
+
+int wgrad_h16_multi(int n, const WgradJob* jobs, hipStream_t st) {
+    if (n < 1 || n > MAX_BWD_JOBS) return PLNERF_EINVAL;
+    // the one round of workgroups, dealt out in proportion to the networks' rows (a single network: all of it, as before)
+    int cap_main[MAX_BWD_JOBS] = {WG_SPLITS, 0}, cap_thin[MAX_BWD_JOBS] = {85, 0};
+    if (n == 2) {
+        const double f = (double)jobs[0].n_rows / ((double)jobs[0].n_rows + (double)jobs[1].n_rows);
+        auto deal = [&](int total, int* cap) {
+            int s0 = (int)(total * f + 0.5);
+            s0 = s0 < 1 ? 1 : (s0 > total - 1 ? total - 1 : s0);
+            cap[0] = s0; cap[1] = total - s0;
+        };
+        deal(WG_SPLITS, cap_main);
+        deal(85, cap_thin);
+    }
+    WgradPlan P[MAX_BWD_JOBS];
+    for (int j = 0; j < n; ++j) {
+        const int rc = plan_job(jobs[j], true, cap_main[j], cap_thin[j], P[j]);
+        if (rc) return rc;
+    }
+    const size_t lds = (size_t)2 * 2 * TR_STEPS * TR_PLANE * sizeof(_Float16);
+    {
+        WgradArgs2 a{};
+        for (int j = 0; j < 2; ++j) a.n[j] = P[j < n ? j : 0].main_args;
+        a.splits0 = P[0].splits;
+        const int splits = P[0].splits + (n == 2 ? P[1].splits : 0);
+        (void)hipFuncSetAttribute((const void*)wgrad_main_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(wgrad_main_kernel, dim3(P[0].nt, splits), dim3(512), lds, st, a);
+        PLNERF_CHECK_LAUNCH();
+    }
+    {
+        WgradArgs2 a{};
+        for (int j = 0; j < 2; ++j) a.n[j] = P[j < n ? j : 0].thin_args;
+        a.splits0 = P[0].splits_thin;
+        const int splits = P[0].splits_thin + (n == 2 ? P[1].splits_thin : 0);
+        (void)hipFuncSetAttribute((const void*)wgrad_thin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(wgrad_thin_kernel, dim3(3, splits), dim3(512), lds, st, a);
+        PLNERF_CHECK_LAUNCH();
+    }
+    {
+        HeadArgs2<_Float16> h{};
+        for (int j = 0; j < 2; ++j) {
+            const int q = j < n ? j : 0;
+            const size_t NS_ = sv_rows((size_t)jobs[q].n_rows);
+            h.n[j] = HeadArgs<_Float16>{jobs[q].g_raw, (const _Float16*)P[q].main_args.jobs[7].B,
+                                        (const _Float16*)((const unsigned char*)jobs[q].saved + (size_t)SV_HV_OFF * NS_ * sizeof(_Float16)),
+                                        jobs[q].n_rows, P[q].rows_per_head_wg, P[q].head_part,
+                                        jobs[q].saved_layout == SV_LAYOUT_TILED};
+        }
+        h.wgs0 = P[0].n_head;
+        hipLaunchKernelGGL(wgrad_head_kernel<_Float16>, dim3(P[0].n_head + (n == 2 ? P[1].n_head : 0)), dim3(256), 0, st, h);
+        PLNERF_CHECK_LAUNCH();
+    }
+    return launch_reduce(P, n, st);
 }
 
 int input_grad(const float* const* params, int n_rows, const void* dzv, const unsigned* gmax, bool h16, int xyz_ch,

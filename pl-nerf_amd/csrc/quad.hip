@@ -41,6 +41,10 @@ struct QuadArgs {
     const float* g_tau;   // linear mode: upstream gradient of the returned tau [R,S+2] (or nullptr)
     const float* g_T;     // linear mode: upstream gradient of the returned T   [R,S+2] (or nullptr)
     float* g_raw;
+    // backward by-product (may be null): max |g_raw| of the launch as (tag << 32 | fp32 bits), raised with atomicMax --
+    // the half dz planes' launch scale, which plnerf_mlp_bwd otherwise finds with a pass of its own over g_raw
+    unsigned long long* absmax_out;
+    unsigned absmax_tag;
 };
 
 template <int MODE>
@@ -206,6 +210,7 @@ __global__ __launch_bounds__(256) void quad_bwd_kernel(QuadArgs a) {
     // pass 3: per-sample gradients
     if (live) {
         float4* out = reinterpret_cast<float4*>(a.g_raw) + (size_t)ray * S;
+        float gmax = 0.0f;
         for (int s = lane; s < S; s += 64) {
             float gtau, coef;
             if (MODE == PLNERF_MODE_LINEAR) {
@@ -230,6 +235,22 @@ __global__ __launch_bounds__(256) void quad_bwd_kernel(QuadArgs a) {
             g.z = gb * coef * (c2 * (1.0f - c2));
             g.w = (tau[s + 1] > 0.0f) ? gtau : 0.0f;
             out[s] = g;
+            const float c[4] = {fabsf(g.x), fabsf(g.y), fabsf(g.z), fabsf(g.w)};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gmax = (c[k] > gmax || c[k] != c[k]) ? c[k] : gmax;   // a NaN sticks (and orders above every float as bits)
+        }
+        if (a.absmax_out) {      // (uniform)
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const float o = __shfl_xor(gmax, d);
+                gmax = (o > gmax || o != o) ? o : gmax;
+            }
+            if (lane == 0 && gmax != 0.0f) {
+                // one atomic per ray at most: skipped where the word already holds this launch's tag with a larger value
+                // (atomics on one address serialise in the L2; the plain load ahead of it is what keeps them rare)
+                const unsigned long long v = ((unsigned long long)a.absmax_tag << 32) | (unsigned long long)__float_as_uint(gmax);
+                if (__builtin_nontemporal_load(a.absmax_out) < v) atomicMax(a.absmax_out, v);
+            }
         }
     }
 }
@@ -285,7 +306,8 @@ extern "C" int plnerf_quad_bwd(const float* raw, const float* z, const float* ne
                                const float* rays_d, const float* noise, int R, int S, int mode,
                                int color_mode, int white_bkgd, int farcolorfix, const float* g_rgb,
                                const float* g_depth, const float* g_acc, const float* g_weights,
-                               const float* g_tau, const float* g_T, float* g_raw, plnerf_stream_t stream) {
+                               const float* g_tau, const float* g_T, float* g_raw, uint64_t* absmax_out,
+                               uint32_t absmax_tag, plnerf_stream_t stream) {
     int rc = check_common(raw, z, near, far, rays_d, R, S, mode, color_mode);
     if (rc) return rc;
     if (R == 0) return PLNERF_OK;
@@ -295,6 +317,7 @@ extern "C" int plnerf_quad_bwd(const float* raw, const float* z, const float* ne
     a.raw = raw; a.z = z; a.near = near; a.far = far; a.rays_d = rays_d; a.noise = noise;
     a.R = R; a.S = S; a.color_mode = color_mode; a.white_bkgd = white_bkgd; a.farcolorfix = farcolorfix;
     a.g_rgb = g_rgb; a.g_depth = g_depth; a.g_acc = g_acc; a.g_weights = g_weights; a.g_tau = g_tau; a.g_T = g_T; a.g_raw = g_raw;
+    a.absmax_out = (unsigned long long*)absmax_out; a.absmax_tag = absmax_tag;
     a.lds_stride = ((5 * S + 4 + 4 * (S + 2)) + 3) & ~3;
     const size_t lds = (size_t)WAVES * a.lds_stride * sizeof(float);
     dim3 grid((R + WAVES - 1) / WAVES), block(WAVES * 64);

@@ -110,6 +110,17 @@ class GradientBucket:
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._works[mi] = (work, flat, tail)
 
+    def gradients_ready(self, modules):
+        """A caller that assigned `.grad` itself (train.TrainStep's merged backward: no AccumulateGrad node ran, so no hook
+        fired) says the gradients of `modules` are complete: their collectives are enqueued now, as the hooks would have."""
+        if not self._hooks:
+            return
+        for m in modules:
+            mi = self._index(m)
+            self._arrived[mi] = 0
+            if mi not in self._works:
+                self._launch(mi)
+
     def pending(self):
         """Collectives enqueued by the hooks and not yet waited for (for tests / diagnostics)."""
         return len(self._works)

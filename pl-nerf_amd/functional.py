@@ -106,8 +106,35 @@ class QuadratureFn(torch.autograd.Function):
         return g_raw, None, None, None, None, None, None, None, None, None
 
 
+class _AbsmaxWords:
+    """plnerf_quad_bwd leaves max |g_raw| of its launch in a 64-bit device word as (tag << 32 | fp32 bits) (atomicMax with a
+    tag that grows from call to call, so a word needs no zeroing); plnerf_mlp_bwd takes the low half as its `g_absmax` and
+    skips its own pass over g_raw.  A ring of words per device: a word is reused after RING further calls, long after the
+    backward that consumed it was enqueued (same stream)."""
+    RING = 16
+
+    def __init__(self):
+        self.words, self.count = {}, 0
+
+    def next(self, device):
+        w = self.words.get(device)
+        if w is None:
+            w = self.words[device] = torch.zeros(self.RING, device=device, dtype=torch.int64)
+        self.count += 1
+        slot = self.count % self.RING
+        return ctypes.c_void_p(w.data_ptr() + 8 * slot), self.count & 0xFFFFFFFF, w.view(torch.int32)[2 * slot:2 * slot + 1]
+
+
+_ABSMAX = _AbsmaxWords()
+# Armed (a list) by a caller that runs plnerf_quad_bwd and the MLP backward itself, back to back (train.TrainStep's merged
+# backward): every plnerf_quad_bwd then leaves its by-product and logs (g_raw.data_ptr(), the word's int32 view) here, and
+# the caller hands the matching views to mlp_backward_multi.  None: no by-product is asked for.
+ABSMAX_LOG = None
+
+
 def _quad_backward(saved, cfg, g_rgb, g_disp, g_acc, g_w, g_depth, g_tau, g_T):
-    """plnerf_quad_bwd from the tensors a quadrature forward saved (shared by QuadratureFn and CoarseEpilogueFn)."""
+    """plnerf_quad_bwd from the tensors a quadrature forward saved (shared by QuadratureFn and CoarseEpilogueFn).  With
+    ABSMAX_LOG armed the launch also leaves max |g_raw| in a device word (see _AbsmaxWords) and logs it."""
     raw_c, z_c, near_c, far_c, d_c, noise_c, depth, acc = saved
     mode, color_mode, white_bkgd, farcolorfix, has_noise = cfg
     R, S = z_c.shape
@@ -130,11 +157,14 @@ def _quad_backward(saved, cfg, g_rgb, g_disp, g_acc, g_w, g_depth, g_tau, g_T):
     g_T = None if (g_T is None or mode != "linear") else _f32c(g_T)
     g_raw = torch.empty(R, S, 4, device=dev)
     if R > 0:
+        word, tag, view = _ABSMAX.next(dev) if ABSMAX_LOG is not None else (None, 0, None)
         L.check(L.lib().plnerf_quad_bwd(
           L.dptr(raw_c), L.dptr(z_c), L.dptr(near_c), L.dptr(far_c), L.dptr(d_c),
           L.dptr(noise_c) if has_noise else None, R, S, L.MODE[mode], L.COLOR[color_mode],
           int(white_bkgd), int(farcolorfix), L.dptr(g_rgb), L.dptr(g_depth), L.dptr(g_acc), L.dptr(g_w),
-          L.dptr(g_tau), L.dptr(g_T), L.dptr(g_raw), L.stream()), "plnerf_quad_bwd")
+          L.dptr(g_tau), L.dptr(g_T), L.dptr(g_raw), word, tag, L.stream()), "plnerf_quad_bwd")
+        if view is not None:
+            ABSMAX_LOG.append((g_raw.data_ptr(), view))
     return g_raw
 
 
@@ -381,6 +411,93 @@ def coarse_samples(rays_o, rays_d, near, far, t_vals, t_rand, lindisp, perturb, 
     return z, pts
 
 
+def _grad_buffer(ctx, dev, zero=False):
+    """A network's 24 gradients as consecutive slices of ONE buffer, in parameter order: optim.FlatAdam and
+    dp.GradientBucket then see the network's gradient as a single flat tensor (one Adam launch, one all-reduce without
+    gather / scatter copies).  GRAD_TAIL floats behind them: [0] = the network's range status as the reduction kernel
+    leaves it, so that a data-parallel exchange of this buffer carries it along (dp.GradientBucket)."""
+    sizes = [int(torch.Size(sh).numel()) for sh in ctx.param_shapes]
+    n_grad = sum(sizes)
+    full = (torch.zeros if zero else torch.empty)(n_grad + GRAD_TAIL, device=dev, dtype=torch.float32)
+    ctx.net.__dict__["_grad_flat"] = full
+    return [t.view(sh) for t, sh in zip(full[:n_grad].split(sizes), ctx.param_shapes)], full
+
+
+def _mlp_backward_launch(ctxs, g_raws, absmax_log=None):
+    """plnerf_mlp_bwd_multi over the saved state of one or two MlpFn forwards (the same precision, input widths and
+    density activation): one launch sequence for all of them.  absmax_log: [(g_raw.data_ptr(), word view)] of the
+    plnerf_quad_bwd launches that produced these g_raws in THIS backward pass (ABSMAX_LOG), or None.  Returns ([the 24
+    gradient views per job], [workspace per job]); each job's flat buffer is left on its network as `_grad_flat`."""
+    n = len(ctxs)
+    c0 = ctxs[0]
+    dev = g_raws[0].device
+    _expect(all(c.prec == c0.prec and c.beta == c0.beta and int(c.net.input_ch) == int(c0.net.input_ch) and
+                int(c.net.hip_view_ch) == int(c0.net.hip_view_ch) for c in ctxs),
+            "jobs of one backward launch share precision, input widths and density activation")
+    gs, wss, grads_all, fulls, absmax = [], [], [], [], []
+    for c, g_raw in zip(ctxs, g_raws):
+        g = _f32c(g_raw)
+        gs.append(g)
+        # (the producer's by-product: the word of the plnerf_quad_bwd launch that wrote exactly this buffer)
+        am = next((v for ptr, v in (absmax_log or ()) if ptr == g.data_ptr()), None)
+        absmax.append(am if (am is not None and c.beta == 0.0 and g.numel() == 4 * c.n_rows) else None)
+        wss.append(torch.empty(L.lib().plnerf_mlp_bwd_workspace_bytes(c.n_rows, c.prec) // 4, device=dev, dtype=torch.float32))
+        grads, full = _grad_buffer(c, dev)
+        grads_all.append(grads)
+        fulls.append(full)
+    vp = lambda items: (ctypes.c_void_p * n)(*[None if x is None else x.value for x in items])
+    n_grad = [full.numel() - GRAD_TAIL for full in fulls]
+    L.check(L.lib().plnerf_mlp_bwd_multi(
+        n, vp([L.dptr(c.packed) for c in ctxs]), c0.prec, vp([L.dptr(g, "g_raw") for g in gs]),
+        vp([L.dptr(a, "g_absmax", torch.int32) for a in absmax]), int(c0.net.input_ch), int(c0.net.hip_view_ch),
+        (ctypes.c_int * n)(*[c.n_rows for c in ctxs]), vp([L.dptr(c.saved_acts) for c in ctxs]),
+        (ctypes.c_int * n)(*[c.saved_layout for c in ctxs]),
+        vp([L.dptr(c.saved_tensors[0]) if c.beta > 0.0 else None for c in ctxs]), c0.beta, vp([L.dptr(w) for w in wss]),
+        L.ptr_table([t for grads in grads_all for t in grads], "grads"),
+        vp([ctypes.c_void_p(full.data_ptr() + 4 * k) for full, k in zip(fulls, n_grad)]), L.stream()),
+        "plnerf_mlp_bwd_multi")
+    global ABSMAX_HITS
+    ABSMAX_HITS += sum(a is not None for a in absmax)
+    return grads_all, wss
+
+
+ABSMAX_HITS = 0      # (diagnostics / tests: backward jobs that took max |g_raw| from plnerf_quad_bwd's by-product)
+
+
+class MlpTape:
+    """Armed by train.TrainStep around a render: records the output tensor of every MlpFn forward (NeRF.query /
+    NeRF.forward append to it), so that the step can run the two networks' backward as ONE launch sequence
+    (mlp_backward_multi) instead of letting autograd run them one after the other."""
+
+    def __init__(self):
+        self.outs = []
+
+
+MLP_TAPE = None
+
+
+def mlp_backward_multi(outs, g_raws, absmax_log=None):
+    """The backward of several MlpFn forwards at once -- `outs`: their output tensors (each one's grad_fn holds the saved
+    state), `g_raws`: the upstream gradients -- through plnerf_mlp_bwd_multi: one dgrad grid and one launch of each
+    weight-gradient kernel for all of them.  Only for networks whose kernel parameters ARE their nn.Parameters
+    (NeRF.is_native()) and whose inputs / camera code take no gradient; returns the per-network lists of 24 gradient
+    tensors (slices of each network's flat buffer), which the caller assigns to `.grad`."""
+    ctxs = [o.grad_fn for o in outs]
+    for c in ctxs:
+        _expect(getattr(c, "saved_acts", None) is not None and c.n_rows > 0 and not c.in_grad and not c.n_cam,
+                "mlp_backward_multi: a forward without saved state, or one whose inputs take a gradient")
+    timer = KERNEL_TIMER
+    if timer is not None:
+        ev = timer.bracket("mlp_bwd[" + "+".join(str(c.n_rows) for c in ctxs) + "]")
+        ev[0].record()
+    grads_all, _ = _mlp_backward_launch(ctxs, g_raws, absmax_log)
+    if timer is not None:
+        ev[1].record()
+    for c in ctxs:
+        c.saved_acts = None
+    return grads_all
+
+
 class MlpFn(torch.autograd.Function):
     """Embedder + NeRF.forward (run_nerf_helpers.py:24-54, 105-128) -> plnerf_mlp_fwd /
     plnerf_mlp_bwd (+ plnerf_mlp_input_grad).  Gradients flow to the 24 parameter tensors, to the inputs when they ask
@@ -450,34 +567,18 @@ class MlpFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_raw):
-        n_rows, prec = ctx.n_rows, ctx.prec
+        n_rows = ctx.n_rows
         dev = g_raw.device
         if ctx.saved_acts is None and n_rows > 0:
             raise RuntimeError("plnerf_amd: backward through an MLP forward that ran without saved state")
-        # the 24 gradients are consecutive slices of ONE buffer, in parameter order: optim.FlatAdam and
-        # dp.GradientBucket then see a network's gradient as a single flat tensor (one Adam launch, one all-reduce
-        # without gather / scatter copies)
-        sizes = [int(torch.Size(s).numel()) for s in ctx.param_shapes]
-        n_grad = sum(sizes)
-        # (+ GRAD_TAIL floats behind them: [0] = the network's range status as the reduction kernel leaves it, so that a
-        # data-parallel exchange of this buffer carries it along -- dp.GradientBucket)
-        full = (torch.zeros if n_rows == 0 else torch.empty)(n_grad + GRAD_TAIL, device=dev, dtype=torch.float32)
-        flat = full[:n_grad]
-        ctx.net.__dict__["_grad_flat"] = full
-        grads = [t.view(s) for t, s in zip(flat.split(sizes), ctx.param_shapes)]
         if n_rows == 0:
-            return (None,) * 3 + (None if not ctx.n_cam else flat.new_zeros(ctx.n_cam),) + (None,) * 3 + tuple(grads)
-        g = _f32c(g_raw)
-        ws = torch.empty(L.lib().plnerf_mlp_bwd_workspace_bytes(n_rows, prec) // 4, device=dev, dtype=torch.float32)
+            grads, _ = _grad_buffer(ctx, dev, zero=True)
+            return (None,) * 3 + (None if not ctx.n_cam else grads[0].new_zeros(ctx.n_cam),) + (None,) * 3 + tuple(grads)
         timer = KERNEL_TIMER
         if timer is not None:
             ev = timer.bracket(f"mlp_bwd[{n_rows}]")
             ev[0].record()
-        L.check(L.lib().plnerf_mlp_bwd(
-            L.dptr(ctx.packed), prec, L.dptr(g, "g_raw"), int(ctx.net.input_ch), int(ctx.net.hip_view_ch), n_rows,
-            L.dptr(ctx.saved_acts), ctx.saved_layout, L.dptr(ctx.saved_tensors[0]) if ctx.beta > 0.0 else None, ctx.beta,
-            L.dptr(ws), L.ptr_table(grads, "grads"), ctypes.c_void_p(full.data_ptr() + 4 * n_grad), L.stream()),
-            "plnerf_mlp_bwd")
+        (grads,), (ws,) = _mlp_backward_launch([ctx], [g_raw])
         if timer is not None:
             ev[1].record()
         g_cam = None
@@ -488,7 +589,7 @@ class MlpFn(torch.autograd.Function):
         if ctx.in_grad:
             xyz_ch, dir_ch = int(ctx.net.input_ch), int(ctx.net.hip_view_ch)
             g_rows = torch.empty(n_rows, xyz_ch + dir_ch, device=dev, dtype=torch.float32)
-            L.check(L.lib().plnerf_mlp_input_grad(L.ptr_table(ctx.in_params, "params"), prec, xyz_ch, dir_ch, n_rows,
+            L.check(L.lib().plnerf_mlp_input_grad(L.ptr_table(ctx.in_params, "params"), ctx.prec, xyz_ch, dir_ch, n_rows,
                                                   L.dptr(ws), L.dptr(g_rows), L.stream()), "plnerf_mlp_input_grad")
             if ctx.in_emb_shape is not None:
                 g_embedded = g_rows.view(ctx.in_emb_shape) if ctx.needs_input_grad[2] else None

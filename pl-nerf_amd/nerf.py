@@ -11,6 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib as L
+from . import functional as Fn
 from .functional import MlpFn
 
 # The architecture the HIP kernels are specialised for: the reference's trunk (run_plnerf.py:784-825),
@@ -146,6 +147,13 @@ class NeRF(nn.Module):
         if not self.use_viewdirs:      # (see param_list; the reference ignores the view columns of x, if any)
             return trunk
         return trunk and 1 <= self.view_ch <= MAX_VIEW_CH
+
+    def is_native(self):
+        """The kernels' 24 parameter tensors ARE this module's nn.Parameters (the reference's own configuration: 8 x 256,
+        skip after layer 4, view directions) -- no padding / identity layers between them that autograd would have to
+        carry gradients through (param_list).  What functional.mlp_backward_multi needs to assign `.grad` directly."""
+        return (self.use_viewdirs and self.D == SUPPORTED["D"] and self.W == SUPPORTED["W"] and
+                self._skip_layout() == ("at", SUPPORTED["skips"][0]) and self.is_supported())
 
     def has_fused_encoding(self):
         """True when the kernel's own positional encoding can be this network's: 3 + 6 L position channels (L <= 10) and
@@ -337,6 +345,8 @@ class NeRF(nn.Module):
         if not self.use_viewdirs:      # the kernels' direction channels: zeros (their weights are zero as well)
             flat = torch.cat([flat[:, :self.input_ch], flat.new_zeros(flat.shape[0], self.hip_view_ch)], -1)
         out = MlpFn.apply(None, None, flat, cam, 1, self, torch.is_grad_enabled(), *self.param_list())
+        if Fn.MLP_TAPE is not None:
+            Fn.MLP_TAPE.outs.append(out)
         return self._outputs(out.reshape(*lead, 4))
 
     def query(self, pts, viewdirs, input_scale=1.0):
@@ -356,4 +366,6 @@ class NeRF(nn.Module):
             out = MlpFn.apply(pts.reshape(-1, 3), viewdirs, None, None, S, self, torch.is_grad_enabled(), *self.param_list())
         finally:
             self._query_scale = 1.0
+        if Fn.MLP_TAPE is not None:
+            Fn.MLP_TAPE.outs.append(out)
         return self._outputs(out.reshape(R, S, 4))

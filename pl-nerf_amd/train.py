@@ -134,6 +134,13 @@ class TrainStep:
         # and raises.  0 = never look (the caller does).
         self.range_check_every = int(range_check_every)
         self.seed = seed
+        # Both networks' backward as ONE launch sequence (functional.mlp_backward_multi -> plnerf_mlp_bwd_multi): autograd
+        # runs only as far as the two upstream gradients d loss / d raw (two plnerf_quad_bwd launches), then one gradient-
+        # chain grid and one launch of each weight-gradient kernel cover both networks (round 5: -0.15 ms of a 6.4 ms step,
+        # profiles/r05_merged_bwd_ab.txt).  Taken whenever the step has the reference's two native networks in a 16-bit
+        # mode (_merged_backward_ok); anything else goes through torch.autograd.backward as before.  PLNERF_MERGED_BWD=0 in
+        # the environment switches it off (A/B measurements).
+        self.merged_backward = os.environ.get("PLNERF_MERGED_BWD", "1") != "0"
         self.bucket = None
         if distributed and self.world > 1:
             # replicas must start from the same weights (create_nerf initialises from each process's own RNG, and a
@@ -203,10 +210,13 @@ class TrainStep:
         if self.draws is not None:
             self.draws.step, self.draws.ray_id0 = self.global_step, self.rank * n_local
             Fn.set_draw_source(self.draws)
+        tape = Fn.MlpTape() if self.merged_backward else None
+        Fn.MLP_TAPE = tape
         try:
             rgb, extras = self._render(H, W, K, rays, near, far, i < getattr(self.args, "constant_init", 0))
         finally:
             Fn.set_draw_source(prev)
+            Fn.MLP_TAPE = None
         rgb0 = extras.get('rgb0')
         self.optimizer.zero_grad()
         self.optimizer_coarse.zero_grad()
@@ -215,8 +225,11 @@ class TrainStep:
             # backward((rgb, rgb0), (d loss / d rgb, d loss / d rgb0)) is loss.backward()
             loss4, g_rgb, g_rgb0 = Fn.image_loss_and_grads(rgb, rgb0, target_s)
             loss, psnr = loss4[0], loss4[3]
-            torch.autograd.backward((rgb,) if rgb0 is None else (rgb, rgb0),
-                                    (g_rgb,) if rgb0 is None else (g_rgb, g_rgb0))
+            if tape is not None and rgb0 is not None and self._merged_backward_ok(tape):
+                self._backward_merged(tape, rgb, rgb0, g_rgb, g_rgb0)
+            else:
+                torch.autograd.backward((rgb,) if rgb0 is None else (rgb, rgb0),
+                                        (g_rgb,) if rgb0 is None else (g_rgb, g_rgb0))
         else:
             img_loss = img2mse(rgb, target_s)
             loss = img_loss if rgb0 is None else img_loss + img2mse(rgb0, target_s)
@@ -233,6 +246,38 @@ class TrainStep:
         if self.range_check_every and self.global_step % self.range_check_every == 0:
             self.check_range()
         return loss.detach(), psnr
+
+    def _merged_backward_ok(self, tape):
+        """One MlpFn forward per network (the batch fitted one launch each), coarse first, both networks native, in one
+        16-bit precision, every parameter trainable, no gradient wanted for the networks' inputs."""
+        if len(tape.outs) != 2 or len(self.nets) != 2 or self.nets[0] is self.nets[1]:
+            return False
+        ctxs = [o.grad_fn for o in tape.outs]
+        if any(c is None or getattr(c, "saved_acts", None) is None for c in ctxs):
+            return False
+        if ctxs[0].net is not self.nets[0] or ctxs[1].net is not self.nets[1]:
+            return False
+        return all(n.is_native() and n.precision in L.GUARDED_PRECISIONS and all(p.requires_grad for p in n.parameters())
+                   for n in self.nets) and self.nets[0].precision == self.nets[1].precision and \
+            not any(c.in_grad or c.n_cam or c.beta for c in ctxs)
+
+    def _backward_merged(self, tape, rgb, rgb0, g_rgb, g_rgb0):
+        """loss.backward() with the two networks' backward in one launch sequence: autograd from the two images down to
+        d loss / d raw of either network (plnerf_quad_bwd x 2; it does not enter the MlpFn nodes), then
+        functional.mlp_backward_multi; the gradients are assigned as autograd would have accumulated them into the
+        zeroed `.grad`s, and a data-parallel bucket is told that the two networks' gradients are complete."""
+        raw_c, raw_f = tape.outs
+        Fn.ABSMAX_LOG = log = []      # (each plnerf_quad_bwd leaves max |g_raw| as a by-product: no absmax pass, no memset)
+        try:
+            g_raw_f, g_raw_c = torch.autograd.grad((rgb, rgb0), (raw_f, raw_c), (g_rgb, g_rgb0))
+        finally:
+            Fn.ABSMAX_LOG = None
+        grads_c, grads_f = Fn.mlp_backward_multi([raw_c, raw_f], [g_raw_c, g_raw_f], log)
+        for net, grads in ((self.nets[0], grads_c), (self.nets[1], grads_f)):
+            for p, g in zip(net.param_list(), grads):
+                p.grad = g
+        if self.bucket is not None:
+            self.bucket.gradients_ready(self.nets)
 
     def check_range(self):
         """Look at the networks' range status words (one 4-byte read each).  Steps the guarded Adam kernels withheld are

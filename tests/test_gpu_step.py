@@ -574,10 +574,116 @@ def test_weight_gradients_do_not_depend_on_what_the_workspace_held(P, precision,
     for fill in (float("nan"), 0.0):
         ws = torch.full((L.lib().plnerf_mlp_bwd_workspace_bytes(n_rows, prec) // 4,), fill, device=dev())
         grads = [torch.full(tuple(s), float("nan"), device=dev()) for s in shapes]
-        L.check(L.lib().plnerf_mlp_bwd(L.dptr(packed), prec, L.dptr(g_raw), 63, 27, n_rows, L.dptr(saved), layout, None, 0.0,
+        L.check(L.lib().plnerf_mlp_bwd(L.dptr(packed), prec, L.dptr(g_raw), None, 63, 27, n_rows, L.dptr(saved), layout, None, 0.0,
                                        L.dptr(ws), L.ptr_table(grads, "grads"), None, L.stream()), "plnerf_mlp_bwd")
         torch.cuda.synchronize()
         results.append(grads)
     for (name, _), a, b in zip(net.named_parameters(), *results):
         assert torch.isfinite(a).all(), f"{name}: non-finite gradient entries out of a NaN-poisoned workspace"
         assert torch.equal(a, b), f"{name}: the gradient depends on the workspace's previous contents"
+
+
+# ----------------------------------------------------------------------------- both networks' backward in one launch sequence
+def test_merged_backward_equals_two_backwards(P):
+    """plnerf_mlp_bwd_multi (ABI 500): the coarse and the fine network's backward as ONE launch sequence -- one gradient-
+    chain grid, one launch of each weight-gradient kernel, the round of workgroups dealt out over the two networks by
+    rows -- against the two separate plnerf_mlp_bwd calls, through the C ABI on poisoned workspaces, at the benchmark's
+    sizes (262,144 + 786,432 rows), at ragged ones, and with the roles swapped.  The gradient chain's arithmetic does not
+    depend on the grid (dz planes bit-identical => bias gradients and head gradients bit-identical); the 256-wide weight
+    gradients sum their split-K partials over other row ranges (21 + 7 instead of 28 + 28), so they agree to fp32
+    summation order.  Also: max |g_raw| handed in (g_absmax) instead of found by the call's own pass = the same bits."""
+    import ctypes
+    from plnerf_amd import _lib as L
+    prec = L.PRECISION["f16x3"]
+    nets = [make_net(P, orc.closed_form_state_dict(k, False), "f16x3") for k in (0, 1)]
+    gen = torch.Generator().manual_seed(6)
+
+    def forward(net, n_rays, spr):
+        n_rows = n_rays * spr
+        pts = g((torch.rand(n_rows, 3, generator=gen) * 2 - 1) * 2.0)
+        vd = g(torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=gen), dim=-1))
+        g_raw = g(torch.randn(n_rows, 4, generator=gen) * 1e-3)
+        packed = net.packed_weights()
+        raw = torch.empty(n_rows, 4, device=dev())
+        saved = torch.empty(L.lib().plnerf_mlp_saved_bytes(n_rows, prec) // 4, device=dev())
+        L.check(L.lib().plnerf_mlp_fwd(L.dptr(packed), prec, L.dptr(pts), L.dptr(vd), None, 63, 27, n_rows, spr, 1.0, 0.0,
+                                       L.dptr(raw), L.dptr(saved), L.FWD_KERNEL, L.stream()), "plnerf_mlp_fwd")
+        return dict(packed=packed, g_raw=g_raw, n_rows=n_rows, saved=saved)
+    layout = L.lib().plnerf_mlp_saved_layout(prec, 0, L.FWD_KERNEL)
+    shapes = [p.shape for p in nets[0].parameters()]
+    names = [n for n, _ in nets[0].named_parameters()]
+    vp = lambda items: (ctypes.c_void_p * len(items))(*[None if x is None else x.value for x in items])
+
+    def fresh(job):
+        ws = torch.full((L.lib().plnerf_mlp_bwd_workspace_bytes(job["n_rows"], prec) // 4,), float("nan"), device=dev())
+        return ws, [torch.full(tuple(s), float("nan"), device=dev()) for s in shapes]
+
+    for sizes in ((4096 * 64, 4096 * 192), (4096 * 192, 4096 * 64), (1000 * 8, 37 * 8), (300 * 8, 90000 * 8)):
+        jobs = [forward(net, n // 8, 8) for net, n in zip(nets, sizes)]
+        single = []
+        for job in jobs:
+            ws, grads = fresh(job)
+            L.check(L.lib().plnerf_mlp_bwd(L.dptr(job["packed"]), prec, L.dptr(job["g_raw"]), None, 63, 27, job["n_rows"],
+                                           L.dptr(job["saved"]), layout, None, 0.0, L.dptr(ws), L.ptr_table(grads, "grads"), None,
+                                           L.stream()), "plnerf_mlp_bwd")
+            single.append((ws, grads))
+        for with_absmax in (False, True):
+            both = [fresh(job) for job in jobs]
+            am = [None, None]
+            if with_absmax:      # the maxima as fp32 bits in device words, as plnerf_quad_bwd's absmax_out leaves them
+                am = [job["g_raw"].abs().max().reshape(1).view(torch.int32) for job in jobs]
+            tails = torch.full((2, 4), -1.0, device=dev())
+            L.check(L.lib().plnerf_mlp_bwd_multi(
+                2, vp([L.dptr(j["packed"]) for j in jobs]), prec, vp([L.dptr(j["g_raw"]) for j in jobs]),
+                vp([L.dptr(a, "g_absmax", torch.int32) for a in am]), 63, 27, (ctypes.c_int * 2)(*[j["n_rows"] for j in jobs]),
+                vp([L.dptr(j["saved"]) for j in jobs]), (ctypes.c_int * 2)(layout, layout), None, 0.0,
+                vp([L.dptr(ws) for ws, _ in both]), L.ptr_table([t for _, gr in both for t in gr], "grads"),
+                vp([ctypes.c_void_p(tails[k].data_ptr()) for k in range(2)]), L.stream()), "plnerf_mlp_bwd_multi")
+            torch.cuda.synchronize()
+            assert tails[:, 0].tolist() == [0.0, 0.0]
+            worst = 0.0
+            for k, job in enumerate(jobs):
+                # the dz planes (the workspace's first section): the gradient chain is the same arithmetic in either grid
+                n_dz = 4864 * ((job["n_rows"] + 191) // 192 * 192) // 4
+                assert torch.equal(single[k][0][:n_dz].view(torch.int32), both[k][0][:n_dz].view(torch.int32)), (sizes, k, "dz planes")
+                for name, a, b in zip(names, single[k][1], both[k][1]):
+                    assert torch.isfinite(b).all(), (sizes, k, name)
+                    scale = float(a.abs().max()) + 1e-30
+                    err = float((a - b).abs().max()) / scale
+                    worst = max(worst, err)
+                    if name.endswith("bias") or name.startswith("alpha_linear") or name.startswith("rgb_linear"):
+                        assert torch.equal(a, b) or err <= 2e-6, (sizes, k, name, err)      # (column sums: per-range partials, other ranges)
+                    assert err <= 2e-5, (sizes, k, name, err)
+            print(f"merged vs separate backward, rows {sizes}, g_absmax handed in {with_absmax}: worst gradient difference "
+                  f"{worst:.2e} of max|g| (fp32 summation order of the split-K partials)")
+
+
+def test_training_step_with_merged_backward_equals_autograd_order(P):
+    """train.TrainStep's merged backward (autograd down to d loss / d raw of both networks with max |g_raw| as
+    plnerf_quad_bwd's by-product, then plnerf_mlp_bwd_multi, `.grad` assigned directly) against the same steps through
+    torch.autograd.backward (PLNERF_MERGED_BWD = 0's route): same losses to fp32 summation order, same weights after five
+    steps to an Adam step's rounding, every backward job took its maximum from the by-product."""
+    from plnerf_amd import functional as Fn
+    H = W = 200
+    K = [[280.0, 0, W / 2], [0, 280.0, H / 2], [0, 0, 1]]
+    image = g(torch.rand(H, W, 3, generator=torch.Generator().manual_seed(3)))
+    poses = [P.rays.pose_spherical(-180.0 + 90.0 * i, -30.0, 4.0)[:3, :4] for i in range(4)]
+
+    def run(merged):
+        args, kw, opt, opt_c = _nets(P)
+        ts = P.TrainStep(args, kw, opt, opt_c, distributed=False, seed=11)
+        ts.merged_backward = merged
+        hits0 = Fn.ABSMAX_HITS
+        losses = []
+        for step in range(5):
+            loss, _ = ts.step_view(H, W, K, poses[step % 4], image, near=2.0, far=6.0, n_rand=4096)
+            losses.append(float(loss))
+        return losses, [p.detach().clone() for n in ts.nets for p in n.parameters()], Fn.ABSMAX_HITS - hits0
+    l1, p1, hits1 = run(True)
+    l0, p0, hits0 = run(False)
+    assert hits1 == 10 and hits0 == 0, (hits1, hits0)
+    for a, b in zip(l1, l0):
+        assert abs(a - b) <= 2e-6 * max(1.0, abs(b)), (l1, l0)
+    worst = max(float((a - b).abs().max()) for a, b in zip(p1, p0))
+    print(f"merged vs autograd-order backward, 5 steps x 4096 rays: losses {l1[-1]:.7f} / {l0[-1]:.7f}, max parameter difference {worst:.2e}")
+    assert worst <= 2e-4, worst

@@ -10,6 +10,7 @@ from plnerf_amd import functional as Fn
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rays", type=int, default=262144)
+ap.add_argument("--reps", type=int, default=10)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 R, S, N = a.rays, 192, 128
@@ -18,7 +19,8 @@ rnd = lambda *s: torch.rand(*s, device=dev, generator=g)
 near, far = torch.full((R, 1), 2.0, device=dev), torch.full((R, 1), 6.0, device=dev)
 rays_o, rays_d = rnd(R, 3), torch.nn.functional.normalize(rnd(R, 3) - 0.5, dim=-1)
 
-def timeit(f, reps=10):
+def timeit(f, reps=None):
+    reps = reps or a.reps
     f(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
