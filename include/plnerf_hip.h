@@ -108,18 +108,17 @@ int plnerf_quad_fwd(const float* raw, const float* z, const float* near, const f
  * (depth_supervised_exps/run_nerf_sample_based_depth.py:923-934) -- g_tau, g_T [R,S+2]
  * (each may be NULL = zero).  disp_map's gradient is folded into g_depth/g_acc by the
  * caller.  g_raw [R,S,4].
- * absmax_out (may be NULL; ABI 500): max |g_raw| of this launch as a by-product, for the consumer that scales by it
- * (plnerf_mlp_bwd's g_absmax: the half dz planes' launch scale) -- one device uint64 that the kernel raises with
- * atomicMax to (absmax_tag << 32 | fp32 bits of the maximum).  The caller passes a tag larger than any it used on this
- * word before (a step counter): the word then needs no zeroing between launches, and its LOW 32 bits -- what
- * (const uint32_t*)absmax_out points at on this little-endian target -- are the maximum once the launch has finished
- * (0 if every element is zero; a NaN gives 0x7fc00000-class bits, which order above every finite value). */
+ * absmax_out (may be NULL; ABI 500): max |g_raw| as a by-product, for the consumer that scales by it (plnerf_mlp_bwd's
+ * g_absmax: the half dz planes' launch scale): [ceil(R / PLNERF_QUAD_RAYS_PER_GROUP)] uint32, one per workgroup of the
+ * launch = the fp32 bit pattern of the largest |g_raw| among that workgroup's rays (plain stores, every entry written; a
+ * NaN leaves NaN bits, which order above every finite value as unsigned integers). */
+#define PLNERF_QUAD_RAYS_PER_GROUP 4
 int plnerf_quad_bwd(const float* raw, const float* z, const float* near, const float* far,
                     const float* rays_d, const float* noise, int R, int S, int mode,
                     int color_mode, int white_bkgd, int farcolorfix, const float* g_rgb,
                     const float* g_depth, const float* g_acc, const float* g_weights,
-                    const float* g_tau, const float* g_T, float* g_raw, uint64_t* absmax_out,
-                    uint32_t absmax_tag, plnerf_stream_t stream);
+                    const float* g_tau, const float* g_T, float* g_raw, uint32_t* absmax_out,
+                    plnerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Hierarchical samplers.  `u` holds the uniform draws: [R,N] when u_row_stride == N, or
@@ -379,9 +378,10 @@ int plnerf_mlp_fwd(const void* packed, int precision, const float* pts, const fl
  * (plnerf_mlp_status_offset) is non-zero when the gradients are complete, else 0 -- a data-parallel caller puts it
  * behind the gradients in the buffer it all-reduces (SUM), so "some rank's forward left the half range" reaches
  * every rank with the gradient itself and can guard plnerf_adam_step there.
- * g_absmax (may be NULL; ABI 500; 16-bit modes without a density activation): one device uint32 that already holds
- * max |g_raw| as fp32 bits (plnerf_quad_bwd's absmax_out) -- the call then skips its own pass over g_raw. */
-int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, const uint32_t* g_absmax, int input_ch,
+ * g_absmax / n_absmax (may be NULL / 0; ABI 500; 16-bit modes without a density activation): n_absmax device uint32
+ * whose maximum (as unsigned integers) is the fp32 bit pattern of max |g_raw| -- plnerf_quad_bwd's absmax_out -- the call
+ * then skips its own pass over g_raw (and its memset): the gradient chain's workgroups take the maximum themselves. */
+int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, const uint32_t* g_absmax, int n_absmax, int input_ch,
                    int input_ch_views, int n_rows, const void* saved, int saved_layout,
                    const float* raw_out, float density_beta, void* workspace,
                    float* const* grads, float* status_out, plnerf_stream_t stream);
@@ -393,11 +393,12 @@ int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, const 
  * runs the jobs one after the other).  Separate calls end each kernel on a partial round of the 256 CUs and pay every
  * launch ramp twice: 0.14-0.16 ms of a 6.4 ms step (profiles/r05_merged_bwd_bound.txt).  Every array has n_jobs entries
  * (host memory, read during the call) and means what the argument of the same name means to plnerf_mlp_bwd; grads holds
- * n_jobs x 24 device pointers, job after job; g_absmax, raw_out and status_out may be NULL as a whole or per entry.
+ * n_jobs x 24 device pointers, job after job; g_absmax (with n_absmax), raw_out and status_out may be NULL as a whole or
+ * per entry.
  * plnerf_mlp_bwd(...) is plnerf_mlp_bwd_multi(1, ...), bit for bit. */
 #define PLNERF_MAX_BWD_JOBS 2
 int plnerf_mlp_bwd_multi(int n_jobs, const void* const* packed, int precision, const float* const* g_raw,
-                         const uint32_t* const* g_absmax, int input_ch, int input_ch_views, const int* n_rows,
+                         const uint32_t* const* g_absmax, const int* n_absmax, int input_ch, int input_ch_views, const int* n_rows,
                          const void* const* saved, const int* saved_layout, const float* const* raw_out,
                          float density_beta, void* const* workspace, float* const* grads,
                          float* const* status_out, plnerf_stream_t stream);

@@ -18,6 +18,7 @@ COLOR = {"midpoint": 0, "left": 1}
 PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3, "f16": 4}
 GUARDED_PRECISIONS = ("f16x3", "f16", "bf16x3", "bf16")      # modes whose kernels can set a bit of the range status word
 N_PARAM_TENSORS = 24
+QUAD_RAYS_PER_GROUP = 4                # PLNERF_QUAD_RAYS_PER_GROUP: rays per workgroup of plnerf_quad_bwd (its absmax_out)
 DEPTH_LOSS_WORKSPACE_BYTES = 4096      # PLNERF_DEPTH_LOSS_WORKSPACE_BYTES
 IMAGE_LOSS_WORKSPACE_BYTES = 4096      # PLNERF_IMAGE_LOSS_WORKSPACE_BYTES
 # plnerf_mlp_fwd's `fwd_kernel` argument (PLNERF_FWD_KERNEL_*).  The library has no setting of its own; this BINDING
@@ -37,7 +38,7 @@ SIGNATURES = {
     "plnerf_build_flags": (c_i, []),
     "plnerf_error_string": (ctypes.c_char_p, [c_i]),
     "plnerf_quad_fwd": (c_i, [c_f] * 6 + [c_i] * 6 + [c_f] * 7 + [c_s]),
-    "plnerf_quad_bwd": (c_i, [c_f] * 6 + [c_i] * 6 + [c_f] * 7 + [c_f, ctypes.c_uint32, c_s]),
+    "plnerf_quad_bwd": (c_i, [c_f] * 6 + [c_i] * 6 + [c_f] * 7 + [c_f, c_s]),
     "plnerf_sample_const": (c_i, [c_f] * 3 + [c_i] * 4 + [c_f] * 2 + [c_s]),
     "plnerf_sample_const_bwd": (c_i, [c_f] * 3 + [c_i] + [c_f] * 2 + [c_i] * 3 + [c_f] + [c_s]),
     "plnerf_sample_pl": (c_i, [c_f] * 7 + [c_i] * 4 + [ctypes.c_float] * 2 + [c_f] * 5 + [c_s]),
@@ -66,11 +67,11 @@ SIGNATURES = {
     "plnerf_mlp_saved_bytes": (ctypes.c_size_t, [c_i, c_i]),
     "plnerf_mlp_bwd_workspace_bytes": (ctypes.c_size_t, [c_i, c_i]),
     "plnerf_mlp_fwd": (c_i, [c_f, c_i, c_f, c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_float, ctypes.c_float, c_f, c_f, c_i, c_s]),
-    "plnerf_mlp_bwd": (c_i, [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_f, c_i, c_f, ctypes.c_float, c_f, ctypes.POINTER(ctypes.c_void_p),
-                             c_f, c_s]),
+    "plnerf_mlp_bwd": (c_i, [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_f, ctypes.c_float, c_f,
+                             ctypes.POINTER(ctypes.c_void_p), c_f, c_s]),
     "plnerf_mlp_bwd_multi": (c_i, [c_i, ctypes.POINTER(ctypes.c_void_p), c_i, ctypes.POINTER(ctypes.c_void_p),
-                                   ctypes.POINTER(ctypes.c_void_p), c_i, c_i, ctypes.POINTER(ctypes.c_int),
-                                   ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int),
+                                   ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), c_i, c_i,
+                                   ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int),
                                    ctypes.POINTER(ctypes.c_void_p), ctypes.c_float, ctypes.POINTER(ctypes.c_void_p),
                                    ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_s]),
     "plnerf_mlp_saved_layout": (c_i, [c_i, c_i, c_i]),

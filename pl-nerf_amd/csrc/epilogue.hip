@@ -52,7 +52,8 @@ struct EpiArgs {
 // HYP = true: raw2outputs + the *_return_u sampler of the depth-supervised variant's LAST stage
 // (run_nerf_sample_based_depth.py:923-934): the samples are the depth hypotheses pred_hyp -- not clamped, kept with their
 // indices and draws for the sampler's backward -- and z_std is theirs (:934); nothing is sorted or positioned.
-template <int KPL, bool HYP>
+// KPL: registers per lane of the general sort network (64 KPL >= S + N); KS: of the samples' own network (64 KS >= N)
+template <int KPL, bool HYP, int KS = KPL>
 __global__ __launch_bounds__(256) void coarse_epilogue_kernel(const EpiArgs a) {
     constexpr int MODE = PLNERF_MODE_LINEAR;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -143,8 +144,8 @@ __global__ __launch_bounds__(256) void coarse_epilogue_kernel(const EpiArgs a) {
         const int di = below < S ? below : S;
         const float d = tau[di + 1] - tau[di];
         float out = (d < zt && d > -zt) ? s0 : -1.0f;
-        if (d >= zt) out = invert_segment(s0, s1, T0, tau0, tau1, u, eps, true);
-        if (d <= -zt) out = invert_segment(s0, s1, T0, tau0, tau1, u, eps, false);
+        const bool rising = d >= zt;
+        if (rising || d <= -zt) out = invert_segment(s0, s1, T0, tau0, tau1, u, eps, rising);      // (one evaluation, operands selected per lane)
         if (out != out) out = s0;
         if constexpr (HYP) {
             if (live) {
@@ -171,29 +172,77 @@ __global__ __launch_bounds__(256) void coarse_epilogue_kernel(const EpiArgs a) {
     if (live && lane == 0) a.z_std[ray] = (float)sqrt(sq / (double)N);
     if constexpr (HYP) return;
 
-    // ---- sort(cat(z, samples)) in registers (merge_sort_kernel's network) ----
-    uint32_t x[KPL];
+    // ---- sort(cat(z, samples)) ----
+    // The coarse depths are ascending in every reference call (stratified bins, run_plnerf.py:683-705) -- checked per ray,
+    // else the general network below.  Then only the N samples need sorting (the bitonic network on KS registers: 28 stages
+    // for 128 keys instead of 36 over 256), and the two ascending runs merge by rank: two binary searches per element in
+    // place of the network's last eight stages.  Same multiset, same order: the same bits as sort(cat()) (round 5; the
+    // launch was VALU-issue bound, profiles/r05_pmc_stream_kernels_262144rays.txt).
+    uint32_t xs[KS];
 #pragma unroll
-    for (int r = 0; r < KPL; ++r) {
-        const int p = 64 * r + lane;
-        uint32_t key = 0xFFFFFFFFu;
-        if (p < S) key = sort_key(zk[p + 1]);
-        else if (p < NF) key = sort_key(smp[p - S]);
-        x[r] = key;
+    for (int r = 0; r < KS; ++r) {
+        const int q = 64 * r + lane;
+        xs[r] = q < N ? sort_key(smp[q]) : 0xFFFFFFFFu;
     }
-    bitonic_sort_regs<KPL>(x, lane);
-    __syncthreads();                  // every read of col / smp is done: the sorted row may overwrite them
-    float* zs = col;                  // NF <= 3 S + K + K + N floats from col on (col, Tr, cdf, smp are contiguous)
+    bitonic_sort_regs<KS>(xs, lane);
+    bool asc = true;
+    for (int p = lane; p + 1 < S; p += 64) asc = asc && (sort_key(zk[p + 1]) <= sort_key(zk[p + 2]));
+    const bool merge = __all(asc) != 0;           // (per wave = per ray; every path below meets the same barriers)
+    __syncthreads();                              // the sampler's and z_std's reads of tau / smp are done
+    uint32_t* zkey = reinterpret_cast<uint32_t*>(tau);
+    uint32_t* skey = reinterpret_cast<uint32_t*>(smp);
+    if (merge) {
+        for (int p = lane; p < S; p += 64) zkey[p] = sort_key(zk[p + 1]);
 #pragma unroll
-    for (int r = 0; r < KPL; ++r) {
-        const int p = 64 * r + lane;
-        if (p < NF) {
-            const float v = sort_unkey(x[r]);
-            zs[p] = v;
-            if (live) a.z_fine[(size_t)ray * NF + p] = v;
+        for (int r = 0; r < KS; ++r) {
+            const int q = 64 * r + lane;
+            if (q < N) skey[q] = xs[r];
         }
     }
     __syncthreads();
+    int rank_s[KS];
+    uint32_t x[KPL];
+    if (merge) {
+#pragma unroll
+        for (int r = 0; r < KS; ++r) rank_s[r] = 64 * r + lane + count_le(zkey, S, xs[r]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) {
+            const int p = 64 * r + lane;
+            uint32_t key = 0xFFFFFFFFu;
+            if (p < S) key = sort_key(zk[p + 1]);
+            else if (p < NF) key = sort_key(smp[p - S]);
+            x[r] = key;
+        }
+        bitonic_sort_regs<KPL>(x, lane);
+    }
+    float* zs = col;                  // NF <= 3 S + K + K + N floats from col on (col, Tr, cdf, smp are contiguous)
+    if (merge) {
+        // (the z elements' ranks read skey, which the sorted row may overwrite: all of them before the barrier)
+        int rank_z[KPL];
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) {
+            const int p = 64 * r + lane;
+            rank_z[r] = p < S ? p + count_lt(skey, N, zkey[p]) : -1;
+        }
+        __syncthreads();              // every read of col / smp / tau is done: the sorted row may overwrite them
+#pragma unroll
+        for (int r = 0; r < KPL; ++r)
+            if (rank_z[r] >= 0) zs[rank_z[r]] = zk[64 * r + lane + 1];
+#pragma unroll
+        for (int r = 0; r < KS; ++r)
+            if (64 * r + lane < N) zs[rank_s[r]] = sort_unkey(xs[r]);
+    } else {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) {
+            const int p = 64 * r + lane;
+            if (p < NF) zs[p] = sort_unkey(x[r]);
+        }
+    }
+    __syncthreads();
+    if (live)
+        for (int p = lane; p < NF; p += 64) a.z_fine[(size_t)ray * NF + p] = zs[p];
     if (!live) return;
     // ---- positions of the merged samples ----
     const float o[3] = {a.rays_o[3 * (size_t)ray], a.rays_o[3 * (size_t)ray + 1], a.rays_o[3 * (size_t)ray + 2]};
@@ -219,12 +268,12 @@ __global__ __launch_bounds__(256) void coarse_epilogue_kernel(const EpiArgs a) {
     }
 }
 
-template <int KPL, bool HYP = false>
+template <int KPL, bool HYP = false, int KS = KPL>
 int launch(const EpiArgs& a, size_t lds, hipStream_t st) {
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)coarse_epilogue_kernel<KPL, HYP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)coarse_epilogue_kernel<KPL, HYP, KS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-    hipLaunchKernelGGL((coarse_epilogue_kernel<KPL, HYP>), dim3((a.R + WAVES - 1) / WAVES), dim3(WAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((coarse_epilogue_kernel<KPL, HYP, KS>), dim3((a.R + WAVES - 1) / WAVES), dim3(WAVES * 64), lds, st, a);
     PLNERF_CHECK_LAUNCH();
     return PLNERF_OK;
 }
@@ -260,9 +309,10 @@ extern "C" int plnerf_coarse_epilogue(const float* raw, const float* z, const fl
     if (lds > 160 * 1024) return PLNERF_ERANGE;
     hipStream_t st = (hipStream_t)stream;
     const int nf = S + N;
+    // (KS: the samples' own network; the small shapes get every size, the large ones sort their samples on the full width)
     if (nf <= 64) return launch<1>(a, lds, st);
-    if (nf <= 128) return launch<2>(a, lds, st);
-    if (nf <= 256) return launch<4>(a, lds, st);
+    if (nf <= 128) return N <= 64 ? launch<2, false, 1>(a, lds, st) : launch<2>(a, lds, st);
+    if (nf <= 256) return N <= 64 ? launch<4, false, 1>(a, lds, st) : (N <= 128 ? launch<4, false, 2>(a, lds, st) : launch<4>(a, lds, st));
     if (nf <= 512) return launch<8>(a, lds, st);
     return launch<16>(a, lds, st);
 }

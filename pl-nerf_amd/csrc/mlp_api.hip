@@ -134,8 +134,8 @@ extern "C" int plnerf_mlp_fwd(const void* packed, int precision, const float* pt
 // reduce launch of the weight-gradient stage cover every job (16-bit modes; the exact-fp32 mode runs the jobs one after
 // the other).  plnerf_mlp_bwd is the one-job case.
 extern "C" int plnerf_mlp_bwd_multi(int n_jobs, const void* const* packed, int precision, const float* const* g_raw,
-                                    const uint32_t* const* g_absmax, int input_ch, int input_ch_views,
-                                    const int* n_rows, const void* const* saved, const int* saved_layout,
+                                    const uint32_t* const* g_absmax, const int* n_absmax, int input_ch,
+                                    int input_ch_views, const int* n_rows, const void* const* saved, const int* saved_layout,
                                     const float* const* raw_out, float density_beta, void* const* workspace,
                                     float* const* grads, float* const* status_out, plnerf_stream_t stream) {
     if (n_jobs < 1 || n_jobs > PLNERF_MAX_BWD_JOBS) return PLNERF_EINVAL;
@@ -178,21 +178,26 @@ extern "C" int plnerf_mlp_bwd_multi(int n_jobs, const void* const* packed, int p
     impl::WgradJob wj[PLNERF_MAX_BWD_JOBS];
     for (int j = 0; j < n_jobs; ++j) {
         unsigned char* ws = (unsigned char*)workspace[j];
-        const unsigned* gmax = (unsigned*)(ws + impl::h16_dz_bytes(n_rows[j]));
+        unsigned* gmax = (unsigned*)(ws + impl::h16_dz_bytes(n_rows[j]));
+        const unsigned* cand = nullptr;
+        int n_cand = 0;
         float* partials = (float*)(ws + impl::h16_dz_bytes(n_rows[j]) + lay::WSH_SCALARS_BYTES);
         const float* g = g_raw[j];
         int rc = PLNERF_OK;
         if (act) {      // one pass: the activation's derivative and the launch scale's maximum
             float* g_eff = (float*)((unsigned char*)partials + part_bytes);
-            rc = impl::absmax_act(g, raw_out[j], density_beta, n_rows[j], g_eff, const_cast<unsigned*>(gmax), st);
+            rc = impl::absmax_act(g, raw_out[j], density_beta, n_rows[j], g_eff, gmax, st);
             g = g_eff;
-        } else if (g_absmax && g_absmax[j]) {
-            gmax = g_absmax[j];      // the caller's producer kernel left it (plnerf_quad_bwd's absmax_out): no pass, no memset
+        } else if (g_absmax && g_absmax[j] && n_absmax && n_absmax[j] > 0) {
+            // the caller's producer kernel left the candidates (plnerf_quad_bwd's absmax_out): no pass, no memset -- the
+            // gradient chain's workgroups take their maximum and leave it in the workspace's word for the kernels behind
+            cand = g_absmax[j];
+            n_cand = n_absmax[j];
         } else {
-            rc = impl::absmax(g, (size_t)n_rows[j] * 4, const_cast<unsigned*>(gmax), st);
+            rc = impl::absmax(g, (size_t)n_rows[j] * 4, gmax, st);
         }
         if (rc) return rc;
-        dj[j] = impl::DgradJob{packed[j], ns_of(precision), g, n_rows[j], saved[j], ws, gmax};
+        dj[j] = impl::DgradJob{packed[j], ns_of(precision), g, n_rows[j], saved[j], ws, gmax, cand, n_cand};
         wj[j] = impl::WgradJob{g, n_rows[j], saved[j], ws, gmax, partials, grads + j * PLNERF_N_PARAM_TENSORS, input_ch,
                                input_ch_views, saved_layout[j], status_word(const_cast<void*>(packed[j]), precision),
                                status_out ? status_out[j] : nullptr};
@@ -202,12 +207,12 @@ extern "C" int plnerf_mlp_bwd_multi(int n_jobs, const void* const* packed, int p
     return impl::wgrad_h16_multi(n_jobs, wj, st);
 }
 
-extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, const uint32_t* g_absmax, int input_ch,
-                              int input_ch_views, int n_rows, const void* saved, int saved_layout,
+extern "C" int plnerf_mlp_bwd(const void* packed, int precision, const float* g_raw, const uint32_t* g_absmax, int n_absmax,
+                              int input_ch, int input_ch_views, int n_rows, const void* saved, int saved_layout,
                               const float* raw_out, float density_beta, void* workspace,
                               float* const* grads, float* status_out, plnerf_stream_t stream) {
     if (!grads) return PLNERF_EINVAL;
-    return plnerf_mlp_bwd_multi(1, &packed, precision, &g_raw, &g_absmax, input_ch, input_ch_views, &n_rows, &saved,
+    return plnerf_mlp_bwd_multi(1, &packed, precision, &g_raw, &g_absmax, &n_absmax, input_ch, input_ch_views, &n_rows, &saved,
                                 &saved_layout, &raw_out, density_beta, &workspace, grads, &status_out, stream);
 }
 

@@ -53,7 +53,9 @@ struct DgradJob {
     int n_rows;
     const void* saved;
     void* dz;
-    const unsigned* gmax;
+    unsigned* gmax;           // the workspace's max |g_raw| word: holds it already, or (n_cand > 0) is written by the launch
+    const unsigned* cand;     // n_cand candidates whose maximum is that word, or nullptr / 0
+    int n_cand;
 };
 // gradient with respect to the embedded input rows, from the dz planes a finished plnerf_mlp_bwd left in its workspace
 int input_grad(const float* const* params, int n_rows, const void* dz, const unsigned* gmax, bool h16, int xyz_ch,

@@ -41,10 +41,9 @@ struct QuadArgs {
     const float* g_tau;   // linear mode: upstream gradient of the returned tau [R,S+2] (or nullptr)
     const float* g_T;     // linear mode: upstream gradient of the returned T   [R,S+2] (or nullptr)
     float* g_raw;
-    // backward by-product (may be null): max |g_raw| of the launch as (tag << 32 | fp32 bits), raised with atomicMax --
-    // the half dz planes' launch scale, which plnerf_mlp_bwd otherwise finds with a pass of its own over g_raw
-    unsigned long long* absmax_out;
-    unsigned absmax_tag;
+    // backward by-product (may be null): max |g_raw| of each workgroup's rays as fp32 bits, [ceil(R / WAVES)] -- the
+    // candidates of the half dz planes' launch scale, which plnerf_mlp_bwd otherwise finds with a pass of its own over g_raw
+    unsigned* absmax_out;
 };
 
 template <int MODE>
@@ -124,6 +123,7 @@ __global__ __launch_bounds__(256) void quad_fwd_kernel(QuadArgs a) {
 template <int MODE>
 __global__ __launch_bounds__(256) void quad_bwd_kernel(QuadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ unsigned wave_max_bits[WAVES];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int ray = blockIdx.x * WAVES + wave;
     const bool live = ray < a.R;
@@ -245,12 +245,20 @@ __global__ __launch_bounds__(256) void quad_bwd_kernel(QuadArgs a) {
                 const float o = __shfl_xor(gmax, d);
                 gmax = (o > gmax || o != o) ? o : gmax;
             }
-            if (lane == 0 && gmax != 0.0f) {
-                // one atomic per ray at most: skipped where the word already holds this launch's tag with a larger value
-                // (atomics on one address serialise in the L2; the plain load ahead of it is what keeps them rare)
-                const unsigned long long v = ((unsigned long long)a.absmax_tag << 32) | (unsigned long long)__float_as_uint(gmax);
-                if (__builtin_nontemporal_load(a.absmax_out) < v) atomicMax(a.absmax_out, v);
-            }
+            if (lane == 0) wave_max_bits[wave] = __float_as_uint(gmax);
+        }
+    }
+    if (a.absmax_out) {
+        // One plain store per workgroup, no atomic: 4096 atomicMax on one address cost the launch 46 us of serialised L2
+        // round trips (14 -> 60 us, round 5) -- every workgroup of this grid is resident at once, so "skip if the word
+        // already holds more" skips nothing.  The consumer (the dgrad kernel's prologue) takes the maximum of the array.
+        if (!live && lane == 0) wave_max_bits[wave] = 0u;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned m = wave_max_bits[0];      // (non-negative floats and NaNs order as unsigned integers; a NaN sticks)
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) m = wave_max_bits[w] > m ? wave_max_bits[w] : m;
+            a.absmax_out[blockIdx.x] = m;
         }
     }
 }
@@ -306,8 +314,8 @@ extern "C" int plnerf_quad_bwd(const float* raw, const float* z, const float* ne
                                const float* rays_d, const float* noise, int R, int S, int mode,
                                int color_mode, int white_bkgd, int farcolorfix, const float* g_rgb,
                                const float* g_depth, const float* g_acc, const float* g_weights,
-                               const float* g_tau, const float* g_T, float* g_raw, uint64_t* absmax_out,
-                               uint32_t absmax_tag, plnerf_stream_t stream) {
+                               const float* g_tau, const float* g_T, float* g_raw, uint32_t* absmax_out,
+                               plnerf_stream_t stream) {
     int rc = check_common(raw, z, near, far, rays_d, R, S, mode, color_mode);
     if (rc) return rc;
     if (R == 0) return PLNERF_OK;
@@ -317,7 +325,7 @@ extern "C" int plnerf_quad_bwd(const float* raw, const float* z, const float* ne
     a.raw = raw; a.z = z; a.near = near; a.far = far; a.rays_d = rays_d; a.noise = noise;
     a.R = R; a.S = S; a.color_mode = color_mode; a.white_bkgd = white_bkgd; a.farcolorfix = farcolorfix;
     a.g_rgb = g_rgb; a.g_depth = g_depth; a.g_acc = g_acc; a.g_weights = g_weights; a.g_tau = g_tau; a.g_T = g_T; a.g_raw = g_raw;
-    a.absmax_out = (unsigned long long*)absmax_out; a.absmax_tag = absmax_tag;
+    a.absmax_out = absmax_out;
     a.lds_stride = ((5 * S + 4 + 4 * (S + 2)) + 3) & ~3;
     const size_t lds = (size_t)WAVES * a.lds_stride * sizeof(float);
     dim3 grid((R + WAVES - 1) / WAVES), block(WAVES * 64);

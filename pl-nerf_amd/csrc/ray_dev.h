@@ -97,19 +97,21 @@ __device__ __forceinline__ int upper_bound(const float* cdf, int len, float u) {
 }
 
 // Closed-form inverse of T0 * exp(-(tau0 t + (tau1-tau0) t^2 / (2 (s1-s0)))) = 1-u on
-// one interval, with the reference's epsilon guards, op for op.
+// one interval, with the reference's epsilon guards, op for op (run_nerf_helpers.py:340-349 rising, 352-361 falling).
+// `rising` is a per-lane value: the two directions differ only in which operand of a subtraction comes first and in the
+// sign of one addend, so ONE evaluation with selected operands serves a wave whose lanes go both ways -- one logf, one
+// sqrtf, two divisions per lane instead of two of each under divergent branches (round 5; every operation is the
+// direction's own, so the bits are the reference's either way).
 __device__ __forceinline__ float invert_segment(float s0, float s1, float T0, float tau0, float tau1,
                                                 float u, float eps, bool rising) {
     const float ln_term = -logf(tmax(eps, (1.0f - u) / tmax(eps, T0)));
     const float span = tmax(eps, s1 - s0);
-    float t;
-    if (rising) {
-        const float disc = tau0 * tau0 + (2.0f * (tau1 - tau0) * ln_term) / span;
-        t = ((s1 - s0) * (-tau0 + sqrtf(tmax(eps, disc)))) / tmax(eps, tau1 - tau0);
-    } else {
-        const float disc = tau0 * tau0 - (2.0f * (tau0 - tau1) * ln_term) / span;
-        t = ((s1 - s0) * (tau0 - sqrtf(tmax(eps, disc)))) / tmax(eps, tau0 - tau1);
-    }
+    const float dt = rising ? tau1 - tau0 : tau0 - tau1;              // the direction's positive slope
+    const float q = (2.0f * dt * ln_term) / span;
+    const float disc = rising ? tau0 * tau0 + q : tau0 * tau0 - q;
+    const float sq = sqrtf(tmax(eps, disc));
+    const float num = rising ? -tau0 + sq : tau0 - sq;
+    float t = ((s1 - s0) * num) / tmax(eps, dt);
     t = tmin(tmax(t, eps), s1 - s0);   // torch.clamp(t, eps, s1-s0)
     return s0 + t;
 }
@@ -159,6 +161,28 @@ __device__ __forceinline__ void bitonic_sort_regs(uint32_t (&x)[KPL], const int 
             }
         }
     }
+}
+
+// Positions in an ASCENDING run of keys a[0..n): how many are < k (count_lt) / <= k (count_le).  Two ascending runs merge by
+// rank with these: an element's place = its index in its own run + the other run's count in front of it (ties: the first
+// run's element first), a permutation of 0 .. n1 + n2 - 1.
+__device__ __forceinline__ int count_lt(const uint32_t* a, int n, uint32_t k) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < k) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ int count_le(const uint32_t* a, int n, uint32_t k) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] <= k) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
 }
 
 }  // namespace plnerf

@@ -264,8 +264,8 @@ __global__ __launch_bounds__(256) void sample_pl_kernel(SamplePlArgs a) {
         const int di = below < S ? below : S;               // H4: reference reads out of bounds at u == 1
         const float d = tau[di + 1] - tau[di];
         float out = (d < zt && d > -zt) ? s0 : -1.0f;
-        if (d >= zt) out = invert_segment(s0, s1, T0, tau0, tau1, u, eps, true);
-        if (d <= -zt) out = invert_segment(s0, s1, T0, tau0, tau1, u, eps, false);
+        const bool rising = d >= zt;
+        if (rising || d <= -zt) out = invert_segment(s0, s1, T0, tau0, tau1, u, eps, rising);      // (one evaluation, operands selected per lane)
         if (out != out) out = s0;
         const size_t o = (size_t)ray * a.N + k;
         a.samples[o] = out;

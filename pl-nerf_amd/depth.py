@@ -526,6 +526,8 @@ class DepthTrainStep:
         self.bucket = None
         self.rank = torch.distributed.get_rank() if distributed else 0
         self.draws = Fn.DrawSource(seed=seed) if counter_rng else None
+        # both networks' backward as one launch sequence, as train.TrainStep (train.backward_merged)
+        self.merged_backward = os.environ.get("PLNERF_MERGED_BWD", "1") != "0"
         if distributed and torch.distributed.get_world_size() > 1:
             dp.broadcast_parameters(nets)      # replicas start from rank 0's weights (see train.TrainStep)
             dp.broadcast_optimizer_state([optimizer])
@@ -550,11 +552,14 @@ class DepthTrainStep:
         if self.draws is not None and ray_batch.is_cuda:
             self.draws.step, self.draws.ray_id0 = self.global_step, self.rank * ray_batch.shape[0]
             Fn.set_draw_source(self.draws)
+        tape = Fn.MlpTape() if self.merged_backward else None
+        Fn.MLP_TAPE = tape
         try:
             out = render_rays(ray_batch, retraw=True, is_joint=getattr(a, "is_joint", False), cached_u=cached_u,
                               quad_solution_v2=getattr(a, "quad_solution_v2", False), pytest=pytest, **kw)
         finally:
             Fn.set_draw_source(prev)
+            Fn.MLP_TAPE = None
         self.optimizer.zero_grad()
         carve = getattr(a, "space_carving_weight", 0.) > 0. and self.global_step + 1 > getattr(a, "warm_start_nerf", 0)
         rgb, rgb0 = out['rgb_map'], out.get('rgb0')
@@ -569,7 +574,11 @@ class DepthTrainStep:
                 is_joint=getattr(a, "is_joint", False))
             loss, img_loss, sc = loss5[0], loss5[1], loss5[3]
             roots = [(rgb, g_rgb)] + ([(rgb0, g_rgb0)] if rgb0 is not None else []) + ([(hyp, g_hyp)] if carve else [])
-            torch.autograd.backward(tuple(r for r, _ in roots), tuple(gr for _, gr in roots))
+            from .train import backward_merged, merged_backward_ok
+            if tape is not None and rgb0 is not None and merged_backward_ok(tape, self.nets):
+                backward_merged(tape, self.nets, [r for r, _ in roots], [gr for _, gr in roots], self.bucket)
+            else:
+                torch.autograd.backward(tuple(r for r, _ in roots), tuple(gr for _, gr in roots))
         else:
             img_loss = torch.mean((rgb - target_s) ** 2)
             loss = img_loss

@@ -83,6 +83,8 @@ class GradientBucket:
         self._tails = {}         # module index -> tail view of the last finished exchange
         self._hooks = []
         self.flat = None         # fallback bucket, allocated on first use
+        for m in self.modules:      # functional._grad_buffer then leaves each backward's flat buffer (with its tail) on the module
+            m.__dict__["_wants_grad_flat"] = True
         if overlap and dist.is_initialized() and dist.get_world_size(group) > 1:
             for mi, m in enumerate(self.modules):
                 for p in m.parameters():
@@ -191,6 +193,7 @@ class GradientBucket:
             work, flat, tail = self._works.pop(mi)
             work.wait()
             self._tails[mi] = tail
+            self.modules[mi].__dict__.pop("_grad_flat", None)      # (the tail view keeps the buffer alive as long as it is the guard)
             if not deferred:
                 (flat if tail is None else flat[:-self.TAIL]).mul_(1.0 / world)
             self.collectives += 1

@@ -106,35 +106,17 @@ class QuadratureFn(torch.autograd.Function):
         return g_raw, None, None, None, None, None, None, None, None, None
 
 
-class _AbsmaxWords:
-    """plnerf_quad_bwd leaves max |g_raw| of its launch in a 64-bit device word as (tag << 32 | fp32 bits) (atomicMax with a
-    tag that grows from call to call, so a word needs no zeroing); plnerf_mlp_bwd takes the low half as its `g_absmax` and
-    skips its own pass over g_raw.  A ring of words per device: a word is reused after RING further calls, long after the
-    backward that consumed it was enqueued (same stream)."""
-    RING = 16
-
-    def __init__(self):
-        self.words, self.count = {}, 0
-
-    def next(self, device):
-        w = self.words.get(device)
-        if w is None:
-            w = self.words[device] = torch.zeros(self.RING, device=device, dtype=torch.int64)
-        self.count += 1
-        slot = self.count % self.RING
-        return ctypes.c_void_p(w.data_ptr() + 8 * slot), self.count & 0xFFFFFFFF, w.view(torch.int32)[2 * slot:2 * slot + 1]
-
-
-_ABSMAX = _AbsmaxWords()
 # Armed (a list) by a caller that runs plnerf_quad_bwd and the MLP backward itself, back to back (train.TrainStep's merged
-# backward): every plnerf_quad_bwd then leaves its by-product and logs (g_raw.data_ptr(), the word's int32 view) here, and
-# the caller hands the matching views to mlp_backward_multi.  None: no by-product is asked for.
+# backward): every plnerf_quad_bwd then leaves its by-product and logs (g_raw.data_ptr(), the int32 tensor of maxima) here, and
+# the caller hands the matching tensors to mlp_backward_multi.  None: no by-product is asked for.  (The by-product: one
+# uint32 per workgroup of the launch = the fp32 bits of the largest |g_raw| among its rays; plnerf_mlp_bwd takes the array
+# as `g_absmax` and skips its own pass over g_raw and its memset.)
 ABSMAX_LOG = None
 
 
 def _quad_backward(saved, cfg, g_rgb, g_disp, g_acc, g_w, g_depth, g_tau, g_T):
     """plnerf_quad_bwd from the tensors a quadrature forward saved (shared by QuadratureFn and CoarseEpilogueFn).  With
-    ABSMAX_LOG armed the launch also leaves max |g_raw| in a device word (see _AbsmaxWords) and logs it."""
+    ABSMAX_LOG armed the launch also leaves its workgroups' max |g_raw| in a tensor and logs it."""
     raw_c, z_c, near_c, far_c, d_c, noise_c, depth, acc = saved
     mode, color_mode, white_bkgd, farcolorfix, has_noise = cfg
     R, S = z_c.shape
@@ -157,14 +139,16 @@ def _quad_backward(saved, cfg, g_rgb, g_disp, g_acc, g_w, g_depth, g_tau, g_T):
     g_T = None if (g_T is None or mode != "linear") else _f32c(g_T)
     g_raw = torch.empty(R, S, 4, device=dev)
     if R > 0:
-        word, tag, view = _ABSMAX.next(dev) if ABSMAX_LOG is not None else (None, 0, None)
+        cand = None
+        if ABSMAX_LOG is not None:
+            cand = torch.empty((R + L.QUAD_RAYS_PER_GROUP - 1) // L.QUAD_RAYS_PER_GROUP, device=dev, dtype=torch.int32)
         L.check(L.lib().plnerf_quad_bwd(
           L.dptr(raw_c), L.dptr(z_c), L.dptr(near_c), L.dptr(far_c), L.dptr(d_c),
           L.dptr(noise_c) if has_noise else None, R, S, L.MODE[mode], L.COLOR[color_mode],
           int(white_bkgd), int(farcolorfix), L.dptr(g_rgb), L.dptr(g_depth), L.dptr(g_acc), L.dptr(g_w),
-          L.dptr(g_tau), L.dptr(g_T), L.dptr(g_raw), word, tag, L.stream()), "plnerf_quad_bwd")
-        if view is not None:
-            ABSMAX_LOG.append((g_raw.data_ptr(), view))
+          L.dptr(g_tau), L.dptr(g_T), L.dptr(g_raw), L.dptr(cand, "absmax_out", torch.int32), L.stream()), "plnerf_quad_bwd")
+        if cand is not None:
+            ABSMAX_LOG.append((g_raw.data_ptr(), cand))
     return g_raw
 
 
@@ -419,15 +403,16 @@ def _grad_buffer(ctx, dev, zero=False):
     sizes = [int(torch.Size(sh).numel()) for sh in ctx.param_shapes]
     n_grad = sum(sizes)
     full = (torch.zeros if zero else torch.empty)(n_grad + GRAD_TAIL, device=dev, dtype=torch.float32)
-    ctx.net.__dict__["_grad_flat"] = full
+    if ctx.net.__dict__.get("_wants_grad_flat"):      # (a dp.GradientBucket is attached: it exchanges the buffer WITH its tail,
+        ctx.net.__dict__["_grad_flat"] = full         #  and lets go of this reference once it has -- GradientBucket.finish)
     return [t.view(sh) for t, sh in zip(full[:n_grad].split(sizes), ctx.param_shapes)], full
 
 
 def _mlp_backward_launch(ctxs, g_raws, absmax_log=None):
     """plnerf_mlp_bwd_multi over the saved state of one or two MlpFn forwards (the same precision, input widths and
-    density activation): one launch sequence for all of them.  absmax_log: [(g_raw.data_ptr(), word view)] of the
+    density activation): one launch sequence for all of them.  absmax_log: [(g_raw.data_ptr(), maxima tensor)] of the
     plnerf_quad_bwd launches that produced these g_raws in THIS backward pass (ABSMAX_LOG), or None.  Returns ([the 24
-    gradient views per job], [workspace per job]); each job's flat buffer is left on its network as `_grad_flat`."""
+    gradient views per job], [workspace per job]); with a dp.GradientBucket attached, each job's flat buffer is left on its network as `_grad_flat` until the exchange."""
     n = len(ctxs)
     c0 = ctxs[0]
     dev = g_raws[0].device
@@ -449,7 +434,8 @@ def _mlp_backward_launch(ctxs, g_raws, absmax_log=None):
     n_grad = [full.numel() - GRAD_TAIL for full in fulls]
     L.check(L.lib().plnerf_mlp_bwd_multi(
         n, vp([L.dptr(c.packed) for c in ctxs]), c0.prec, vp([L.dptr(g, "g_raw") for g in gs]),
-        vp([L.dptr(a, "g_absmax", torch.int32) for a in absmax]), int(c0.net.input_ch), int(c0.net.hip_view_ch),
+        vp([L.dptr(a, "g_absmax", torch.int32) for a in absmax]), (ctypes.c_int * n)(*[0 if a is None else a.numel() for a in absmax]),
+        int(c0.net.input_ch), int(c0.net.hip_view_ch),
         (ctypes.c_int * n)(*[c.n_rows for c in ctxs]), vp([L.dptr(c.saved_acts) for c in ctxs]),
         (ctypes.c_int * n)(*[c.saved_layout for c in ctxs]),
         vp([L.dptr(c.saved_tensors[0]) if c.beta > 0.0 else None for c in ctxs]), c0.beta, vp([L.dptr(w) for w in wss]),

@@ -102,11 +102,52 @@ def select_view_rays(H, W, K, c2w, image, n_rand, near, far, seed=0, step=0, ray
     return RB.RayColumns(o, d, nr_col, fr_col, vd), target, pix
 
 
+def merged_backward_ok(tape, nets):
+    """Can this step's two network backwards run as one launch sequence (backward_merged)?  One MlpFn forward per
+    network (the batch fitted one launch each), coarse first, both networks native (NeRF.is_native), in one 16-bit
+    precision and with one density activation, every parameter trainable, no gradient wanted for the networks' inputs."""
+    if len(tape.outs) != 2 or len(nets) != 2 or nets[0] is nets[1]:
+        return False
+    ctxs = [o.grad_fn for o in tape.outs]
+    if any(c is None or getattr(c, "saved_acts", None) is None for c in ctxs):
+        return False
+    if ctxs[0].net is not nets[0] or ctxs[1].net is not nets[1]:
+        return False
+    return all(n.is_native() and n.precision in L.GUARDED_PRECISIONS and all(p.requires_grad for p in n.parameters())
+               for n in nets) and nets[0].precision == nets[1].precision and ctxs[0].beta == ctxs[1].beta and \
+        not any(c.in_grad or c.n_cam for c in ctxs)
+
+
+def backward_merged(tape, nets, roots, root_grads, bucket=None):
+    """loss.backward() with the two networks' backward in one launch sequence: autograd from the loss's roots (the
+    rendered images, the depth hypotheses) down to d loss / d raw of either network (plnerf_quad_bwd x 2, each leaving
+    max |g_raw| as a by-product; autograd does not enter the MlpFn nodes), then functional.mlp_backward_multi; the
+    gradients are assigned as autograd would have accumulated them into the zeroed `.grad`s, and a data-parallel bucket
+    is told that the two networks' gradients are complete."""
+    raw_c, raw_f = tape.outs
+    Fn.ABSMAX_LOG = log = []
+    try:
+        g_raw_f, g_raw_c = torch.autograd.grad(tuple(roots), (raw_f, raw_c), tuple(root_grads))
+    finally:
+        Fn.ABSMAX_LOG = None
+    grads_c, grads_f = Fn.mlp_backward_multi([raw_c, raw_f], [g_raw_c, g_raw_f], log)
+    for net, grads in ((nets[0], grads_c), (nets[1], grads_f)):
+        for p, g in zip(net.param_list(), grads):
+            p.grad = g
+    if bucket is not None:
+        bucket.gradients_ready(nets)
+
+
 class TrainStep:
     """One training iteration of the reference loop on the HIP path.
 
     render_kwargs / optimizer / optimizer_coarse come from create_nerf(args).  `args` supplies
     lrate, lrate_decay, constant_init (iterations of forced constant-mode warm-up), chunk.
+
+    `.grad` after a step: the gradients autograd would have left -- except under data parallelism with optim.FlatAdam, where
+    each network's flat gradient buffer is all-reduced in place and the 1 / world factor is applied INSIDE the step kernel:
+    `.grad` then holds the SUM over the ranks (world times the mean).  Code that reads `.grad` after the step (gradient-norm
+    logging, external clipping) divides by the world size, or calls `bucket.allreduce_mean()` itself before stepping.
 
     Random draws (stratified jitter, sampler u, pixel choice) come from a counter-based generator keyed on
     (`seed`, step, global ray id) (functional.DrawSource): a global batch gives the same step whether one rank
@@ -225,8 +266,8 @@ class TrainStep:
             # backward((rgb, rgb0), (d loss / d rgb, d loss / d rgb0)) is loss.backward()
             loss4, g_rgb, g_rgb0 = Fn.image_loss_and_grads(rgb, rgb0, target_s)
             loss, psnr = loss4[0], loss4[3]
-            if tape is not None and rgb0 is not None and self._merged_backward_ok(tape):
-                self._backward_merged(tape, rgb, rgb0, g_rgb, g_rgb0)
+            if tape is not None and rgb0 is not None and merged_backward_ok(tape, self.nets):
+                backward_merged(tape, self.nets, (rgb, rgb0), (g_rgb, g_rgb0), self.bucket)
             else:
                 torch.autograd.backward((rgb,) if rgb0 is None else (rgb, rgb0),
                                         (g_rgb,) if rgb0 is None else (g_rgb, g_rgb0))
@@ -246,38 +287,6 @@ class TrainStep:
         if self.range_check_every and self.global_step % self.range_check_every == 0:
             self.check_range()
         return loss.detach(), psnr
-
-    def _merged_backward_ok(self, tape):
-        """One MlpFn forward per network (the batch fitted one launch each), coarse first, both networks native, in one
-        16-bit precision, every parameter trainable, no gradient wanted for the networks' inputs."""
-        if len(tape.outs) != 2 or len(self.nets) != 2 or self.nets[0] is self.nets[1]:
-            return False
-        ctxs = [o.grad_fn for o in tape.outs]
-        if any(c is None or getattr(c, "saved_acts", None) is None for c in ctxs):
-            return False
-        if ctxs[0].net is not self.nets[0] or ctxs[1].net is not self.nets[1]:
-            return False
-        return all(n.is_native() and n.precision in L.GUARDED_PRECISIONS and all(p.requires_grad for p in n.parameters())
-                   for n in self.nets) and self.nets[0].precision == self.nets[1].precision and \
-            not any(c.in_grad or c.n_cam or c.beta for c in ctxs)
-
-    def _backward_merged(self, tape, rgb, rgb0, g_rgb, g_rgb0):
-        """loss.backward() with the two networks' backward in one launch sequence: autograd from the two images down to
-        d loss / d raw of either network (plnerf_quad_bwd x 2; it does not enter the MlpFn nodes), then
-        functional.mlp_backward_multi; the gradients are assigned as autograd would have accumulated them into the
-        zeroed `.grad`s, and a data-parallel bucket is told that the two networks' gradients are complete."""
-        raw_c, raw_f = tape.outs
-        Fn.ABSMAX_LOG = log = []      # (each plnerf_quad_bwd leaves max |g_raw| as a by-product: no absmax pass, no memset)
-        try:
-            g_raw_f, g_raw_c = torch.autograd.grad((rgb, rgb0), (raw_f, raw_c), (g_rgb, g_rgb0))
-        finally:
-            Fn.ABSMAX_LOG = None
-        grads_c, grads_f = Fn.mlp_backward_multi([raw_c, raw_f], [g_raw_c, g_raw_f], log)
-        for net, grads in ((self.nets[0], grads_c), (self.nets[1], grads_f)):
-            for p, g in zip(net.param_list(), grads):
-                p.grad = g
-        if self.bucket is not None:
-            self.bucket.gradients_ready(self.nets)
 
     def check_range(self):
         """Look at the networks' range status words (one 4-byte read each).  Steps the guarded Adam kernels withheld are

@@ -13,7 +13,7 @@ int main(void) {
     int (*p_build_flags)(void) = plnerf_build_flags;
     const char* (*p_error_string)(int) = plnerf_error_string;
     int (*p_quad_fwd)(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, int, float*, float*, float*, float*, float*, float*, float*, plnerf_stream_t) = plnerf_quad_fwd;
-    int (*p_quad_bwd)(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, int, const float*, const float*, const float*, const float*, const float*, const float*, float*, uint64_t*, uint32_t, plnerf_stream_t) = plnerf_quad_bwd;
+    int (*p_quad_bwd)(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, int, const float*, const float*, const float*, const float*, const float*, const float*, float*, uint32_t*, plnerf_stream_t) = plnerf_quad_bwd;
     int (*p_sample_const)(const float*, const float*, const float*, int, int, int, int, float*, int64_t*, plnerf_stream_t) = plnerf_sample_const;
     int (*p_sample_const_bwd)(const float*, const float*, const float*, int, const int64_t*, const float*, int, int, int, float*, plnerf_stream_t) = plnerf_sample_const_bwd;
     int (*p_sample_pl)(const float*, const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, float, float, float*, float*, float*, float*, int64_t*, plnerf_stream_t) = plnerf_sample_pl;
@@ -38,8 +38,8 @@ int main(void) {
     size_t (*p_mlp_bwd_workspace_bytes)(int, int) = plnerf_mlp_bwd_workspace_bytes;
     int (*p_mlp_saved_layout)(int, int, int) = plnerf_mlp_saved_layout;
     int (*p_mlp_fwd)(const void*, int, const float*, const float*, const float*, int, int, int, int, float, float, float*, void*, int, plnerf_stream_t) = plnerf_mlp_fwd;
-    int (*p_mlp_bwd)(const void*, int, const float*, const uint32_t*, int, int, int, const void*, int, const float*, float, void*, float* const*, float*, plnerf_stream_t) = plnerf_mlp_bwd;
-    int (*p_mlp_bwd_multi)(int, const void* const*, int, const float* const*, const uint32_t* const*, int, int, const int*, const void* const*, const int*, const float* const*, float, void* const*, float* const*, float* const*, plnerf_stream_t) = plnerf_mlp_bwd_multi;
+    int (*p_mlp_bwd)(const void*, int, const float*, const uint32_t*, int, int, int, int, const void*, int, const float*, float, void*, float* const*, float*, plnerf_stream_t) = plnerf_mlp_bwd;
+    int (*p_mlp_bwd_multi)(int, const void* const*, int, const float* const*, const uint32_t* const*, const int*, int, int, const int*, const void* const*, const int*, const float* const*, float, void* const*, float* const*, float* const*, plnerf_stream_t) = plnerf_mlp_bwd_multi;
     int (*p_mlp_input_grad)(const float* const*, int, int, int, int, const void*, float*, plnerf_stream_t) = plnerf_mlp_input_grad;
     int (*p_adam_step)(float*, const float*, float*, float*, int64_t, float, float, float, float, int, float, float, const uint32_t*, const uint32_t*, uint32_t*, plnerf_stream_t) = plnerf_adam_step;
     const void* entry[] = {
@@ -67,9 +67,9 @@ int main(void) {
         PLNERF_EINVAL)
         return 8;
     if (p_image_loss(NULL, NULL, NULL, 4, NULL, NULL, NULL, NULL, NULL, NULL) != PLNERF_EINVAL) return 9;
-    if (p_mlp_bwd(NULL, PLNERF_PREC_F16X3, NULL, NULL, 63, 27, 8, NULL, 1, NULL, 0.0f, NULL, NULL, NULL, NULL) != PLNERF_EINVAL) return 10;
-    if (p_mlp_bwd_multi(PLNERF_MAX_BWD_JOBS + 1, NULL, PLNERF_PREC_F16X3, NULL, NULL, 63, 27, NULL, NULL, NULL, NULL, 0.0f, NULL, NULL, NULL, NULL) != PLNERF_EINVAL) return 11;
-    if (p_mlp_bwd_multi(2, NULL, PLNERF_PREC_F16X3, NULL, NULL, 63, 27, NULL, NULL, NULL, NULL, 0.0f, NULL, NULL, NULL, NULL) != PLNERF_EINVAL) return 12;
+    if (p_mlp_bwd(NULL, PLNERF_PREC_F16X3, NULL, NULL, 0, 63, 27, 8, NULL, 1, NULL, 0.0f, NULL, NULL, NULL, NULL) != PLNERF_EINVAL) return 10;
+    if (p_mlp_bwd_multi(PLNERF_MAX_BWD_JOBS + 1, NULL, PLNERF_PREC_F16X3, NULL, NULL, NULL, 63, 27, NULL, NULL, NULL, NULL, 0.0f, NULL, NULL, NULL, NULL) != PLNERF_EINVAL) return 11;
+    if (p_mlp_bwd_multi(2, NULL, PLNERF_PREC_F16X3, NULL, NULL, NULL, 63, 27, NULL, NULL, NULL, NULL, 0.0f, NULL, NULL, NULL, NULL) != PLNERF_EINVAL) return 12;
     printf("%u entry points, version %d, packed bytes fp32 %zu f16x3 %zu, saved bytes per 256 rows (f16x3) %zu: %s\n",
            (unsigned)n, p_version(), p_mlp_packed_bytes(PLNERF_PREC_FP32), p_mlp_packed_bytes(PLNERF_PREC_F16X3),
            p_mlp_saved_bytes(256, PLNERF_PREC_F16X3), p_error_string(PLNERF_EINVAL));

@@ -378,3 +378,35 @@ def test_depth_step_is_invariant_to_sharding_of_the_batch(P, golden):
                          what=f"two shards {k} {over}")
     other = run(rays, 1)
     assert not torch.equal(other["u"], run(rays, 0)["u"])
+
+
+def test_depth_step_with_merged_backward_equals_autograd_order(P, golden):
+    """DepthTrainStep's merged backward (train.backward_merged: autograd from rgb / rgb0 / pred_hyp down to d loss / d raw
+    of both networks, then plnerf_mlp_bwd_multi with the density activation's derivative applied per job) against the same
+    steps through torch.autograd.backward: losses to fp32 summation order, weights after three clipped Adam steps to an
+    Adam step's rounding."""
+    from test_gpu_modes import _depth_args, _depth_setup
+    gd = golden("g8b_depth_variant_128_64")
+    R = 2048
+    batch, target = orc.synthetic_blender_rays(R, seed=9)
+    target_h = 2.0 + 4.0 * torch.rand(3, R, 1, generator=torch.Generator().manual_seed(9))
+    batch, target, target_h = g(batch), g(target), g(target_h)
+
+    def run(merged):
+        Dp, kw, grad_vars, opt = _depth_setup(gd, "f16x3")
+        step = Dp.DepthTrainStep(_depth_args(gd, "f16x3"), kw, opt, grad_vars, distributed=False, seed=2)
+        step.merged_backward = merged
+        out = []
+        for _ in range(3):
+            loss, img_loss, sc, _ = step(batch, target, target_h)
+            out.append((float(loss), float(sc)))
+        return out, [p.detach().clone() for p in grad_vars]
+    l1, p1 = run(True)
+    l0, p0 = run(False)
+    for (a, sa), (b, sb) in zip(l1, l0):
+        assert abs(a - b) <= 2e-6 * max(1.0, abs(b)) and abs(sa - sb) <= 1e-5 * max(1.0, abs(sb)), (l1, l0)
+    worst = max(float((a - b).abs().max()) for a, b in zip(p1, p0))
+    print(f"depth step, merged vs autograd-order backward, 3 steps x {R} rays: loss {l1[-1][0]:.7f} / {l0[-1][0]:.7f}, max parameter difference {worst:.2e}")
+    # (Adam moves every weight by ~lr = 5e-4 per step whatever its gradient's size: an entry whose gradient is ~0 -- and this
+    # loss runs through the sampler's ill-conditioned closed form -- may flip sign under another summation order: 2 lr)
+    assert worst <= 1.1e-3, worst

@@ -574,7 +574,7 @@ def test_weight_gradients_do_not_depend_on_what_the_workspace_held(P, precision,
     for fill in (float("nan"), 0.0):
         ws = torch.full((L.lib().plnerf_mlp_bwd_workspace_bytes(n_rows, prec) // 4,), fill, device=dev())
         grads = [torch.full(tuple(s), float("nan"), device=dev()) for s in shapes]
-        L.check(L.lib().plnerf_mlp_bwd(L.dptr(packed), prec, L.dptr(g_raw), None, 63, 27, n_rows, L.dptr(saved), layout, None, 0.0,
+        L.check(L.lib().plnerf_mlp_bwd(L.dptr(packed), prec, L.dptr(g_raw), None, 0, 63, 27, n_rows, L.dptr(saved), layout, None, 0.0,
                                        L.dptr(ws), L.ptr_table(grads, "grads"), None, L.stream()), "plnerf_mlp_bwd")
         torch.cuda.synchronize()
         results.append(grads)
@@ -591,7 +591,8 @@ def test_merged_backward_equals_two_backwards(P):
     sizes (262,144 + 786,432 rows), at ragged ones, and with the roles swapped.  The gradient chain's arithmetic does not
     depend on the grid (dz planes bit-identical => bias gradients and head gradients bit-identical); the 256-wide weight
     gradients sum their split-K partials over other row ranges (21 + 7 instead of 28 + 28), so they agree to fp32
-    summation order.  Also: max |g_raw| handed in (g_absmax) instead of found by the call's own pass = the same bits."""
+    summation order.  Also: max |g_raw| handed in as an array of partial maxima (g_absmax / n_absmax: what plnerf_quad_bwd
+    leaves per workgroup) instead of found by the call's own pass = the same bits."""
     import ctypes
     from plnerf_amd import _lib as L
     prec = L.PRECISION["f16x3"]
@@ -623,19 +624,21 @@ def test_merged_backward_equals_two_backwards(P):
         single = []
         for job in jobs:
             ws, grads = fresh(job)
-            L.check(L.lib().plnerf_mlp_bwd(L.dptr(job["packed"]), prec, L.dptr(job["g_raw"]), None, 63, 27, job["n_rows"],
+            L.check(L.lib().plnerf_mlp_bwd(L.dptr(job["packed"]), prec, L.dptr(job["g_raw"]), None, 0, 63, 27, job["n_rows"],
                                            L.dptr(job["saved"]), layout, None, 0.0, L.dptr(ws), L.ptr_table(grads, "grads"), None,
                                            L.stream()), "plnerf_mlp_bwd")
             single.append((ws, grads))
         for with_absmax in (False, True):
             both = [fresh(job) for job in jobs]
             am = [None, None]
-            if with_absmax:      # the maxima as fp32 bits in device words, as plnerf_quad_bwd's absmax_out leaves them
-                am = [job["g_raw"].abs().max().reshape(1).view(torch.int32) for job in jobs]
+            if with_absmax:      # per-group maxima as fp32 bits, as plnerf_quad_bwd's absmax_out leaves them (here: per 8 rows, ragged)
+                am = [torch.nn.functional.pad(job["g_raw"].abs().reshape(-1), (0, (-job["g_raw"].numel()) % 32)).reshape(-1, 32)
+                      .max(-1).values.contiguous().view(torch.int32) for job in jobs]
             tails = torch.full((2, 4), -1.0, device=dev())
             L.check(L.lib().plnerf_mlp_bwd_multi(
                 2, vp([L.dptr(j["packed"]) for j in jobs]), prec, vp([L.dptr(j["g_raw"]) for j in jobs]),
-                vp([L.dptr(a, "g_absmax", torch.int32) for a in am]), 63, 27, (ctypes.c_int * 2)(*[j["n_rows"] for j in jobs]),
+                vp([L.dptr(a, "g_absmax", torch.int32) for a in am]), (ctypes.c_int * 2)(*[0 if a is None else a.numel() for a in am]),
+                63, 27, (ctypes.c_int * 2)(*[j["n_rows"] for j in jobs]),
                 vp([L.dptr(j["saved"]) for j in jobs]), (ctypes.c_int * 2)(layout, layout), None, 0.0,
                 vp([L.dptr(ws) for ws, _ in both]), L.ptr_table([t for _, gr in both for t in gr], "grads"),
                 vp([ctypes.c_void_p(tails[k].data_ptr()) for k in range(2)]), L.stream()), "plnerf_mlp_bwd_multi")

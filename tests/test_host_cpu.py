@@ -531,7 +531,9 @@ out = FlatGradFn.apply(X, *ref[0].parameters()) + 0.5 * FlatGradFn.apply(X, *ref
 for n, r in zip(nets, ref):
     for p, q in zip(n.parameters(), r.parameters()):      # .grad holds the SUM over the ranks = the full batch's gradient
         assert float((p.grad - q.grad).abs().max()) <= 1e-3 * float(q.grad.abs().max()) + 1e-6
-    assert n._grad_flat.data_ptr() == next(n.parameters()).grad.data_ptr()       # in place
+    assert "_grad_flat" not in n.__dict__       # the bucket let go of the buffer once exchanged (its tail view keeps it alive)
+for t, n in zip(bucket.tails(), nets):
+    assert t.data_ptr() == next(n.parameters()).grad.data_ptr() + 4 * sum(p.numel() for p in n.parameters())       # in place
 print(f"rank {rank} ok")
 '''
 
