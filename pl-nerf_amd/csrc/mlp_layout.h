@@ -101,8 +101,8 @@ constexpr int DZ_PER_ROW = DZ_V_OFF + HV;    // 2432
 // plane_off(p) * sv_rows(n_rows)), so that the TILED layout below never runs from one plane into the next and every
 // wave of the forward kernel that writes it owns a whole tile (rows past n_rows: padding, written, never read).
 //
-// Layouts of the 256-wide planes h0..h7, feature and of hv (128 wide) -- the encoding planes and the relu bits are
-// always row-major:
+// Layouts of the planes h0..h7, feature (256 wide), hv (128) and -- since round 5 -- the two encoding planes (64 / 32 wide, in
+// the register-resident forward's own column order: sv_enc_channel); the relu bits are always row-major:
 //   SV_LAYOUT_ROWS   [row][width]: written by the ping-pong forward (its LDS tile is in this order)
 //   SV_LAYOUT_TILED  32-row tiles in the register-resident forward's own order: tile t = row / 32 holds
 //                    [slab j = col / 32][fragment f][lane half g][row r = row % 32][8 halves], the 8 halves being
@@ -110,6 +110,23 @@ constexpr int DZ_PER_ROW = DZ_V_OFF + HV;    // 2432
 //                    accumulator layout holds, so a wave stores a fragment as ONE contiguous KiB straight from its
 //                    registers.  4 consecutive features of a row stay contiguous, which is all the weight-gradient
 //                    kernel's transposing LDS reads need.
+// The register-resident forward's k order of the ENCODING operands (its operand registers hold, in k-step s, lane half g,
+// element e, slot t = 8 s + e): xyz (63 channels + 1 pad): t < 30: frequency band 5 g + t / 6, function / axis t % 6 (sin x,
+// sin y, sin z, cos x, cos y, cos z, the reference's order); t = 30, 31: x, y | z, pad -- each lane half evaluates whole
+// bands.  Direction (27 + 5 pad), t in 0..15: t < 12: band 2 g + t / 6; then x, y, z, channel 27 | channels 28..31.  Both
+// are bijections onto 0..63 / 0..31.  Its saved encoding planes are TILED planes whose column 16 s + 8 (e >> 2) + 4 g +
+// (e & 3) holds that channel (sv_enc_channel below): what the weight-gradient reduction un-permutes.
+__host__ __device__ constexpr int rr_pe_channel(int g, int t) {
+    return t < 30 ? 3 + 6 * (5 * g + t / 6) + t % 6 : (t == 30 ? (g ? 2 : 0) : (g ? PE_K - 1 : 1));
+}
+__host__ __device__ constexpr int rr_dpe_channel(int g, int t) {
+    return t < 12 ? 3 + 6 * (2 * g + t / 6) + t % 6 : (g ? 28 + (t - 12) : (t < 15 ? t - 12 : 27));
+}
+// channel held by column c of a tiled encoding plane (xyz: 64 columns, direction: 32)
+__host__ __device__ constexpr int sv_enc_channel(int c, bool dir) {
+    const int s = c >> 4, g = (c >> 2) & 1, e = ((c >> 3) & 1) * 4 + (c & 3);
+    return dir ? rr_dpe_channel(g, 8 * s + e) : rr_pe_channel(g, 8 * s + e);
+}
 constexpr int SV_ROW_PAD = 256;     // = the register-resident forward's largest workgroup tile: its plane stores are unconditional
 constexpr int SV_LAYOUT_ROWS = 0, SV_LAYOUT_TILED = 1;
 __host__ __device__ constexpr size_t sv_rows(size_t n_rows) { return (n_rows + SV_ROW_PAD - 1) / SV_ROW_PAD * SV_ROW_PAD; }

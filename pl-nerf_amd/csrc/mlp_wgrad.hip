@@ -201,7 +201,9 @@ __device__ __forceinline__ wh8 tr_frag_tiled(const _Float16* stage, int srows, i
 // rows past the range are loaded from the clamped last row and zeroed by a select.
 template <int O, int I, int NI, bool DEEP, bool TILED = false>
 __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& job, const int split, unsigned char* smem_raw) {
-    static_assert(!TILED || I == W, "the tiled layout exists for the 256-wide planes");
+    // (TILED B: the 256-wide activation planes, and since round 5 the 64- / 32-wide encoding planes of the register-resident
+    // forward, whose columns are in ITS order -- the reduction kernel un-permutes them, sv_enc_channel)
+    constexpr int B_CT = 4 * I;                             // 16-byte chunks per 32-row tile of a tiled B plane
     // the A operand: a half dz plane -- TILED too when it is 256 wide (written by the dgrad kernel's MFMA epilogues,
     // mlp_layout.h); dz_view (O = 128) is row-major
     constexpr bool ATILED = O == W;
@@ -235,8 +237,8 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
 #pragma unroll
     for (int j = 0; j < SB; ++j) {
         const int q = tid % B_THREADS + 512 * j;           // (threads past B_THREADS reload a neighbour's chunk, unused)
-        if (TILED) {                                       // chunk q of the stage = tile q / 1024, piece q % 1024
-            b_row[j] = (q >> 10) * 32 + (q & 31); b_col[j] = (q & 1023) >> 5;
+        if (TILED) {                                       // chunk q of the stage = tile q / B_CT, piece q % B_CT
+            b_row[j] = (q / B_CT) * 32 + (q & 31); b_col[j] = (q % B_CT) >> 5;
         } else {
             b_row[j] = q / B_C8; b_col[j] = (q % B_C8) * 8;
         }
@@ -269,7 +271,7 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
         for (int j = 0; j < SB; ++j) {
             if (TILED)      // (m is a multiple of 64: a stage is two whole tiles; a tile past the plane re-reads the last one)
                 s.b[j] = *reinterpret_cast<const wh8*>(
-                    Bg + ((size_t)min((m >> 5) + (b_row[j] >> 5), last_tile) * 1024 + b_col[j] * 32 + (b_row[j] & 31)) * 8);
+                    Bg + ((size_t)min((m >> 5) + (b_row[j] >> 5), last_tile) * B_CT + b_col[j] * 32 + (b_row[j] & 31)) * 8);
             else
                 s.b[j] = *reinterpret_cast<const wh8*>(Bg + (size_t)min(m + b_row[j], last) * I + b_col[j]);
         }
@@ -397,8 +399,13 @@ __global__ __launch_bounds__(512) void wgrad_thin_kernel(WgradArgs2 p) {
     const int split = (int)blockIdx.y - (second ? p.splits0 : 0);
     const int j = a.tile_job[blockIdx.x];
     const WJob job = a.jobs[j];
-    if (job.O == W) wgrad_half_body<W, PE_K, 1, true>(a, job, split, smem_raw);      // encoding columns of L0 / L5
-    else wgrad_half_body<HV, DPE_K, 1, true>(a, job, split, smem_raw);               // direction columns of the view layer
+    if (job.b_tiled) {      // (uniform per workgroup: the register-resident forward's encoding planes)
+        if (job.O == W) wgrad_half_body<W, PE_K, 1, true, true>(a, job, split, smem_raw);
+        else wgrad_half_body<HV, DPE_K, 1, true, true>(a, job, split, smem_raw);
+    } else {
+        if (job.O == W) wgrad_half_body<W, PE_K, 1, true>(a, job, split, smem_raw);      // encoding columns of L0 / L5
+        else wgrad_half_body<HV, DPE_K, 1, true>(a, job, split, smem_raw);               // direction columns of the view layer
+    }
 }
 
 // the 256-wide jobs on the same body (256 x 256 layers, 128 x 256 feature columns of the view layer)
@@ -655,6 +662,7 @@ struct ReduceArgs {
     const unsigned* gmax;   // 16-bit modes: the dz planes were scaled by 2^(DZH_TARGET_EXP - exponent(max |g_raw|))
     const unsigned* status; // the network's range status word (16-bit modes), or nullptr
     float* status_out;      // nullptr, or where this launch leaves (float)(*status != 0): the tail of the caller's flat gradient
+    int enc_tiled;          // the encoding planes were tiled (mlp_layout.h): column c of the thin jobs' results = channel sv_enc_channel(c)
     GradPtrs G;
 };
 
@@ -720,13 +728,13 @@ __global__ void wgrad_reduce_kernel(ReduceArgs2 p) {
         const int r = idx - PART_VMAIN, o = r >> 8, i = r & 255;
         a.G.p[P_WV][o * (W + a.G.dir_ch) + i] = s;
     } else if (idx < PART_PE5) {
-        const int r = idx - PART_PE0, o = r >> 6, i = r & 63;
+        const int r = idx - PART_PE0, o = r >> 6, i = a.enc_tiled ? sv_enc_channel(r & 63, false) : (r & 63);
         if (i < a.G.xyz_ch) a.G.p[0][o * a.G.xyz_ch + i] = s;
     } else if (idx < PART_VDIR) {
-        const int r = idx - PART_PE5, o = r >> 6, i = r & 63;
+        const int r = idx - PART_PE5, o = r >> 6, i = a.enc_tiled ? sv_enc_channel(r & 63, false) : (r & 63);
         if (i < a.G.xyz_ch) a.G.p[10][o * (W + a.G.xyz_ch) + i] = s;
     } else if (idx < PART_BIAS) {
-        const int r = idx - PART_VDIR, o = r >> 5, i = r & 31;
+        const int r = idx - PART_VDIR, o = r >> 5, i = a.enc_tiled ? sv_enc_channel(r & 31, true) : (r & 31);
         if (i < a.G.dir_ch) a.G.p[P_WV][o * (W + a.G.dir_ch) + W + i] = s;
     } else {
         const int r = idx - PART_BIAS;
@@ -912,9 +920,9 @@ int plan_job(const plnerf::impl::WgradJob& jb, bool h16, int cap_main, int cap_t
         // the three thin jobs: encoding columns of L0 / L5 (256 x 64), direction columns of the view layer (128 x 32)
         // (folding them into the main launch as extra tiles measured 1-2 % slower than this second launch)
         WgradArgs a{};
-        a.jobs[0] = WJob{dplane(0), pe_plane, W, PE_K, W, PE_K, PART_PE0, PART_BIAS + 0 * W, 0};
-        a.jobs[1] = WJob{dplane(5), pe_plane, W, PE_K, W, PE_K, PART_PE5, -1, 0};
-        a.jobs[2] = WJob{dzv_plane, dpe_plane, HV, DPE_K, HV, DPE_K, PART_VDIR, -1, 0};
+        a.jobs[0] = WJob{dplane(0), pe_plane, W, PE_K, W, PE_K, PART_PE0, PART_BIAS + 0 * W, tiled};
+        a.jobs[1] = WJob{dplane(5), pe_plane, W, PE_K, W, PE_K, PART_PE5, -1, tiled};
+        a.jobs[2] = WJob{dzv_plane, dpe_plane, HV, DPE_K, HV, DPE_K, PART_VDIR, -1, tiled};
         for (int t = 0; t < 3; ++t) { a.tile_job[t] = t; a.tile_o0[t] = 0; }
         // half: three tiles only, so more row ranges than the main launch to cover the 256 CUs (3 x 85 = 255).
         // (Equal ROW counts per workgroup, not equal bytes: a stage costs its latency whatever its width, so
@@ -930,6 +938,7 @@ int plan_job(const plnerf::impl::WgradJob& jb, bool h16, int cap_main, int cap_t
         a.part = part; a.head_part = P.head_part; a.splits = splits; a.splits_thin = splits_thin; a.n_head = P.n_head;
         a.gmax = h16 ? jb.gmax : nullptr;
         a.status = jb.status; a.status_out = jb.status_out;
+        a.enc_tiled = tiled;
         a.G.xyz_ch = jb.xyz_ch; a.G.dir_ch = jb.dir_ch;
         for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i) {
             if (!jb.grads[i]) return PLNERF_EINVAL;

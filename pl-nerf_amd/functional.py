@@ -395,14 +395,15 @@ def coarse_samples(rays_o, rays_d, near, far, t_vals, t_rand, lindisp, perturb, 
     return z, pts
 
 
-def _grad_buffer(ctx, dev, zero=False):
+def _grad_buffer(ctx, dev, zero=False, block=None):
     """A network's 24 gradients as consecutive slices of ONE buffer, in parameter order: optim.FlatAdam and
     dp.GradientBucket then see the network's gradient as a single flat tensor (one Adam launch, one all-reduce without
     gather / scatter copies).  GRAD_TAIL floats behind them: [0] = the network's range status as the reduction kernel
     leaves it, so that a data-parallel exchange of this buffer carries it along (dp.GradientBucket)."""
     sizes = [int(torch.Size(sh).numel()) for sh in ctx.param_shapes]
     n_grad = sum(sizes)
-    full = (torch.zeros if zero else torch.empty)(n_grad + GRAD_TAIL, device=dev, dtype=torch.float32)
+    # (`block`: a slice of a buffer that holds several networks' gradients back to back -- one collective for all of them)
+    full = (torch.zeros if zero else torch.empty)(n_grad + GRAD_TAIL, device=dev, dtype=torch.float32) if block is None else block
     if ctx.net.__dict__.get("_wants_grad_flat"):      # (a dp.GradientBucket is attached: it exchanges the buffer WITH its tail,
         ctx.net.__dict__["_grad_flat"] = full         #  and lets go of this reference once it has -- GradientBucket.finish)
     return [t.view(sh) for t, sh in zip(full[:n_grad].split(sizes), ctx.param_shapes)], full
@@ -420,14 +421,19 @@ def _mlp_backward_launch(ctxs, g_raws, absmax_log=None):
                 int(c.net.hip_view_ch) == int(c0.net.hip_view_ch) for c in ctxs),
             "jobs of one backward launch share precision, input widths and density activation")
     gs, wss, grads_all, fulls, absmax = [], [], [], [], []
-    for c, g_raw in zip(ctxs, g_raws):
+    # the jobs' gradient buffers back to back in ONE allocation: a data-parallel exchange of a merged backward is then one
+    # all-reduce over both networks (dp.GradientBucket.gradients_ready) instead of two latency-bound ones
+    sizes = [sum(int(torch.Size(sh).numel()) for sh in c.param_shapes) + GRAD_TAIL for c in ctxs]
+    block = torch.empty(sum(sizes), device=dev, dtype=torch.float32) if n > 1 else None
+    offs = [sum(sizes[:j]) for j in range(n)]
+    for j, (c, g_raw) in enumerate(zip(ctxs, g_raws)):
         g = _f32c(g_raw)
         gs.append(g)
         # (the producer's by-product: the word of the plnerf_quad_bwd launch that wrote exactly this buffer)
         am = next((v for ptr, v in (absmax_log or ()) if ptr == g.data_ptr()), None)
         absmax.append(am if (am is not None and c.beta == 0.0 and g.numel() == 4 * c.n_rows) else None)
         wss.append(torch.empty(L.lib().plnerf_mlp_bwd_workspace_bytes(c.n_rows, c.prec) // 4, device=dev, dtype=torch.float32))
-        grads, full = _grad_buffer(c, dev)
+        grads, full = _grad_buffer(c, dev, block=None if block is None else block[offs[j]:offs[j] + sizes[j]])
         grads_all.append(grads)
         fulls.append(full)
     vp = lambda items: (ctypes.c_void_p * n)(*[None if x is None else x.value for x in items])

@@ -438,6 +438,8 @@ losses = []
 for step in range(STEPS):
     loss, _ = ts.step_view(H, W, K, c2w, image, near=2.0, far=6.0, n_rand=N_RAND)
     assert ts.bucket.pending() == 0
+    # the merged backward leaves both networks' gradients (and their status tails) back to back: ONE collective per step
+    assert ts.bucket.collectives == 1, ts.bucket.collectives
     losses.append(float(loss))
 digest = [float(p.detach().double().sum()) for n in ts.nets for p in n.parameters()]
 gathered = [None] * world

@@ -11,6 +11,6 @@ for r in $(seq $rounds); do
     python $R/bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-strict-fp32 --no-extra-legs "$@" 2>/dev/null | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); rf = d['roofline']
-print('round $r %-10s step %.3f ms  (min %.3f median %.3f)  fine fwd %.3f ms  fine bwd %.3f ms  loss %.6f' % ('$name', d['ms_per_step'], d['step_ms']['min'], d['step_ms']['median'], rf['launch_ms'], rf['mlp_bwd_launch_ms'], d['config']['final_loss']))"
+print('round $r %-10s step %.3f ms  (min %.3f median %.3f)  fine fwd %.3f ms  bwd %.3f ms  loss %.6f' % ('$name', d['ms_per_step'], d['step_ms']['min'], d['step_ms']['median'], rf['launch_ms'], (rf.get('mlp_bwd_both_networks_ms') or rf.get('mlp_bwd_launch_ms') or 0.0), d['config']['final_loss']))"
   done
 done
