@@ -634,15 +634,40 @@ def test_input_gradients_match_the_oracle(P, precision):
     p_o, v_o = pts.double().requires_grad_(True), vd.double().requires_grad_(True)
     (orc.query_network(sd64, p_o, v_o) * cot.double()).sum().backward()
     tol = 2e-5 if precision == "fp32" else 4e-3      # (16-bit modes: half planes in the backward)
+
+    def smallest_preactivation(emb64):
+        """Per row: the smallest |pre-activation| of any ReLU unit, in fp64 (the trunk's eight layers and the view layer)."""
+        enc_xyz, enc_dir = emb64[..., :orc.XYZ_CH], emb64[..., orc.XYZ_CH:]
+        h, small = enc_xyz, torch.full((emb64.shape[0],), float("inf"), dtype=torch.float64)
+        F = torch.nn.functional
+        for i in range(orc.DEPTH):
+            z = F.linear(h, sd64[f"pts_linears.{i}.weight"], sd64[f"pts_linears.{i}.bias"])
+            small = torch.minimum(small, z.abs().min(-1).values)
+            h = F.relu(z)
+            if i == orc.SKIP_AFTER:
+                h = torch.cat([enc_xyz, h], -1)
+        feat = F.linear(h, sd64["feature_linear.weight"], sd64["feature_linear.bias"])
+        zv = F.linear(torch.cat([feat, enc_dir], -1), sd64["views_linears.0.weight"], sd64["views_linears.0.bias"])
+        return torch.minimum(small, zv.abs().min(-1).values)
+    # A row may sit beyond `tol` for ONE reason: a unit whose pre-activation is within the forward's rounding error of zero
+    # takes the other side of its ReLU than the fp64 reference does, and the row's gradient differs by that unit's whole
+    # contribution (DESIGN.md section 6).  Asserted: every such row has a unit with |z| (fp64) below the mode's forward error
+    # -- and at most three rows do.
+    flip_below = {"fp32": 2e-6, "f16x3": 1e-5, "bf16x3": 5e-5}[precision]      # (the mode's forward error on a hidden unit)
     net = make_net(P, sd, precision)
     p_g, v_g = g(pts).requires_grad_(True), g(vd).requires_grad_(True)
     (net.query(p_g, v_g) * g(cot)).sum().backward()
-    for got, ref, what in ((p_g.grad, p_o.grad, "pts"), (v_g.grad, v_o.grad, "viewdirs")):
+    emb_q = torch.cat([orc.positional_encoding(pts.reshape(-1, 3), orc.XYZ_FREQS),
+                       orc.positional_encoding(vd[:, None, :].expand(R, S, 3).reshape(-1, 3), orc.DIR_FREQS)], -1).double()
+    small = smallest_preactivation(emb_q)                     # [R * S]
+    small_ray = small.reshape(R, S).min(-1).values            # (a direction's gradient sums its ray's rows)
+    for got, ref, what, sm in ((p_g.grad, p_o.grad, "pts", small), (v_g.grad, v_o.grad, "viewdirs", small_ray)):
         row_err = (got.cpu().double() - ref).abs().reshape(-1, 3).max(-1).values / float(ref.abs().max())
-        n_bad = int((row_err > tol).sum())
+        bad = row_err > tol
         print(f"{precision} d/d {what}: median row {float(row_err.median()):.2e}, worst {float(row_err.max()):.2e} of max |g|, "
-              f"{n_bad} rows beyond {tol:g}")
-        assert got.shape == ref.shape and n_bad <= 3 and float(row_err.max()) <= 5e-2, (what, float(row_err.max()))
+              f"{int(bad.sum())} rows beyond {tol:g}" + (f", their smallest |z| {[f'{float(x):.1e}' for x in sm[bad]]}" if bad.any() else ""))
+        assert got.shape == ref.shape and int(bad.sum()) <= 3 and float(row_err.max()) <= 5e-2, (what, float(row_err.max()))
+        assert bool((sm[bad] < flip_below).all()), f"{what}: a row beyond {tol:g} without a pre-activation near zero"
     w_with = [p.grad.clone() for p in net.parameters()]
     net.zero_grad()
     (net.query(g(pts), g(vd)) * g(cot)).sum().backward()
@@ -661,10 +686,12 @@ def test_input_gradients_match_the_oracle(P, precision):
     # (a pre-activation within fp32 rounding of zero takes the other side of its ReLU in fp64: such a row's gradient
     # differs by that unit's whole contribution -- DESIGN.md section 6 -- so rows are counted, as in test_gpu_fullsize.py)
     row_err = (e_g.grad.cpu().double() - e_o.grad).abs().max(-1).values / float(e_o.grad.abs().max())
-    n_bad = int((row_err > tol).sum())
+    bad = row_err > tol
+    small_e = smallest_preactivation(emb.double())
     print(f"{precision} d/d embedded: median row {float(row_err.median()):.2e}, worst {float(row_err.max()):.2e} of max |g|, "
-          f"{n_bad} of {row_err.numel()} rows beyond {tol:g}")
-    assert e_g.grad.shape == emb.shape and n_bad <= 3 and float(row_err.max()) <= 5e-2
+          f"{int(bad.sum())} of {row_err.numel()} rows beyond {tol:g}" + (f", their smallest |z| {[f'{float(x):.1e}' for x in small_e[bad]]}" if bad.any() else ""))
+    assert e_g.grad.shape == emb.shape and int(bad.sum()) <= 3 and float(row_err.max()) <= 5e-2
+    assert bool((small_e[bad] < flip_below).all()), "a row beyond the bound without a pre-activation near zero"
 
 
 # ----------------------------------------------------------------------------- range of the half modes

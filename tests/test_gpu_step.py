@@ -663,6 +663,49 @@ def test_merged_backward_equals_two_backwards(P):
                   f"{worst:.2e} of max|g| (fp32 summation order of the split-K partials)")
 
 
+def test_multi_backward_in_exact_fp32_is_the_jobs_in_turn(P):
+    """plnerf_mlp_bwd_multi in PLNERF_PREC_FP32 runs its jobs one after the other on the exact-fp32 kernels: bit-identical to
+    separate plnerf_mlp_bwd calls (and the argument checks: more than PLNERF_MAX_BWD_JOBS jobs, a null entry)."""
+    import ctypes
+    from plnerf_amd import _lib as L
+    prec = L.PRECISION["fp32"]
+    nets = [make_net(P, orc.closed_form_state_dict(k, False), "fp32") for k in (0, 1)]
+    gen = torch.Generator().manual_seed(8)
+    vp = lambda items: (ctypes.c_void_p * len(items))(*[None if x is None else x.value for x in items])
+    jobs = []
+    for net, n_rays in zip(nets, (700, 231)):
+        n_rows = n_rays * 8
+        pts = g((torch.rand(n_rows, 3, generator=gen) * 2 - 1) * 2.0)
+        vd = g(torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=gen), dim=-1))
+        packed = net.packed_weights()
+        raw = torch.empty(n_rows, 4, device=dev())
+        saved = torch.empty(L.lib().plnerf_mlp_saved_bytes(n_rows, prec) // 4, device=dev())
+        L.check(L.lib().plnerf_mlp_fwd(L.dptr(packed), prec, L.dptr(pts), L.dptr(vd), None, 63, 27, n_rows, 8, 1.0, 0.0, L.dptr(raw),
+                                       L.dptr(saved), L.FWD_KERNEL, L.stream()), "plnerf_mlp_fwd")
+        jobs.append(dict(packed=packed, g_raw=g(torch.randn(n_rows, 4, generator=gen)), n_rows=n_rows, saved=saved))
+    shapes = [p.shape for p in nets[0].parameters()]
+    fresh = lambda job: (torch.zeros(L.lib().plnerf_mlp_bwd_workspace_bytes(job["n_rows"], prec) // 4, device=dev()),
+                         [torch.full(tuple(s), float("nan"), device=dev()) for s in shapes])
+    single = []
+    for job in jobs:
+        ws, grads = fresh(job)
+        L.check(L.lib().plnerf_mlp_bwd(L.dptr(job["packed"]), prec, L.dptr(job["g_raw"]), None, 0, 63, 27, job["n_rows"],
+                                       L.dptr(job["saved"]), 0, None, 0.0, L.dptr(ws), L.ptr_table(grads, "grads"), None, L.stream()),
+                "plnerf_mlp_bwd")
+        single.append(grads)
+    both = [fresh(job) for job in jobs]
+    call = lambda n: L.lib().plnerf_mlp_bwd_multi(
+        n, vp([L.dptr(j["packed"]) for j in jobs]), prec, vp([L.dptr(j["g_raw"]) for j in jobs]), None, None, 63, 27,
+        (ctypes.c_int * 2)(*[j["n_rows"] for j in jobs]), vp([L.dptr(j["saved"]) for j in jobs]), (ctypes.c_int * 2)(0, 0), None, 0.0,
+        vp([L.dptr(ws) for ws, _ in both]), L.ptr_table([t for _, gr in both for t in gr], "grads"), None, L.stream())
+    L.check(call(2), "plnerf_mlp_bwd_multi")
+    torch.cuda.synchronize()
+    for k in range(2):
+        for a, b in zip(single[k], both[k][1]):
+            assert torch.equal(a, b)
+    assert call(3) == -1 and call(0) == -1      # PLNERF_EINVAL
+
+
 def test_training_step_with_merged_backward_equals_autograd_order(P):
     """train.TrainStep's merged backward (autograd down to d loss / d raw of both networks with max |g_raw| as
     plnerf_quad_bwd's by-product, then plnerf_mlp_bwd_multi, `.grad` assigned directly) against the same steps through
