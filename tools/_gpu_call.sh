@@ -1,4 +1,5 @@
 set -x
-mkdir -p gpurun_out
-(timeout 1200 python -m pytest tests/test_gpu_modes.py tests/test_gpu_step.py -m gpu -q -s -x --timeout=1100 -k "input_gradients or two_ranks or eight_shards" > gpurun_out/r05_tests_misc.log 2>&1; echo "rc=$?" >> gpurun_out/r05_tests_misc.log)
-grep -n "d/d\|passed\|failed\|Error\|max |param" gpurun_out/r05_tests_misc.log | cut -c1-300
+COMMIT=a44181b bash tools/refresh_profiles_r05.sh > gpurun_out/r05_refresh.log 2>&1
+tail -5 gpurun_out/r05_refresh.log
+(timeout 2400 python -m pytest tests -m gpu -q -x --timeout=2000 > gpurun_out/r05_tests_final.log 2>&1; echo "rc=$?" >> gpurun_out/r05_tests_final.log)
+tail -4 gpurun_out/r05_tests_final.log
