@@ -3,6 +3,8 @@
 //   wgrad_f32_kernel      exact fp32 (v_mfma_f32_32x32x2_f32) straight from the fp32 planes
 //   wgrad_main_kernel     the 256-wide jobs of the 16-bit modes on v_mfma_f32_32x32x16_f16 over the HALF planes of
 //   wgrad_thin_kernel     mlp_layout.h (LDS-staged, ds_read_b64_tr_b16); the encoding / direction columns two stages deep
+//                         (tiled saved planes: the view layer's direction columns ride on the idle half of the main
+//                         launch's view job instead -- X2 in wgrad_half_body -- and the thin launch has two jobs)
 //   wgrad_head_kernel     sigma / rgb head rows (VALU reductions)
 //   wgrad_reduce_kernel   deterministic split-K sum into the 24 gradient tensors (+ the launch scale of the half dz
 //                         planes divided back out, + the range status for a data-parallel exchange)
@@ -44,6 +46,8 @@ struct WJob {
     int part_off;     // offset (floats) of this job's [O][I] partial inside a split block
     int bias_off;     // offset of the [O] bias partial, or -1
     int b_tiled;      // half planes: B is in SV_LAYOUT_TILED (mlp_layout.h) instead of row-major
+    const void* B2;   // view job of the tiled layout only (else nullptr): the direction-encoding plane (32 wide, tiled) --
+    int part2_off;    //   dz_view^T dpe rides on the job's four idle waves instead of re-reading dz_view in a thin job
 };
 constexpr int MAX_WTILES = 20;
 struct WgradArgs {
@@ -199,7 +203,7 @@ __device__ __forceinline__ wh8 tr_frag_tiled(const _Float16* stage, int srows, i
 // vmcnt(0) and the younger stage's latency is back on the critical path (a first attempt inside the generic
 // kernel measured +-0 for exactly that reason).  O and I are therefore template parameters (slot counts static),
 // rows past the range are loaded from the clamped last row and zeroed by a select.
-template <int O, int I, int NI, bool DEEP, bool TILED = false>
+template <int O, int I, int NI, bool DEEP, bool TILED = false, bool X2 = false>
 __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& job, const int split, unsigned char* smem_raw) {
     // (TILED B: the 256-wide activation planes, and since round 5 the 64- / 32-wide encoding planes of the register-resident
     // forward, whose columns are in ITS order -- the reduction kernel un-permutes them, sv_enc_channel)
@@ -216,8 +220,16 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
     constexpr int B_THREADS = B_CHUNKS >= 512 ? 512 : B_CHUNKS;   // threads that own a B chunk
     static_assert(SROWS * A_C8 % 512 == 0 && B_CHUNKS % B_THREADS == 0 && 512 % B_THREADS == 0, "slot layout");
     static_assert(I == NI * 32 * WI || I == 32, "two waves across I");
-    _Float16* lds = reinterpret_cast<_Float16*>(smem_raw);   // [buffer 2][operand A,B][SROWS][TR_RS]
+    _Float16* lds = reinterpret_cast<_Float16*>(smem_raw);   // [buffer 2][operand A,B][SROWS][TR_RS] (+ X2: [buffer 2][4 piece blocks])
+    // X2 (the view job, O = 128, of a tiled backward; round 5): its waves 4..7 own no output tile (o_base >= O) -- they
+    // multiply the SAME dz_view stage with a second, 32-wide B operand, the direction-encoding plane: the view layer's
+    // direction columns, for which a thin job used to read dz_view (256 B/row) a second time.
+    static_assert(!X2 || (O == HV && I == W && TILED && !DEEP), "the second B operand rides on the view job's idle waves");
+    constexpr int I2 = DPE_K, B2_CT = 4 * I2, B2_CHUNKS = SROWS * I2 / 8, B2_BLOCK = SROWS * 8 + TRB_PAD;
+    _Float16* lds2 = lds + (size_t)4 * SPLANE;
+    const _Float16* B2g = (const _Float16*)job.B2;
     const int tid = threadIdx.x, lane = tid & 63;
+    const int q2 = tid % B2_CHUNKS, b2_row = (q2 / B2_CT) * 32 + (q2 & 31), b2_col = (q2 % B2_CT) >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const _Float16* Ag = (const _Float16*)job.A;
     const _Float16* Bg = (const _Float16*)job.B;
@@ -245,7 +257,7 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
     }
     const int last_tile = (a.n_rows + 31) / 32 - 1;      // the last tile that holds a real row
     const bool b_owner = tid < B_THREADS;
-    struct Set { wh8 a[SA]; wh8 b[SB]; };
+    struct Set { wh8 a[SA]; wh8 b[SB]; wh8 b2; };
     Set s0, s1;      // (s1 only in the DEEP variant)
     // bias partial = column sums of the dz stage.  Row-major A: a thread's chunks share one chunk column.  Tiled A: its
     // chunks alternate between two piece blocks (q and q + 512: blocks pb and pb + 16), one set of sums each.
@@ -275,6 +287,9 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
             else
                 s.b[j] = *reinterpret_cast<const wh8*>(Bg + (size_t)min(m + b_row[j], last) * I + b_col[j]);
         }
+        if constexpr (X2)      // (every thread, like B: threads past the chunk count reload a neighbour's -- static load counts)
+            s.b2 = *reinterpret_cast<const wh8*>(
+                B2g + ((size_t)min((m >> 5) + (b2_row >> 5), last_tile) * B2_CT + b2_col * 32 + (b2_row & 31)) * 8);
     };
     auto stash = [&](const Set& s, const int buf, const int m) {
         _Float16* A0 = lds + (size_t)buf * 2 * SPLANE;
@@ -295,11 +310,25 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
                 *reinterpret_cast<wh8*>(dst) = m + b_row[j] < m_end ? s.b[j] : zero8;
             }
         }
+        if constexpr (X2) {
+            if (tid < B2_CHUNKS)
+                *reinterpret_cast<wh8*>(lds2 + (size_t)(buf * 4 + b2_col) * B2_BLOCK + b2_row * 8) = m + b2_row < m_end ? s.b2 : zero8;
+        }
     };
     f32x16 acc[NO][NI];
     zero_acc(acc);
     auto compute = [&](const int buf) {
-        if (!live) return;
+        if (!live) {
+            if constexpr (X2) {      // waves 4..7: output tile (wave - 4) of dz_view^T dpe, in acc[0][0] (theirs is otherwise unused)
+                const _Float16* A0 = lds + (size_t)buf * 2 * SPLANE;
+                const _Float16* B2s = lds2 + (size_t)buf * 4 * B2_BLOCK;
+#pragma unroll
+                for (int k = 0; k < KST; ++k)
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tr_frag(A0 + k * TR_PLANE, lane, 32 * (wave - 4)),
+                                                                       tr_frag_tiled(B2s, SROWS, k, lane, 0), acc[0][0], 0, 0, 0);
+            }
+            return;
+        }
         const _Float16* A0 = lds + (size_t)buf * 2 * SPLANE;
         const _Float16* B0 = A0 + SPLANE;
 #pragma unroll
@@ -364,6 +393,13 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
                 for (int r = 0; r < 16; ++r)
                     cpart[(size_t)(o_base + o * 32 + frag_row(r, lane)) * I + i_base + i * 32 + ll] = acc[o][i][r];
     }
+    if constexpr (X2) {
+        if (!live) {
+            float* c2 = part + job.part2_off;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c2[(size_t)(32 * (wave - 4) + frag_row(r, lane)) * I2 + (lane & 31)] = acc[0][0][r];
+        }
+    }
     if (job.bias_off >= 0) {
         // bias partial = column sums of the dz slabs: a thread's slots share one chunk column (512 % A_C8 == 0)
         float* red = reinterpret_cast<float*>(smem_raw);      // [RED_ROWS][O] floats, reusing the LDS
@@ -398,6 +434,7 @@ __global__ __launch_bounds__(512) void wgrad_thin_kernel(WgradArgs2 p) {
     const WgradArgs& a = p.n[second ? 1 : 0];
     const int split = (int)blockIdx.y - (second ? p.splits0 : 0);
     const int j = a.tile_job[blockIdx.x];
+    if (j < 0) return;      // (this network's direction columns ride on its view job: X2)
     const WJob job = a.jobs[j];
     if (job.b_tiled) {      // (uniform per workgroup: the register-resident forward's encoding planes)
         if (job.O == W) wgrad_half_body<W, PE_K, 1, true, true>(a, job, split, smem_raw);
@@ -417,7 +454,7 @@ __global__ __launch_bounds__(512) void wgrad_main_kernel(WgradArgs2 p) {
     const WJob job = a.jobs[a.tile_job[blockIdx.x]];
     if (job.b_tiled) {      // (uniform per workgroup)
         if (job.O == W) wgrad_half_body<W, W, 4, false, true>(a, job, split, smem_raw);
-        else wgrad_half_body<HV, W, 4, false, true>(a, job, split, smem_raw);
+        else wgrad_half_body<HV, W, 4, false, true, true>(a, job, split, smem_raw);      // (+ the direction columns: X2)
     } else {
         if (job.O == W) wgrad_half_body<W, W, 4, false>(a, job, split, smem_raw);
         else wgrad_half_body<HV, W, 4, false>(a, job, split, smem_raw);
@@ -662,7 +699,8 @@ struct ReduceArgs {
     const unsigned* gmax;   // 16-bit modes: the dz planes were scaled by 2^(DZH_TARGET_EXP - exponent(max |g_raw|))
     const unsigned* status; // the network's range status word (16-bit modes), or nullptr
     float* status_out;      // nullptr, or where this launch leaves (float)(*status != 0): the tail of the caller's flat gradient
-    int enc_tiled;          // the encoding planes were tiled (mlp_layout.h): column c of the thin jobs' results = channel sv_enc_channel(c)
+    int enc_tiled;          // the encoding planes were tiled (mlp_layout.h): column c of the thin jobs' results = channel sv_enc_channel(c);
+                            // the view layer's direction columns then come from the MAIN launch's row ranges (its view job)
     GradPtrs G;
 };
 
@@ -693,7 +731,7 @@ __global__ void wgrad_reduce_kernel(ReduceArgs2 p) {
     }
     // the thin jobs (encoding columns of L0 / L5, direction columns of the view layer, and L0's bias, which
     // rides on them) are launched over their own number of row ranges
-    const bool thin = (idx >= PART_PE0 && idx < PART_BIAS) || (idx >= PART_BIAS && idx < PART_BIAS + W);
+    const bool thin = (idx >= PART_PE0 && idx < (a.enc_tiled ? PART_VDIR : PART_BIAS)) || (idx >= PART_BIAS && idx < PART_BIAS + W);
     const int ns = thin ? a.splits_thin : a.splits;
     float s = 0.0f;
     {   // a batch's loads all in flight before its first add (one dependent load per add held the kernel at 33 us;
@@ -912,6 +950,7 @@ int plan_job(const plnerf::impl::WgradJob& jb, bool h16, int cap_main, int cap_t
         WJob& jv = a.jobs[8];
         jv.A = dzv_plane; jv.lda = HV; jv.B = splane(SV_FEAT); jv.ldb = W; jv.O = HV; jv.I = W;
         jv.part_off = PART_VMAIN; jv.bias_off = PART_BIAS + 9 * W; jv.b_tiled = tiled;
+        if (tiled) { jv.B2 = dpe_plane; jv.part2_off = PART_VDIR; }      // (the direction columns on the job's idle waves)
         a.tile_job[nt] = 8; a.tile_o0[nt++] = 0;
         a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
         P.main_args = a; P.nt = nt;
@@ -924,7 +963,8 @@ int plan_job(const plnerf::impl::WgradJob& jb, bool h16, int cap_main, int cap_t
         a.jobs[1] = WJob{dplane(5), pe_plane, W, PE_K, W, PE_K, PART_PE5, -1, tiled};
         a.jobs[2] = WJob{dzv_plane, dpe_plane, HV, DPE_K, HV, DPE_K, PART_VDIR, -1, tiled};
         for (int t = 0; t < 3; ++t) { a.tile_job[t] = t; a.tile_o0[t] = 0; }
-        // half: three tiles only, so more row ranges than the main launch to cover the 256 CUs (3 x 85 = 255).
+        if (tiled) a.tile_job[2] = -1;      // (dz_view^T dpe: the view job of the main launch)
+        // half: three (tiled: two) tiles only, so more row ranges than the main launch to cover the 256 CUs (3 x 85 = 255, 2 x 127).
         // (Equal ROW counts per workgroup, not equal bytes: a stage costs its latency whatever its width, so
         // giving the 128 x 32 job half as many, twice as long ranges measured 0.27 ms slower per step.)
         a.n_rows = n_rows; a.rows_per_split = h16 ? rps_thin : rps; a.part = part;
@@ -990,7 +1030,11 @@ int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, co
 int wgrad_h16_multi(int n, const WgradJob* jobs, hipStream_t st) {
     if (n < 1 || n > MAX_BWD_JOBS) return PLNERF_EINVAL;
     // the one round of workgroups, dealt out in proportion to the networks' rows (a single network: all of it, as before)
-    int cap_main[MAX_BWD_JOBS] = {WG_SPLITS, 0}, cap_thin[MAX_BWD_JOBS] = {85, 0};
+    bool all_tiled = true;
+    for (int j = 0; j < n; ++j) all_tiled = all_tiled && jobs[j].saved_layout == SV_LAYOUT_TILED;
+    const int thin_tiles = all_tiled ? 2 : 3;               // (tiled: the direction columns ride on the main launch's view job)
+    const int thin_round = all_tiled ? 127 : 85;            // row ranges of a thin job: 2 x 127 = 254 / 3 x 85 = 255 workgroups
+    int cap_main[MAX_BWD_JOBS] = {WG_SPLITS, 0}, cap_thin[MAX_BWD_JOBS] = {thin_round, 0};
     if (n == 2) {
         const double f = (double)jobs[0].n_rows / ((double)jobs[0].n_rows + (double)jobs[1].n_rows);
         auto deal = [&](int total, int* cap) {
@@ -999,7 +1043,7 @@ int wgrad_h16_multi(int n, const WgradJob* jobs, hipStream_t st) {
             cap[0] = s0; cap[1] = total - s0;
         };
         deal(WG_SPLITS, cap_main);
-        deal(85, cap_thin);
+        deal(thin_round, cap_thin);
     }
     WgradPlan P[MAX_BWD_JOBS];
     for (int j = 0; j < n; ++j) {
@@ -1008,12 +1052,14 @@ int wgrad_h16_multi(int n, const WgradJob* jobs, hipStream_t st) {
     }
     const size_t lds = (size_t)2 * 2 * TR_STEPS * TR_PLANE * sizeof(_Float16);
     {
+        // (+ the view job's second B operand, two buffers of four piece blocks)
+        const size_t lds_main = lds + (size_t)2 * 4 * (TR_ROWS * TR_STEPS * 8 + TRB_PAD) * sizeof(_Float16);
         WgradArgs2 a{};
         for (int j = 0; j < 2; ++j) a.n[j] = P[j < n ? j : 0].main_args;
         a.splits0 = P[0].splits;
         const int splits = P[0].splits + (n == 2 ? P[1].splits : 0);
-        (void)hipFuncSetAttribute((const void*)wgrad_main_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(wgrad_main_kernel, dim3(P[0].nt, splits), dim3(512), lds, st, a);
+        (void)hipFuncSetAttribute((const void*)wgrad_main_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main);
+        hipLaunchKernelGGL(wgrad_main_kernel, dim3(P[0].nt, splits), dim3(512), lds_main, st, a);
         PLNERF_CHECK_LAUNCH();
     }
     {
@@ -1022,7 +1068,7 @@ int wgrad_h16_multi(int n, const WgradJob* jobs, hipStream_t st) {
         a.splits0 = P[0].splits_thin;
         const int splits = P[0].splits_thin + (n == 2 ? P[1].splits_thin : 0);
         (void)hipFuncSetAttribute((const void*)wgrad_thin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(wgrad_thin_kernel, dim3(3, splits), dim3(512), lds, st, a);
+        hipLaunchKernelGGL(wgrad_thin_kernel, dim3(thin_tiles, splits), dim3(512), lds, st, a);
         PLNERF_CHECK_LAUNCH();
     }
     {
