@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PLNERF_VERSION 500 /* major*10000 + minor*100 + patch */
+#define PLNERF_VERSION 501 /* major*10000 + minor*100 + patch */
 
 /* error codes */
 #define PLNERF_OK 0
@@ -119,6 +119,19 @@ int plnerf_quad_bwd(const float* raw, const float* z, const float* near, const f
                     const float* g_depth, const float* g_acc, const float* g_weights,
                     const float* g_tau, const float* g_T, float* g_raw, uint32_t* absmax_out,
                     plnerf_stream_t stream);
+
+/* The same backward plus the gradient of the RAY GEOMETRY (ABI 501) -- what autograd also gives the reference when the
+ * ray batch itself requires a gradient (run_plnerf.py:707, 735: z_vals, near and far enter raw2outputs' interval lengths
+ * and depth map, run_plnerf.py:516-550, 604-617; |rays_d| scales every interval): g_z [R,S], g_near, g_far [R] (the outer
+ * knots of the piecewise-linear rule; written as zero in constant mode, which does not use them), g_dnorm [R] = d loss /
+ * d |rays_d| (the caller applies d|d|/dd = d / |d|).  All four required.  g_raw as above.  No reference training path
+ * asks for these (camera-pose optimisation would). */
+int plnerf_quad_bwd_rays(const float* raw, const float* z, const float* near, const float* far,
+                         const float* rays_d, const float* noise, int R, int S, int mode,
+                         int color_mode, int white_bkgd, int farcolorfix, const float* g_rgb,
+                         const float* g_depth, const float* g_acc, const float* g_weights,
+                         const float* g_tau, const float* g_T, float* g_raw, float* g_z, float* g_near,
+                         float* g_far, float* g_dnorm, plnerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Hierarchical samplers.  `u` holds the uniform draws: [R,N] when u_row_stride == N, or

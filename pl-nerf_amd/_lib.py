@@ -39,6 +39,7 @@ SIGNATURES = {
     "plnerf_error_string": (ctypes.c_char_p, [c_i]),
     "plnerf_quad_fwd": (c_i, [c_f] * 6 + [c_i] * 6 + [c_f] * 7 + [c_s]),
     "plnerf_quad_bwd": (c_i, [c_f] * 6 + [c_i] * 6 + [c_f] * 7 + [c_f, c_s]),
+    "plnerf_quad_bwd_rays": (c_i, [c_f] * 6 + [c_i] * 6 + [c_f] * 7 + [c_f] * 4 + [c_s]),
     "plnerf_sample_const": (c_i, [c_f] * 3 + [c_i] * 4 + [c_f] * 2 + [c_s]),
     "plnerf_sample_const_bwd": (c_i, [c_f] * 3 + [c_i] + [c_f] * 2 + [c_i] * 3 + [c_f] + [c_s]),
     "plnerf_sample_pl": (c_i, [c_f] * 7 + [c_i] * 4 + [ctypes.c_float] * 2 + [c_f] * 5 + [c_s]),

@@ -44,6 +44,13 @@ struct QuadArgs {
     // backward by-product (may be null): max |g_raw| of each workgroup's rays as fp32 bits, [ceil(R / WAVES)] -- the
     // candidates of the half dz planes' launch scale, which plnerf_mlp_bwd otherwise finds with a pass of its own over g_raw
     unsigned* absmax_out;
+    // backward, the ray geometry's gradient (all four or none; plnerf_quad_bwd_rays): what autograd gives the reference
+    // for z_vals [R,S], near, far [R] (the outer knots of the piecewise-linear rule; zero in constant mode) and for
+    // |rays_d| [R], which scales every interval
+    float* g_z;
+    float* g_near;
+    float* g_far;
+    float* g_dnorm;
 };
 
 template <int MODE>
@@ -137,6 +144,7 @@ __global__ __launch_bounds__(256) void quad_bwd_kernel(QuadArgs a) {
     float* av = fv + (n + 1);    // G_i (1 - e_i)  (av[n] = 0)
     float* wv = av + (n + 1);    // w_i
     float* qv = wv + (n + 1);    // T_i, then Q_i = dL/de_i * seg_i * e_i
+    float* sv = qv + (n + 1);    // (only with g_z) dL/dseg_i = dL/de_i * e_i * (-density of the interval)
     float dnorm;
     load_ray(RayIn{a.raw, a.z, a.near, a.far, a.rays_d, a.noise, a.S}, ray, lane, zk, tau, col, dnorm);
     const float gr = a.g_rgb[3 * ray + 0], gg = a.g_rgb[3 * ray + 1], gb = a.g_rgb[3 * ray + 2];
@@ -203,6 +211,10 @@ __global__ __launch_bounds__(256) void quad_bwd_kernel(QuadArgs a) {
             const float Ti = qv[i];
             const float dLde = Ti * (X - G);
             qv[i] = dLde * seg * e;                // Q_i
+            if (a.g_z) {                           // e_i = exp(-dens_i seg_i)
+                const float dens = (MODE == PLNERF_MODE_LINEAR) ? 0.5f * (tau[i + 1] + tau[i]) : tau[i + 1];
+                sv[i] = (dLde * e) * (-dens);
+            }
         }
     }
     __syncthreads();
@@ -247,6 +259,33 @@ __global__ __launch_bounds__(256) void quad_bwd_kernel(QuadArgs a) {
             }
             if (lane == 0) wave_max_bits[wave] = __float_as_uint(gmax);
         }
+    }
+    if (a.g_z && live) {
+        // seg_i = (knot_{i+1} - knot_i) |d|, the depth map weighs the elements' depths: a knot collects from the two
+        // elements it bounds.  Linear: knots [near, z, far], element i between knots i and i + 1, depth = their mean.
+        // Constant: element i from z_i to z_{i+1} (the last one is 1e10 |d| long), depth = z_i.
+        float gdn = 0.0f;
+        if (MODE == PLNERF_MODE_LINEAR) {
+            for (int k = lane; k < S + 2; k += 64) {
+                const float s_lo = k > 0 ? sv[k - 1] : 0.0f, s_hi = k <= S ? sv[k] : 0.0f;
+                const float w_lo = k > 0 ? wv[k - 1] : 0.0f, w_hi = k <= S ? wv[k] : 0.0f;
+                const float g = dnorm * (s_lo - s_hi) + gdep * (0.5f * (w_lo + w_hi));
+                if (k == 0) a.g_near[ray] = g;
+                else if (k == S + 1) a.g_far[ray] = g;
+                else a.g_z[(size_t)ray * S + k - 1] = g;
+                if (k <= S) gdn += sv[k] * (zk[k + 1] - zk[k]);
+            }
+        } else {
+            for (int k = lane; k < S; k += 64) {
+                const float s_lo = k > 0 ? sv[k - 1] : 0.0f, s_hi = k < S - 1 ? sv[k] : 0.0f;
+                a.g_z[(size_t)ray * S + k] = dnorm * (s_lo - s_hi) + gdep * wv[k];
+                gdn += sv[k] * (k < S - 1 ? zk[k + 2] - zk[k + 1] : 1e10f);
+            }
+            if (lane == 0) { a.g_near[ray] = 0.0f; a.g_far[ray] = 0.0f; }
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) gdn += __shfl_xor(gdn, d);
+        if (lane == 0) a.g_dnorm[ray] = gdn;
     }
     if (a.absmax_out) {
         // One plain store per workgroup, no atomic: 4096 atomicMax on one address cost the launch 46 us of serialised L2
@@ -310,12 +349,12 @@ extern "C" int plnerf_quad_fwd(const float* raw, const float* z, const float* ne
     return PLNERF_OK;
 }
 
-extern "C" int plnerf_quad_bwd(const float* raw, const float* z, const float* near, const float* far,
-                               const float* rays_d, const float* noise, int R, int S, int mode,
-                               int color_mode, int white_bkgd, int farcolorfix, const float* g_rgb,
-                               const float* g_depth, const float* g_acc, const float* g_weights,
-                               const float* g_tau, const float* g_T, float* g_raw, uint32_t* absmax_out,
-                               plnerf_stream_t stream) {
+namespace {
+int quad_bwd_launch(const float* raw, const float* z, const float* near, const float* far, const float* rays_d,
+                    const float* noise, int R, int S, int mode, int color_mode, int white_bkgd, int farcolorfix,
+                    const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_weights,
+                    const float* g_tau, const float* g_T, float* g_raw, uint32_t* absmax_out, float* g_z, float* g_near,
+                    float* g_far, float* g_dnorm, plnerf_stream_t stream) {
     int rc = check_common(raw, z, near, far, rays_d, R, S, mode, color_mode);
     if (rc) return rc;
     if (R == 0) return PLNERF_OK;
@@ -326,7 +365,8 @@ extern "C" int plnerf_quad_bwd(const float* raw, const float* z, const float* ne
     a.R = R; a.S = S; a.color_mode = color_mode; a.white_bkgd = white_bkgd; a.farcolorfix = farcolorfix;
     a.g_rgb = g_rgb; a.g_depth = g_depth; a.g_acc = g_acc; a.g_weights = g_weights; a.g_tau = g_tau; a.g_T = g_T; a.g_raw = g_raw;
     a.absmax_out = absmax_out;
-    a.lds_stride = ((5 * S + 4 + 4 * (S + 2)) + 3) & ~3;
+    a.g_z = g_z; a.g_near = g_near; a.g_far = g_far; a.g_dnorm = g_dnorm;
+    a.lds_stride = ((5 * S + 4 + (g_z ? 5 : 4) * (S + 2)) + 3) & ~3;
     const size_t lds = (size_t)WAVES * a.lds_stride * sizeof(float);
     dim3 grid((R + WAVES - 1) / WAVES), block(WAVES * 64);
     hipStream_t st = (hipStream_t)stream;
@@ -346,4 +386,26 @@ extern "C" int plnerf_quad_bwd(const float* raw, const float* z, const float* ne
         hipLaunchKernelGGL(quad_bwd_kernel<PLNERF_MODE_CONSTANT>, grid, block, lds, st, a);
     PLNERF_CHECK_LAUNCH();
     return PLNERF_OK;
+}
+}  // namespace
+
+extern "C" int plnerf_quad_bwd(const float* raw, const float* z, const float* near, const float* far,
+                               const float* rays_d, const float* noise, int R, int S, int mode,
+                               int color_mode, int white_bkgd, int farcolorfix, const float* g_rgb,
+                               const float* g_depth, const float* g_acc, const float* g_weights,
+                               const float* g_tau, const float* g_T, float* g_raw, uint32_t* absmax_out,
+                               plnerf_stream_t stream) {
+    return quad_bwd_launch(raw, z, near, far, rays_d, noise, R, S, mode, color_mode, white_bkgd, farcolorfix, g_rgb, g_depth,
+                           g_acc, g_weights, g_tau, g_T, g_raw, absmax_out, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int plnerf_quad_bwd_rays(const float* raw, const float* z, const float* near, const float* far,
+                                    const float* rays_d, const float* noise, int R, int S, int mode,
+                                    int color_mode, int white_bkgd, int farcolorfix, const float* g_rgb,
+                                    const float* g_depth, const float* g_acc, const float* g_weights,
+                                    const float* g_tau, const float* g_T, float* g_raw, float* g_z, float* g_near,
+                                    float* g_far, float* g_dnorm, plnerf_stream_t stream) {
+    if (R > 0 && (!g_z || !g_near || !g_far || !g_dnorm)) return PLNERF_EINVAL;
+    return quad_bwd_launch(raw, z, near, far, rays_d, noise, R, S, mode, color_mode, white_bkgd, farcolorfix, g_rgb, g_depth,
+                           g_acc, g_weights, g_tau, g_T, g_raw, nullptr, g_z, g_near, g_far, g_dnorm, stream);
 }

@@ -230,6 +230,13 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
     depth_map, z_vals, weights, pred_hyp, u (+ raw; + rgb0, disp0, acc0, depth0, z_vals0, weights0, z_std)."""
     dev = ray_batch.device
     N_rays = ray_batch.shape[0]
+    if torch.is_grad_enabled() and getattr(ray_batch, "requires_grad", False):
+        # The NVS render_rays carries a ray batch's gradient (render.py: plnerf_quad_bwd_rays + plnerf_mlp_input_grad).
+        # Here the depth hypotheses are samples that STAY attached (:923-934), and the sampler's backward
+        # (plnerf_sample_pl_bwd) covers weights / tau / T, not its bins: returning the rest would be silently wrong.
+        raise NotImplementedError(
+            "plnerf_amd: the depth-supervised render_rays has no gradient with respect to the ray batch (its depth "
+            "hypotheses depend on the ray geometry through the sampler's bins); detach the rays")
     if isinstance(ray_batch, RB.RayColumns):      # (what plnerf_select_rays writes: no packing, no slice copies)
         rays_o, rays_d, near, far = ray_batch.rays_o, ray_batch.rays_d, ray_batch.near.reshape(-1, 1), \
             ray_batch.far.reshape(-1, 1)
@@ -239,8 +246,7 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
         viewdirs = ray_batch[:, 8:11].contiguous() if use_viewdirs else None
         near, far = ray_batch[:, 6:7].contiguous(), ray_batch[:, 7:8].contiguous()
     t_vals = Fn.cpu_linspace(N_samples, dev)
-    fused_glue = ray_batch.is_cuda and N_rays > 0 and not (torch.is_grad_enabled() and
-                                                           getattr(ray_batch, "requires_grad", False))
+    fused_glue = ray_batch.is_cuda and N_rays > 0
     draws = None if pytest else Fn.DRAWS      # counter-based draws inside the consuming kernels (functional.DrawSource)
     if draws is not None:
         draws.noise_calls = 0

@@ -95,6 +95,7 @@ class QuadratureFn(torch.autograd.Function):
         ctx.save_for_backward(raw_c, z_c, near_c, far_c, d_c, noise_c if noise_c is not None else torch.empty(0),
                               depth, acc)
         ctx.cfg = (mode, color_mode, bool(white_bkgd), bool(farcolorfix), noise_c is not None)
+        ctx.near_shape, ctx.far_shape = near.shape, far.shape
         if not linear:
             ctx.mark_non_differentiable(tau, T)
         ctx.set_materialize_grads(False)
@@ -102,8 +103,18 @@ class QuadratureFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, g_w, g_depth, g_tau, g_T):
-        g_raw = _quad_backward(ctx.saved_tensors, ctx.cfg, g_rgb, g_disp, g_acc, g_w, g_depth, g_tau, g_T)
-        return g_raw, None, None, None, None, None, None, None, None, None
+        if not any(ctx.needs_input_grad[1:5]):
+            g_raw = _quad_backward(ctx.saved_tensors, ctx.cfg, g_rgb, g_disp, g_acc, g_w, g_depth, g_tau, g_T)
+            return g_raw, None, None, None, None, None, None, None, None, None
+        # the ray geometry asks too (z_vals / near / far / rays_d came from a ray batch that requires a gradient:
+        # run_plnerf.py:707, 735 under autograd) -- plnerf_quad_bwd_rays
+        g_raw, g_z, g_near, g_far, g_dnorm = _quad_backward(ctx.saved_tensors, ctx.cfg, g_rgb, g_disp, g_acc, g_w, g_depth,
+                                                            g_tau, g_T, geometry=True)
+        d_c = ctx.saved_tensors[4]
+        need = ctx.needs_input_grad
+        g_d = (g_dnorm[:, None] * (d_c / torch.norm(d_c, dim=-1, keepdim=True))) if need[4] else None
+        return (g_raw, g_z if need[1] else None, g_near.reshape(ctx.near_shape) if need[2] else None,
+                g_far.reshape(ctx.far_shape) if need[3] else None, g_d, None, None, None, None, None)
 
 
 # Armed (a list) by a caller that runs plnerf_quad_bwd and the MLP backward itself, back to back (train.TrainStep's merged
@@ -114,9 +125,10 @@ class QuadratureFn(torch.autograd.Function):
 ABSMAX_LOG = None
 
 
-def _quad_backward(saved, cfg, g_rgb, g_disp, g_acc, g_w, g_depth, g_tau, g_T):
+def _quad_backward(saved, cfg, g_rgb, g_disp, g_acc, g_w, g_depth, g_tau, g_T, geometry=False):
     """plnerf_quad_bwd from the tensors a quadrature forward saved (shared by QuadratureFn and CoarseEpilogueFn).  With
-    ABSMAX_LOG armed the launch also leaves its workgroups' max |g_raw| in a tensor and logs it."""
+    ABSMAX_LOG armed the launch also leaves its workgroups' max |g_raw| in a tensor and logs it.  geometry=True:
+    plnerf_quad_bwd_rays -- returns (g_raw, g_z, g_near, g_far, g_dnorm)."""
     raw_c, z_c, near_c, far_c, d_c, noise_c, depth, acc = saved
     mode, color_mode, white_bkgd, farcolorfix, has_noise = cfg
     R, S = z_c.shape
@@ -138,6 +150,17 @@ def _quad_backward(saved, cfg, g_rgb, g_disp, g_acc, g_w, g_depth, g_tau, g_T):
     g_tau = None if (g_tau is None or mode != "linear") else _f32c(g_tau)
     g_T = None if (g_T is None or mode != "linear") else _f32c(g_T)
     g_raw = torch.empty(R, S, 4, device=dev)
+    if geometry:
+        g_z = torch.empty(R, S, device=dev)
+        g_near, g_far, g_dnorm = (torch.empty(R, device=dev) for _ in range(3))
+        if R > 0:
+            L.check(L.lib().plnerf_quad_bwd_rays(
+              L.dptr(raw_c), L.dptr(z_c), L.dptr(near_c), L.dptr(far_c), L.dptr(d_c),
+              L.dptr(noise_c) if has_noise else None, R, S, L.MODE[mode], L.COLOR[color_mode],
+              int(white_bkgd), int(farcolorfix), L.dptr(g_rgb), L.dptr(g_depth), L.dptr(g_acc), L.dptr(g_w),
+              L.dptr(g_tau), L.dptr(g_T), L.dptr(g_raw), L.dptr(g_z), L.dptr(g_near), L.dptr(g_far), L.dptr(g_dnorm),
+              L.stream()), "plnerf_quad_bwd_rays")
+        return g_raw, g_z, g_near, g_far, g_dnorm
     if R > 0:
         cand = None
         if ABSMAX_LOG is not None:

@@ -173,15 +173,6 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_
     + rgb0, disp0, depth0, acc0, z_std if N_importance > 0)."""
     dev = ray_batch.device
     N_rays = ray_batch.shape[0]
-    if torch.is_grad_enabled() and getattr(ray_batch, "requires_grad", False):
-        # In the reference autograd would carry d(loss)/d(rays) through z_vals, the sample positions AND the MLP's
-        # inputs.  The MLP's inputs have their gradient here (NeRF.query / NeRF.forward: plnerf_mlp_input_grad); the
-        # quadrature's z_vals / ray-length inputs and the fused position kernels do not (SURVEY.md section 8d: nothing
-        # on the training path asks).  Returning a partial gradient would be silently wrong.
-        raise NotImplementedError(
-            "plnerf_amd: render_rays has no gradient with respect to the ray batch (origins / directions / bounds); "
-            "detach the rays -- the network itself is differentiable in its inputs (NeRF.query, NeRF.forward), the "
-            "quadrature and the samplers with respect to the ray geometry are not")
     if isinstance(ray_batch, RB.RayColumns):
         rays_o, rays_d, near, far, viewdirs = (ray_batch.rays_o, ray_batch.rays_d, ray_batch.near.reshape(-1, 1),
                                                ray_batch.far.reshape(-1, 1), ray_batch.viewdirs)
@@ -191,11 +182,18 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_
         rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
         viewdirs = ray_batch[:, -3:].contiguous() if ray_batch.shape[-1] > 8 else None
         near, far = ray_batch[:, 6:7].contiguous(), ray_batch[:, 7:8].contiguous()
+    # A ray batch that requires a gradient (no reference training path has one; camera-pose optimisation would): autograd
+    # carries d(loss)/d(rays) through z_vals, the sample positions, the interval lengths and the MLP's inputs
+    # (run_plnerf.py:683-707, 731-735 are torch expressions there).  The same expressions run here as torch operations, the
+    # quadrature returns the geometry's gradient (plnerf_quad_bwd_rays) and the MLP its inputs' (plnerf_mlp_input_grad);
+    # the fused position / epilogue kernels are for batches without one.
+    rays_grad = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (rays_o, rays_d, near, far, viewdirs))
 
     t_vals = Fn.cpu_linspace(N_samples, dev)
-    # The ray batch carries no gradient on this path (refused above), so the prologue's element-wise chain runs as
-    # ONE kernel (depths + positions, bit-identical to the torch expressions below, which remain for an empty batch).
-    fused_glue = ray_batch.is_cuda and N_rays > 0
+    # Without a gradient for the ray batch the prologue's element-wise chain runs as ONE kernel (depths + positions,
+    # bit-identical to the torch expressions below, which remain for an empty batch and for rays_grad).
+    fused_glue = ray_batch.is_cuda and N_rays > 0 and not rays_grad
     # Random draws: pytest=True replays the reference's numpy draws; otherwise an installed functional.DrawSource
     # supplies counter-based draws (inside the consuming kernels on the fused path), else torch.rand as the
     # reference does.
@@ -253,22 +251,34 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_
 
     if N_importance > 0 and not fused_epilogue:
         rgb_map_0, disp_map_0, acc_map_0, depth_map_0 = rgb_map, disp_map, acc_map, depth_map
-        if mode == "linear" and tap is not None:
-            u = _draw_u(z_vals.shape[:-1], N_importance, perturb == 0., pytest, dev)
-            z_samples, inds = Fn.sample_pl(z_vals, weights, tau, T, near, far, u, zero_tol, epsilon, want_inds=True)
-            tap.update(weights0=weights, tau0=tau, T0=T, u=u, inds=inds)
-        elif mode == "linear":
-            z_samples, _, _, _ = sample_pdf_reformulation(
-                z_vals, weights, tau, T, near, far, N_importance, det=(perturb == 0.), pytest=pytest,
-                quad_solution_v2=quad_solution_v2, zero_threshold=zero_tol, epsilon_=epsilon)
-        elif mode == "constant":
-            z_vals_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
-            z_samples = sample_pdf(z_vals_mid, weights[..., 1:-1], N_importance, det=(perturb == 0.),
-                                   pytest=pytest)
+        with torch.set_grad_enabled(torch.is_grad_enabled() and not rays_grad):      # (rays_grad: detached below either way)
+            if mode == "linear" and tap is not None:
+                u = _draw_u(z_vals.shape[:-1], N_importance, perturb == 0., pytest, dev)
+                z_samples, inds = Fn.sample_pl(z_vals, weights, tau, T, near, far, u, zero_tol, epsilon, want_inds=True)
+                tap.update(weights0=weights, tau0=tau, T0=T, u=u, inds=inds)
+            elif mode == "linear":
+                z_samples, _, _, _ = sample_pdf_reformulation(
+                    z_vals, weights, tau, T, near, far, N_importance, det=(perturb == 0.), pytest=pytest,
+                    quad_solution_v2=quad_solution_v2, zero_threshold=zero_tol, epsilon_=epsilon)
+            elif mode == "constant":
+                z_vals_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
+                z_samples = sample_pdf(z_vals_mid, weights[..., 1:-1], N_importance, det=(perturb == 0.),
+                                       pytest=pytest)
         z_samples = z_samples.detach()
-        # clamp + cat + sort (run_plnerf.py:731-734) in one kernel; z_samples clamped for z_std
-        z_vals = Fn.merge_sort(z_vals, z_samples, near, far)
-        z_std = torch.std(torch.clamp(z_samples, near, far), dim=-1, unbiased=False)
+        if rays_grad:
+            # run_plnerf.py:731-734 as written: the clamp's bounds and the coarse depths carry the batch's gradient
+            z_clamped = torch.clamp(z_samples, near, far)
+            z_vals, order = torch.sort(torch.cat([z_vals, z_clamped], -1), -1)
+            z_std = torch.std(z_clamped, dim=-1, unbiased=False)
+            if tap is not None:
+                # (a fine sample that the sampler's clamp put ON a coarse depth ties with it, and the tied slots' gradients
+                # reach near / far through whichever of the two the sort placed there -- torch.sort is not stable, here as
+                # in the reference; a test that compares gradients slot by slot needs the order that was used)
+                tap.update(sort_order=order)
+        else:
+            # clamp + cat + sort in one kernel; z_samples clamped for z_std
+            z_vals = Fn.merge_sort(z_vals, z_samples, near, far)
+            z_std = torch.std(torch.clamp(z_samples, near, far), dim=-1, unbiased=False)
         if fused_glue:
             pts = Fn.ray_points(rays_o, rays_d, z_vals)
         else:
