@@ -436,9 +436,8 @@ __global__ __launch_bounds__(512) void wgrad_thin_kernel(WgradArgs2 p) {
     const int j = a.tile_job[blockIdx.x];
     if (j < 0) return;      // (this network's direction columns ride on its view job: X2)
     const WJob job = a.jobs[j];
-    if (job.b_tiled) {      // (uniform per workgroup: the register-resident forward's encoding planes)
-        if (job.O == W) wgrad_half_body<W, PE_K, 1, true, true>(a, job, split, smem_raw);
-        else wgrad_half_body<HV, DPE_K, 1, true, true>(a, job, split, smem_raw);
+    if (job.b_tiled) {      // (uniform per workgroup: the register-resident forward's encoding planes; O = W only -- X2 above)
+        wgrad_half_body<W, PE_K, 1, true, true>(a, job, split, smem_raw);
     } else {
         if (job.O == W) wgrad_half_body<W, PE_K, 1, true>(a, job, split, smem_raw);      // encoding columns of L0 / L5
         else wgrad_half_body<HV, DPE_K, 1, true>(a, job, split, smem_raw);               // direction columns of the view layer

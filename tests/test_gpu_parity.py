@@ -5,6 +5,8 @@ Tolerances: bit-exact for searchsorted indices; 1e-5 (abs+rel) for rendered quan
 stage on identical inputs (the end-to-end pipeline is discontinuous in the
 sampler, so per-stage parity is the meaningful statement).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -411,6 +413,81 @@ def test_mlp_fwd_bwd_vs_oracle(P, R, S):
         scale = float(ref.abs().max())
         err = maxdiff(prm.grad, ref)
         assert err <= 2e-5 * max(scale, 1e-3) + 1e-7, f"grad {name}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_c_host_without_torch(P, precision, tmp_path):
+    """The drop-in boundary is the C ABI, not the Python mirror: tests/c_abi_gpu.cpp -- a host that knows only
+    include/plnerf_hip.h and the HIP runtime (g++, no torch, no Python) -- packs the weights, runs the network, the
+    piecewise-linear quadrature, both backwards and one Adam step on device memory it allocated itself; its outputs are
+    compared with the oracle (forward 1e-5; gradients at the bounds of test_mlp_fwd_bwd_vs_oracle / test_mlp_bf16_modes) and
+    with the Python mirror's on the same inputs (the same kernels: bit for bit)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_gpu")
+    libdir = os.path.join(root, "pl-nerf_amd")
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"), "-I", "/opt/rocm/include",
+                            os.path.join(root, "tests", "c_abi_gpu.cpp"), "-o", exe, "-L", libdir, "-lplnerf_hip",
+                            "-L", "/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"],
+                           capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-2000:]
+    R, S = 37, 50                                  # (1850 rows: ragged against every tile size)
+    gen = torch.Generator().manual_seed(4242)
+    pts = (torch.rand(R, S, 3, generator=gen) * 2 - 1) * 2.5
+    vd = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
+    z, _ = torch.sort(2.0 + 4.0 * torch.rand(R, S, generator=gen), -1)
+    near, far = torch.full((R, 1), 2.0), torch.full((R, 1), 6.0)
+    d = torch.randn(R, 3, generator=gen)
+    g_rgb, g_depth, g_acc = torch.randn(R, 3, generator=gen), torch.randn(R, generator=gen), torch.randn(R, generator=gen)
+    sd = orc.closed_form_state_dict(3, True)
+    names = [n for n, _ in orc.param_shapes()]
+    with open(tmp_path / "in.bin", "wb") as f:
+        for t in [sd[n] for n in names] + [pts, vd, z, near, far, d, g_rgb, g_depth, g_acc]:
+            f.write(t.contiguous().float().numpy().tobytes())
+    prec = {"fp32": 0, "f16x3": 3}[precision]      # PLNERF_PREC_*
+    run = subprocess.run([exe, str(prec), str(R), str(S), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")],
+                         capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, (run.returncode, run.stderr[-2000:])
+    out = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
+    pos = [0]
+
+    def take(*shape):
+        n = int(np.prod(shape))
+        a = torch.from_numpy(out[pos[0]:pos[0] + n].copy()).reshape(*shape)
+        pos[0] += n
+        return a
+    raw, rgb, disp, acc, depth, w, g_raw = (take(R, S, 4), take(R, 3), take(R), take(R), take(R), take(R, S + 1),
+                                            take(R, S, 4))
+    grads = {n: take(*shp) for n, shp in orc.param_shapes()}
+    w0_after = take(*dict(orc.param_shapes())[names[0]])
+    assert pos[0] == out.size
+    # the oracle on the same inputs
+    sd_o = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    raw_o = orc.query_network(sd_o, pts, vd)
+    ro = orc.raw2outputs(raw_o, z, near, far, d, "linear", "midpoint", white_bkgd=True)
+    ((ro[0] * g_rgb).sum() + (ro[4] * g_depth).sum() + (ro[2] * g_acc).sum()).backward()
+    assert_close(raw, raw_o, what="C host: raw")
+    for name, a, b in (("rgb", rgb, ro[0]), ("disp", disp, ro[1]), ("acc", acc, ro[2]), ("weights", w, ro[3]), ("depth", depth, ro[4])):
+        assert_close(a, b, what=f"C host: {name}")
+    gtol = 2e-5 if precision == "fp32" else 1.5e-3
+    for n in names:
+        ref = sd_o[n].grad
+        err, scale = maxdiff(grads[n], ref), float(ref.abs().max())
+        assert err <= gtol * max(scale, 1e-3) + 1e-7, f"C host: grad {n}: {err:.3e} vs scale {scale:.3e}"
+    # Adam, step 1 from zero moments: the parameter moves by lr * g / (|g| + eps (1 - beta2)^0.5 ...) -- torch's own step
+    p0 = sd[names[0]].clone().requires_grad_(True)
+    p0.grad = grads[names[0]].clone()
+    torch.optim.Adam([p0], lr=5e-4, betas=(0.9, 0.999), eps=1e-8).step()
+    assert float((w0_after - p0.detach()).abs().max()) <= 1e-7
+    # the Python mirror drives the same kernels: bit for bit
+    from plnerf_amd.functional import QuadratureFn
+    net = make_net(P, sd, precision)
+    raw_h = net.query(g(pts), g(vd))
+    rh = QuadratureFn.apply(raw_h, g(z), g(near), g(far), g(d), None, "linear", "midpoint", True, False)
+    ((rh[0] * g(g_rgb)).sum() + (rh[4] * g(g_depth)).sum() + (rh[2] * g(g_acc)).sum()).backward()
+    assert torch.equal(raw_h.detach().cpu(), raw) and torch.equal(rh[0].detach().cpu(), rgb)
+    for n, prm in net.named_parameters():
+        assert torch.equal(prm.grad.cpu(), grads[n]), n
 
 
 @pytest.mark.parametrize("precision,fwd_tol,grad_tol", [("bf16x3", 1e-5, 1.5e-3), ("f16x3", 2e-6, 1.5e-3), ("bf16", 5e-3, 5e-2),
