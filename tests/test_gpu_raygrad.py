@@ -272,6 +272,42 @@ def test_single_pass_lindisp_and_one_column_group(P):
     assert float(err.max()) <= 5e-4
 
 
+def test_camera_pose_gradient_through_render(P):
+    """The use a ray-batch gradient has: d loss / d c2w through render() (run_plnerf.py:110-175: get_rays, unit view
+    directions, packing, chunks of render_rays) -- every host step of the mirror is a torch expression and stays on the
+    tape.  6 x 8 pixels, 32 + 48 samples, two chunks; against the same chain in fp64."""
+    H, W, Ns, Ni = 6, 8, 32, 48
+    K = [[10.0, 0.0, W / 2], [0.0, 10.0, H / 2], [0.0, 0.0, 1.0]]
+    c2w = orc.pose_spherical(30.0, -30.0, 4.0)[:3, :4]
+    sd_c, sd_f = _decisive_state_dict(0, max_band=3), _decisive_state_dict(1, max_band=3)
+    gen = torch.Generator().manual_seed(23)
+    cot_rgb, cot_depth = torch.randn(H, W, 3, generator=gen), torch.randn(H, W, generator=gen)
+    kw = dict(N_samples=Ns, mode="linear", color_mode="midpoint", perturb=0.0, N_importance=Ni, white_bkgd=True)
+    # fp64: the same chain written out
+    c_o = c2w.double().clone().requires_grad_(True)
+    px = torch.arange(W, dtype=torch.float64)[None, :].expand(H, W)
+    py = torch.arange(H, dtype=torch.float64)[:, None].expand(H, W)
+    cam = torch.stack([(px - K[0][2]) / K[0][0], -(py - K[1][2]) / K[1][1], -torch.ones_like(px)], -1)
+    d = torch.sum(cam[..., None, :] * c_o[:3, :3], -1).reshape(-1, 3)
+    o = c_o[:3, -1].expand(d.shape)
+    ones = torch.ones_like(d[:, :1])
+    batch = torch.cat([o, d, 2.0 * ones, 6.0 * ones, d / torch.norm(d, dim=-1, keepdim=True)], -1)
+    ref = orc.render_rays(batch, {k: v.double() for k, v in sd_c.items()}, {k: v.double() for k, v in sd_f.items()}, Ns,
+                          "linear", "midpoint", perturb=0.0, N_importance=Ni, white_bkgd=True)
+    ((ref["rgb_map"].reshape(H, W, 3) * cot_rgb.double()).sum() + (ref["depth_map"].reshape(H, W) * cot_depth.double()).sum()).backward()
+    # the mirror
+    net_c, net_f = make_net(P, sd_c, "fp32"), make_net(P, sd_f, "fp32")
+    c_h = g(c2w).clone().requires_grad_(True)
+    rgb, disp, acc, extras = P.render(H, W, K, chunk=32, c2w=c_h, ndc=False, near=2.0, far=6.0, use_viewdirs=True,
+                                      network_fn=net_c, network_fine=net_f, network_query_fn=_query_fn(P), **kw)
+    assert rgb.shape == (H, W, 3) and float((rgb.detach().cpu().double() - ref["rgb_map"].detach().reshape(H, W, 3)).abs().max()) <= 5e-4
+    ((rgb * g(cot_rgb)).sum() + (extras["depth_map"] * g(cot_depth)).sum()).backward()
+    scale = float(c_o.grad.abs().max())
+    err = float((c_h.grad.cpu().double() - c_o.grad).abs().max()) / scale
+    print(f"d loss / d c2w: max |g| {scale:.3g}, largest error {err:.2e} of it")
+    assert c_h.grad.shape == (3, 4) and err <= 2e-5
+
+
 def test_depth_variant_refuses_a_ray_batch_gradient(P):
     """Its depth hypotheses are samples that stay attached (run_nerf_sample_based_depth.py:923-934) and the sampler's
     backward covers weights / tau / T only, not the bins: a partial gradient would be silently wrong."""
