@@ -271,7 +271,8 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, mode, color_
             z_vals, order = torch.sort(torch.cat([z_vals, z_clamped], -1), -1)
             z_std = torch.std(z_clamped, dim=-1, unbiased=False)
             if tap is not None:
-                # (a fine sample that the sampler's clamp put ON a coarse depth ties with it, and the tied slots' gradients
+                # (a fine sample ON a coarse depth -- the sampler returns the left knot where the density is flat,
+                # run_nerf_helpers.py:425 -- ties with it, and the tied slots' gradients
                 # reach near / far through whichever of the two the sort placed there -- torch.sort is not stable, here as
                 # in the reference; a test that compares gradients slot by slot needs the order that was used)
                 tap.update(sort_order=order)

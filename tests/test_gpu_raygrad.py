@@ -121,10 +121,9 @@ def _decisive_state_dict(seed, box=4.5, n_probe=20000, margin=1.5, max_band=None
         sd[key] += -0.5 * (hi + lo) + sign * (margin * 0.5 * (hi - lo) + 0.05)
     _, sigma, rgb = _preactivations(sd, pts, vd)
     # density ~ N(0.3, 0.06^2): positive everywhere (its own ReLU is decisive too), rays end semi-transparent.  Empty space
-    # would do more than flip that ReLU: where tau = 0 the sampler's closed form degenerates and its clamp puts the sample ON
-    # the next coarse depth (run_nerf_helpers.py:340-361) -- a tie in the sort of :734, and autograd hands the tied slot's
-    # gradient to near / far through whichever of the two equal values the sort placed there, which differs between fp32
-    # and the fp64 oracle (measured: near / far off by 7e-2 on such rays, every other column at 7e-6).
+    # would do more than flip that ReLU: between two knots of equal density (tau = 0 on both sides) the sampler returns the
+    # LEFT KNOT itself (run_nerf_helpers.py:425, |d tau| < zero_threshold) -- a tie in the sort of run_plnerf.py:734 for every
+    # sample that lands in empty space (_both_gradients deals with the few ties that remain).
     k_s = 0.06 / float(sigma.std())
     sd["alpha_linear.weight"] *= k_s
     sd["alpha_linear.bias"] = (sd["alpha_linear.bias"] - sigma.mean()) * k_s + 0.3
@@ -144,8 +143,9 @@ def _both_gradients(P, batch, sd_c, sd_f, precision, mode, Ns, Ni, cot, **extra)
 
     The fine pass of the fp64 side runs on the HIP path's OWN importance samples in the HIP path's OWN sort order (taken
     from render.STAGE_TAP).  The samples are detached on both sides (run_plnerf.py:728), so this changes no gradient path;
-    what it removes is an ambiguity of the reference itself: the sampler's clamp puts several samples per ray exactly ON a
-    coarse depth (run_nerf_helpers.py:349, 361), the sort of :734 then holds ties, torch.sort is not stable, and the two
+    what it removes is an ambiguity of the reference itself: where the density is flat between two knots the sampler returns
+    the left knot itself (run_nerf_helpers.py:425) -- several samples per ray exactly ON a coarse depth -- the sort of :734
+    then holds ties, torch.sort is not stable, and the two
     tied slots hand different gradients to near / far depending on which of the equal values landed where (measured
     before this: near / far off by up to 5e-2 on exactly the rays with ties, every other column at 7e-6)."""
     import sys
