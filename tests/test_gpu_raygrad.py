@@ -14,6 +14,8 @@ are data -- but a drop-in must either give the same gradient or refuse, never a 
 
 Tolerances are stated at each assertion, as fractions of the largest |g| of the column group.
 """
+import functools
+
 import pytest
 import torch
 
@@ -92,6 +94,7 @@ def _preactivations(sd64, pts64, vd64):
     return torch.cat(zs, -1), sigma, rgb
 
 
+@functools.lru_cache(maxsize=None)
 def _decisive_state_dict(seed, box=4.5, n_probe=20000, margin=1.5, max_band=None):
     """The closed-form weights with every hidden unit's bias moved so that the unit is decisively ON or decisively OFF
     over the whole scene box (at random, half each), and the heads rescaled to a scene-like density / colour range.
@@ -110,16 +113,26 @@ def _decisive_state_dict(seed, box=4.5, n_probe=20000, margin=1.5, max_band=None
         sd["pts_linears.0.weight"][:, 3 + 6 * max_band:orc.XYZ_CH] = 0.0
         sd[f"pts_linears.{orc.SKIP_AFTER + 1}.weight"][:, 3 + 6 * max_band:orc.XYZ_CH] = 0.0
     gen = torch.Generator().manual_seed(1000 + seed)
-    pts = (torch.rand(n_probe, 1, 3, generator=gen, dtype=torch.float64) * 2 - 1) * box
+    pts = (torch.rand(n_probe, 3, generator=gen, dtype=torch.float64) * 2 - 1) * box
     vd = F.normalize(torch.randn(n_probe, 3, generator=gen, dtype=torch.float64), dim=-1)
-    widths = [orc.WIDTH] * orc.DEPTH + [orc.WIDTH // 2]
-    keys = [f"pts_linears.{i}.bias" for i in range(orc.DEPTH)] + ["views_linears.0.bias"]
-    for layer, (key, width) in enumerate(zip(keys, widths)):      # (layer by layer: a shift changes what follows)
-        z = _preactivations(sd, pts, vd)[0][:, sum(widths[:layer]):sum(widths[:layer]) + width]
+    enc_xyz, enc_dir = orc.positional_encoding(pts, orc.XYZ_FREQS), orc.positional_encoding(vd, orc.DIR_FREQS)
+
+    def decide(z, key):      # move every unit's range over the probe points away from zero, on or off at random
         lo, hi = z.min(0).values, z.max(0).values
-        sign = torch.where(torch.rand(width, generator=gen) < 0.5, 1.0, -1.0).double()
-        sd[key] += -0.5 * (hi + lo) + sign * (margin * 0.5 * (hi - lo) + 0.05)
-    _, sigma, rgb = _preactivations(sd, pts, vd)
+        sign = torch.where(torch.rand(z.shape[1], generator=gen) < 0.5, 1.0, -1.0).double()
+        shift = -0.5 * (hi + lo) + sign * (margin * 0.5 * (hi - lo) + 0.05)
+        sd[key] += shift
+        return z + shift
+    h = enc_xyz
+    for i in range(orc.DEPTH):      # (one walk: a layer's shift is known before the next layer is evaluated)
+        h = F.relu(decide(F.linear(h, sd[f"pts_linears.{i}.weight"], sd[f"pts_linears.{i}.bias"]), f"pts_linears.{i}.bias"))
+        if i == orc.SKIP_AFTER:
+            h = torch.cat([enc_xyz, h], -1)
+    sigma = F.linear(h, sd["alpha_linear.weight"], sd["alpha_linear.bias"])
+    feat = F.linear(h, sd["feature_linear.weight"], sd["feature_linear.bias"])
+    hv = F.relu(decide(F.linear(torch.cat([feat, enc_dir], -1), sd["views_linears.0.weight"], sd["views_linears.0.bias"]),
+                       "views_linears.0.bias"))
+    rgb = F.linear(hv, sd["rgb_linear.weight"], sd["rgb_linear.bias"])
     # density ~ N(0.3, 0.06^2): positive everywhere (its own ReLU is decisive too), rays end semi-transparent.  Empty space
     # would do more than flip that ReLU: between two knots of equal density (tau = 0 on both sides) the sampler returns the
     # LEFT KNOT itself (run_nerf_helpers.py:425, |d tau| < zero_threshold) -- a tie in the sort of run_plnerf.py:734 for every
