@@ -123,6 +123,10 @@ def run_network(inputs, viewdirs, embedded_cam, fn, embed_fn, embeddirs_fn, bb_c
                 (not fn.use_viewdirs or fn.input_ch_views == 3 + 6 * fd)):
             # the encoding in the MLP kernel's own prologue, as on the NVS path: no `embedded` matrix at all
             rays_per_launch = max(1, MAX_ROWS_PER_LAUNCH // max(S, 1))
+            if not torch.is_grad_enabled():      # (inference saves nothing: one launch whatever the size)
+                rays_per_launch = max(R, 1)
+            else:                                # equal shares (a remainder launch of a few rows costs a whole tile walk)
+                rays_per_launch = -(-R // max(-(-R // rays_per_launch), 1)) if R > 0 else 1
             vd = viewdirs if fn.use_viewdirs else None
             outs = [fn.query(inputs[i:i + rays_per_launch], None if vd is None else vd[i:i + rays_per_launch],
                              input_scale=scale) for i in range(0, R, rays_per_launch)]

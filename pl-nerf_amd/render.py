@@ -56,10 +56,13 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
         rays_per_launch = max(1, MAX_ROWS_PER_LAUNCH // max(S, 1))
         if not fn.use_viewdirs:
             viewdirs = None
-        if R <= rays_per_launch:
+        if R <= rays_per_launch or not torch.is_grad_enabled():      # (inference saves nothing: one launch whatever the size)
             return fn.query(inputs, viewdirs)
-        outs = [fn.query(inputs[i:i + rays_per_launch], None if viewdirs is None else viewdirs[i:i + rays_per_launch])
-                for i in range(0, R, rays_per_launch)]
+        # equal shares: a remainder launch of a few hundred rows costs a whole tile walk (60 us for 384 rows of a 32,768-ray
+        # chunk at 192 samples, 57 times per 800 x 800 frame -- profiles/r05_render_frame_kernel_stats.csv)
+        n_launches = -(-R // rays_per_launch)
+        per = -(-R // n_launches)
+        outs = [fn.query(inputs[i:i + per], None if viewdirs is None else viewdirs[i:i + per]) for i in range(0, R, per)]
         return torch.cat(outs, 0)
     inputs_flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
     embedded = embed_fn(inputs_flat)
