@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PLNERF_VERSION 501 /* major*10000 + minor*100 + patch */
+#define PLNERF_VERSION 502 /* major*10000 + minor*100 + patch */
 
 /* error codes */
 #define PLNERF_OK 0
@@ -178,6 +178,15 @@ int plnerf_sample_pl_bwd(const float* z, const float* tau, const float* T, const
                          const float* far, const float* u, int u_row_stride, const int64_t* inds,
                          const float* g_samples, int R, int S, int N, float zero_tol, float epsilon,
                          float* g_tau, float* g_T, plnerf_stream_t stream);
+
+/* The same backward plus the gradient of the KNOTS (ABI 502): g_knots [R,S+2] for [near, z, far] -- what autograd also gives
+ * the reference when the sampler's bins carry a gradient (a ray batch that requires one; run_nerf_helpers.py:340-361, 425, 432:
+ * the closed-form inverse depends on the interval's ends directly and through its length, a flat interval and a NaN sample are
+ * the left knot itself, the clamp's upper bound is the interval's length).  g_tau, g_T as above. */
+int plnerf_sample_pl_bwd_rays(const float* z, const float* tau, const float* T, const float* near,
+                              const float* far, const float* u, int u_row_stride, const int64_t* inds,
+                              const float* g_samples, int R, int S, int N, float zero_tol, float epsilon,
+                              float* g_tau, float* g_T, float* g_knots, plnerf_stream_t stream);
 
 /* Coarse sample depths of a ray batch (run_plnerf.py:683-705): z = near (1 - t) + far t over the table
  * t_vals [S] (= torch.linspace(0, 1, S), supplied by the caller), or the `lindisp` form 1 / (1/near (1 - t) +

@@ -44,6 +44,7 @@ SIGNATURES = {
     "plnerf_sample_const_bwd": (c_i, [c_f] * 3 + [c_i] + [c_f] * 2 + [c_i] * 3 + [c_f] + [c_s]),
     "plnerf_sample_pl": (c_i, [c_f] * 7 + [c_i] * 4 + [ctypes.c_float] * 2 + [c_f] * 5 + [c_s]),
     "plnerf_sample_pl_bwd": (c_i, [c_f] * 6 + [c_i] + [c_f] * 2 + [c_i] * 3 + [ctypes.c_float] * 2 + [c_f] * 2 + [c_s]),
+    "plnerf_sample_pl_bwd_rays": (c_i, [c_f] * 6 + [c_i] + [c_f] * 2 + [c_i] * 3 + [ctypes.c_float] * 2 + [c_f] * 3 + [c_s]),
     "plnerf_stratified_z": (c_i, [c_f] * 4 + [c_i] * 3 + [c_f] + [c_s]),
     "plnerf_ray_points": (c_i, [c_f] * 3 + [c_i] * 2 + [c_f] + [c_s]),
     "plnerf_merge_sort": (c_i, [c_f] * 4 + [c_i] * 3 + [c_f] + [c_s]),

@@ -292,6 +292,7 @@ struct SamplePlBwdArgs {
     float zero_tol, eps;
     float* g_tau;
     float* g_T;
+    float* g_knots;   // (nullable; plnerf_sample_pl_bwd_rays) [R,S+2]: gradient of the knots [near, z, far] themselves
 };
 
 // Gradient of invert_segment (above) with respect to (T0, tau0, tau1), following torch's rules for
@@ -326,6 +327,30 @@ __device__ __forceinline__ bool invert_segment_grad(float s0, float s1, float T0
     return true;
 }
 
+// d sample / d (s0, s1) of sample = s0 + clamp(t_raw(L), eps, L), L = s1 - s0, as autograd derives it for the reference
+// (run_nerf_helpers.py:340-361; torch.clamp with a tensor bound: a value inside [eps, L] carries the gradient, beyond L --
+// or when eps > L, where clamp returns its upper bound -- the bound does).  t_raw = L num / den depends on L directly and
+// through the discriminant's 1 / span.
+__device__ __forceinline__ void invert_segment_knot_grad(float s0, float s1, float T0, float tau0, float tau1, float u,
+                                                         float eps, bool rising, float g, float& g_s0, float& g_s1) {
+    const float L = s1 - s0;
+    const float ln_term = -logf(tmax(eps, (1.0f - u) / tmax(eps, T0)));
+    const float span = tmax(eps, L);
+    const float diff = rising ? tau1 - tau0 : tau0 - tau1;
+    const float q = (2.0f * diff * ln_term) / span;
+    const float disc = rising ? tau0 * tau0 + q : tau0 * tau0 - q;
+    const float sq = sqrtf(tmax(eps, disc));
+    const float den = tmax(eps, diff);
+    const float num = rising ? -tau0 + sq : tau0 - sq;
+    const float t_raw = (L * num) / den;
+    if (eps > L || t_raw > L) { g_s0 = 0.0f; g_s1 = g; return; }      // sample = s0 + (s1 - s0)
+    if (t_raw < eps) { g_s0 = g; g_s1 = 0.0f; return; }               // sample = s0 + eps
+    float dt = num / den;
+    if (disc > eps && L > eps) dt -= (L / den) * ((0.5f / sq) * (q / span));
+    g_s1 = g * dt;
+    g_s0 = g - g_s1;
+}
+
 __global__ __launch_bounds__(256) void sample_pl_bwd_kernel(SamplePlBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -341,6 +366,8 @@ __global__ __launch_bounds__(256) void sample_pl_bwd_kernel(SamplePlBwdArgs a) {
     float* gb = ga + N;           //             on tau[above]
     int* lo = reinterpret_cast<int*>(gb + N);   // below (above = min(below + 1, K - 1) unless clamped at 0)
     int* hi = lo + N;
+    float* gs0 = reinterpret_cast<float*>(hi + N);      // (only with g_knots) on knot[below]
+    float* gs1 = gs0 + N;                               //                     on knot[above]
     for (int j = lane; j < K; j += 64) {
         tau[j] = a.tau[(size_t)ray * K + j];
         Tr[j] = a.T[(size_t)ray * K + j];
@@ -364,13 +391,18 @@ __global__ __launch_bounds__(256) void sample_pl_bwd_kernel(SamplePlBwdArgs a) {
         const float d = tau[di + 1] - tau[di];
         float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
         const float g = a.g_samples[o];
+        float k0 = g, k1 = 0.0f;      // (a flat interval and a NaN sample are the left knot itself, run_nerf_helpers.py:425, 432)
         if (d >= zt || d <= -zt) {
             const bool rising = d >= zt;
             // (a NaN sample falls back to s_left in the forward: no gradient)
             const float t = invert_segment(s0, s1, Tr[below], tau[below], tau[above], u, eps, rising);
-            if (t == t) invert_segment_grad(s0, s1, Tr[below], tau[below], tau[above], u, eps, rising, g, g0, g1, g2);
+            if (t == t) {
+                invert_segment_grad(s0, s1, Tr[below], tau[below], tau[above], u, eps, rising, g, g0, g1, g2);
+                if (a.g_knots) invert_segment_knot_grad(s0, s1, Tr[below], tau[below], tau[above], u, eps, rising, g, k0, k1);
+            }
         }
         gT0[k] = g0; ga[k] = g1; gb[k] = g2;
+        if (a.g_knots) { gs0[k] = k0; gs1[k] = k1; }
         lo[k] = below; hi[k] = above;
     }
     __syncthreads();
@@ -385,6 +417,14 @@ __global__ __launch_bounds__(256) void sample_pl_bwd_kernel(SamplePlBwdArgs a) {
         }
         a.g_tau[(size_t)ray * K + j] = st;
         a.g_T[(size_t)ray * K + j] = sT;
+        if (a.g_knots) {
+            float sk = 0.0f;
+            for (int k = 0; k < N; ++k) {
+                if (lo[k] == j) sk += gs0[k];
+                if (hi[k] == j) sk += gs1[k];
+            }
+            a.g_knots[(size_t)ray * K + j] = sk;
+        }
     }
 }
 
@@ -497,17 +537,18 @@ extern "C" int plnerf_sample_pl(const float* z, const float* weights, const floa
 }
 
 
-extern "C" int plnerf_sample_pl_bwd(const float* z, const float* tau, const float* T, const float* near,
-                                    const float* far, const float* u, int u_row_stride, const int64_t* inds,
-                                    const float* g_samples, int R, int S, int N, float zero_tol, float epsilon,
-                                    float* g_tau, float* g_T, plnerf_stream_t stream) {
+namespace {
+int sample_pl_bwd_launch(const float* z, const float* tau, const float* T, const float* near,
+                         const float* far, const float* u, int u_row_stride, const int64_t* inds,
+                         const float* g_samples, int R, int S, int N, float zero_tol, float epsilon,
+                         float* g_tau, float* g_T, float* g_knots, plnerf_stream_t stream) {
     if (R < 0 || S < 1 || N < 1 || (u_row_stride != 0 && u_row_stride != N)) return PLNERF_EINVAL;
     if (S > PLNERF_MAX_SAMPLES) return PLNERF_ERANGE;
     if (R == 0) return PLNERF_OK;
     if (!z || !tau || !T || !near || !far || !u || !inds || !g_samples || !g_tau || !g_T) return PLNERF_EINVAL;
     SamplePlBwdArgs a{z, tau, T, near, far, u, u_row_stride, inds, g_samples, R, S, N, 0, zero_tol, epsilon,
-                      g_tau, g_T};
-    a.lds_stride = ((3 * (S + 2) + 5 * N) + 3) & ~3;
+                      g_tau, g_T, g_knots};
+    a.lds_stride = ((3 * (S + 2) + (g_knots ? 7 : 5) * N) + 3) & ~3;
     const size_t lds = (size_t)WAVES * a.lds_stride * sizeof(float);
     int rc = set_lds((const void*)sample_pl_bwd_kernel, lds);
     if (rc) return rc;
@@ -515,6 +556,24 @@ extern "C" int plnerf_sample_pl_bwd(const float* z, const float* tau, const floa
                        (hipStream_t)stream, a);
     PLNERF_CHECK_LAUNCH();
     return PLNERF_OK;
+}
+}  // namespace
+
+extern "C" int plnerf_sample_pl_bwd(const float* z, const float* tau, const float* T, const float* near,
+                                    const float* far, const float* u, int u_row_stride, const int64_t* inds,
+                                    const float* g_samples, int R, int S, int N, float zero_tol, float epsilon,
+                                    float* g_tau, float* g_T, plnerf_stream_t stream) {
+    return sample_pl_bwd_launch(z, tau, T, near, far, u, u_row_stride, inds, g_samples, R, S, N, zero_tol, epsilon, g_tau, g_T,
+                                nullptr, stream);
+}
+
+extern "C" int plnerf_sample_pl_bwd_rays(const float* z, const float* tau, const float* T, const float* near,
+                                         const float* far, const float* u, int u_row_stride, const int64_t* inds,
+                                         const float* g_samples, int R, int S, int N, float zero_tol, float epsilon,
+                                         float* g_tau, float* g_T, float* g_knots, plnerf_stream_t stream) {
+    if (R > 0 && !g_knots) return PLNERF_EINVAL;
+    return sample_pl_bwd_launch(z, tau, T, near, far, u, u_row_stride, inds, g_samples, R, S, N, zero_tol, epsilon, g_tau, g_T,
+                                g_knots, stream);
 }
 
 extern "C" int plnerf_merge_sort(const float* z, const float* z_new, const float* near, const float* far,

@@ -234,13 +234,6 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
     depth_map, z_vals, weights, pred_hyp, u (+ raw; + rgb0, disp0, acc0, depth0, z_vals0, weights0, z_std)."""
     dev = ray_batch.device
     N_rays = ray_batch.shape[0]
-    if torch.is_grad_enabled() and getattr(ray_batch, "requires_grad", False):
-        # The NVS render_rays carries a ray batch's gradient (render.py: plnerf_quad_bwd_rays + plnerf_mlp_input_grad).
-        # Here the depth hypotheses are samples that STAY attached (:923-934), and the sampler's backward
-        # (plnerf_sample_pl_bwd) covers weights / tau / T, not its bins: returning the rest would be silently wrong.
-        raise NotImplementedError(
-            "plnerf_amd: the depth-supervised render_rays has no gradient with respect to the ray batch (its depth "
-            "hypotheses depend on the ray geometry through the sampler's bins); detach the rays")
     if isinstance(ray_batch, RB.RayColumns):      # (what plnerf_select_rays writes: no packing, no slice copies)
         rays_o, rays_d, near, far = ray_batch.rays_o, ray_batch.rays_d, ray_batch.near.reshape(-1, 1), \
             ray_batch.far.reshape(-1, 1)
@@ -249,8 +242,19 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
         rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
         viewdirs = ray_batch[:, 8:11].contiguous() if use_viewdirs else None
         near, far = ray_batch[:, 6:7].contiguous(), ray_batch[:, 7:8].contiguous()
+    # A ray batch that requires a gradient (no training path of the reference has one): as in render.py, the glue then runs
+    # as the reference's own torch expressions, the quadrature and the sampler return the geometry's gradient
+    # (plnerf_quad_bwd_rays; plnerf_sample_pl_bwd_rays -- here the depth hypotheses STAY attached to the sampler's bins,
+    # :923-934), the networks their inputs' (plnerf_mlp_input_grad).  Piecewise-constant mode refuses: its sampler's
+    # backward (plnerf_sample_const_bwd) covers the weights only, and a partial gradient would be silently wrong.
+    rays_grad = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (rays_o, rays_d, near, far, viewdirs))
+    if rays_grad and mode != "linear":
+        raise NotImplementedError(
+            "plnerf_amd: the depth-supervised render_rays has no gradient with respect to the ray batch in piecewise-"
+            "constant mode (its depth hypotheses depend on the ray geometry through sample_pdf's bins); detach the rays")
     t_vals = Fn.cpu_linspace(N_samples, dev)
-    fused_glue = ray_batch.is_cuda and N_rays > 0
+    fused_glue = ray_batch.is_cuda and N_rays > 0 and not rays_grad
     draws = None if pytest else Fn.DRAWS      # counter-based draws inside the consuming kernels (functional.DrawSource)
     if draws is not None:
         draws.noise_calls = 0
@@ -333,14 +337,20 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
             z_samples, inds0 = Fn.sample_pl(z_vals, weights, tau, T, near, far, u0, zero_tol, epsilon, want_inds=True)
             tap.update(weights0_full=weights, tau0=tau, T0=T, u0=u0, inds0=inds0, z_samples=z_samples)
         elif mode == "linear":
-            z_samples = sample_pdf_reformulation(z_vals, weights, tau, T, near, far, N_importance, det=(perturb == 0.),
-                                                 pytest=pytest, quad_solution_v2=quad_solution_v2,
-                                                 zero_threshold=zero_tol, epsilon_=epsilon)[0]
+            with torch.set_grad_enabled(torch.is_grad_enabled() and not rays_grad):      # (detached below either way)
+                z_samples = sample_pdf_reformulation(z_vals, weights, tau, T, near, far, N_importance, det=(perturb == 0.),
+                                                     pytest=pytest, quad_solution_v2=quad_solution_v2,
+                                                     zero_threshold=zero_tol, epsilon_=epsilon)[0]
         else:
             z_mid = .5 * (z_vals[..., 1:] + z_vals[..., :-1])
             z_samples = sample_pdf(z_mid, weights[..., 1:-1], N_importance, det=(perturb == 0.), pytest=pytest)
         z_samples = z_samples.detach()
-        z_vals = Fn.merge_sort(z_vals, z_samples, near, far)          # clamp + cat + sort (:902-906)
+        if rays_grad:      # :902-906 as written: the clamp's bounds and the coarse depths carry the batch's gradient
+            z_vals, order = torch.sort(torch.cat([z_vals, torch.clamp(z_samples, near, far)], -1), -1)
+            if tap is not None:
+                tap.update(sort_order=order)      # (ties: render.py)
+        else:
+            z_vals = Fn.merge_sort(z_vals, z_samples, near, far)          # clamp + cat + sort (:902-906)
         if fused_glue:
             pts = Fn.ray_points(rays_o, rays_d, z_vals)
         else:

@@ -683,7 +683,8 @@ def sample_const(bins, weights, u, want_inds=False):
 class SamplePlFn(torch.autograd.Function):
     """sample_pdf_reformulation (run_nerf_helpers.py:364-445) -> plnerf_sample_pl / plnerf_sample_pl_bwd.
     Differentiable with respect to tau and T (what autograd derives for the reference: the interval
-    search is piecewise constant in the weights; z, near, far are detached upstream).  Outputs:
+    search is piecewise constant in the weights) and, when they ask, to the bins z / near / far themselves
+    (plnerf_sample_pl_bwd_rays: a ray batch that requires a gradient).  Outputs:
     samples, T_below, tau_below, bin_below, inds -- only `samples` carries a gradient."""
 
     @staticmethod
@@ -712,6 +713,7 @@ class SamplePlFn(torch.autograd.Function):
                 L.dptr(inds, "inds", torch.int64), L.stream()), "plnerf_sample_pl")
         ctx.save_for_backward(z_c, tau_c, T_c, near_c, far_c, u_c, inds)
         ctx.cfg = (stride, float(zero_tol), float(eps))
+        ctx.near_shape, ctx.far_shape = near.shape, far.shape
         ctx.mark_non_differentiable(Tb, taub, binb, inds)
         ctx.set_materialize_grads(False)
         return out, Tb, taub, binb, inds
@@ -727,6 +729,18 @@ class SamplePlFn(torch.autograd.Function):
         g_c = _f32c(g_samples)
         g_tau = torch.empty(R, S + 2, device=z_c.device)
         g_T = torch.empty(R, S + 2, device=z_c.device)
+        need = ctx.needs_input_grad
+        if need[0] or need[4] or need[5]:
+            # the bins carry a gradient (a ray batch that requires one): plnerf_sample_pl_bwd_rays also returns the knots' own
+            g_k = torch.empty(R, S + 2, device=z_c.device)
+            if R > 0:
+                L.check(L.lib().plnerf_sample_pl_bwd_rays(
+                    L.dptr(z_c), L.dptr(tau_c), L.dptr(T_c), L.dptr(near_c), L.dptr(far_c), L.dptr(u_c), stride,
+                    L.dptr(inds, "inds", torch.int64), L.dptr(g_c), R, S, N, zero_tol, eps, L.dptr(g_tau), L.dptr(g_T),
+                    L.dptr(g_k), L.stream()), "plnerf_sample_pl_bwd_rays")
+            return (g_k[:, 1:-1] if need[0] else None, None, g_tau, g_T,
+                    g_k[:, 0].reshape(ctx.near_shape) if need[4] else None,
+                    g_k[:, -1].reshape(ctx.far_shape) if need[5] else None, None, None, None)
         if R > 0:
             L.check(L.lib().plnerf_sample_pl_bwd(
                 L.dptr(z_c), L.dptr(tau_c), L.dptr(T_c), L.dptr(near_c), L.dptr(far_c), L.dptr(u_c), stride,

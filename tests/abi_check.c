@@ -19,6 +19,7 @@ int main(void) {
     int (*p_sample_const_bwd)(const float*, const float*, const float*, int, const int64_t*, const float*, int, int, int, float*, plnerf_stream_t) = plnerf_sample_const_bwd;
     int (*p_sample_pl)(const float*, const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, float, float, float*, float*, float*, float*, int64_t*, plnerf_stream_t) = plnerf_sample_pl;
     int (*p_sample_pl_bwd)(const float*, const float*, const float*, const float*, const float*, const float*, int, const int64_t*, const float*, int, int, int, float, float, float*, float*, plnerf_stream_t) = plnerf_sample_pl_bwd;
+    int (*p_sample_pl_bwd_rays)(const float*, const float*, const float*, const float*, const float*, const float*, int, const int64_t*, const float*, int, int, int, float, float, float*, float*, float*, plnerf_stream_t) = plnerf_sample_pl_bwd_rays;
     int (*p_stratified_z)(const float*, const float*, const float*, const float*, int, int, int, float*, plnerf_stream_t) = plnerf_stratified_z;
     int (*p_ray_points)(const float*, const float*, const float*, int, int, float*, plnerf_stream_t) = plnerf_ray_points;
     int (*p_merge_sort)(const float*, const float*, const float*, const float*, int, int, int, float*, plnerf_stream_t) = plnerf_merge_sort;
@@ -46,7 +47,7 @@ int main(void) {
     const void* entry[] = {
         (const void*)&p_version, (const void*)&p_build_flags, (const void*)&p_error_string, (const void*)&p_quad_fwd,
         (const void*)&p_quad_bwd, (const void*)&p_quad_bwd_rays, (const void*)&p_sample_const, (const void*)&p_sample_const_bwd, (const void*)&p_sample_pl,
-        (const void*)&p_sample_pl_bwd, (const void*)&p_stratified_z, (const void*)&p_ray_points, (const void*)&p_merge_sort,
+        (const void*)&p_sample_pl_bwd, (const void*)&p_sample_pl_bwd_rays, (const void*)&p_stratified_z, (const void*)&p_ray_points, (const void*)&p_merge_sort,
         (const void*)&p_coarse_epilogue, (const void*)&p_fine_epilogue, (const void*)&p_uniform, (const void*)&p_normal,
         (const void*)&p_select_rays, (const void*)&p_ndc_rays, (const void*)&p_coarse_samples, (const void*)&p_image_loss, (const void*)&p_depth_loss,
         (const void*)&p_embed_rows, (const void*)&p_mlp_packed_bytes, (const void*)&p_mlp_status_offset, (const void*)&p_mlp_pack_weights,

@@ -9,8 +9,9 @@ are data -- but a drop-in must either give the same gradient or refuse, never a 
     on every output, both quadrature rules, ragged sample counts;
   * render_rays end to end, 64 + 128 samples, both networks: d / d ray_batch [R, 11] against the oracle's fp64 autograd on
     identical draws, in the exact fp32 mode and in the benchmarked f16x3;
-  * the depth-supervised variant (whose depth hypotheses depend on the geometry through a sampler that is NOT detached)
-    refuses loudly instead of returning the part it has.
+  * plnerf_sample_pl_bwd_rays (SamplePlFn): d samples / d (z_vals, near, far), and with it the depth-supervised variant,
+    whose depth hypotheses depend on the geometry through a sampler that is NOT detached -- in piecewise-linear mode;
+    piecewise-constant mode refuses loudly instead of returning the part it has.
 
 Tolerances are stated at each assertion, as fractions of the largest |g| of the column group.
 """
@@ -67,6 +68,47 @@ def test_quadrature_geometry_gradients_vs_oracle(P, mode, cmode, S):
         r2 = QuadratureFn.apply(raw_only, g(z), g(near), g(far), g(d), g(noise), mode, cmode, wb, False)
         sum((a * g(b)).sum() for a, b in zip(r2[:5], cot)).backward()
         assert torch.equal(raw_only.grad, leaves_h[0].grad)
+
+
+def test_sampler_bin_gradients_vs_oracle(P):
+    """d samples / d (z_vals, near, far) of sample_pdf_reformulation (plnerf_sample_pl_bwd_rays) against autograd on the
+    oracle: the closed-form inverse's dependence on the interval's ends (run_nerf_helpers.py:340-361), the flat-interval and
+    NaN fall-backs to the left knot (:425, :432), the clamp's upper bound.  Yardstick and bound as in
+    test_sampler_backward_vs_oracle_autograd: the fp64 oracle, twice the fp32 oracle's own distance from it + 1e-5 (the closed
+    form cancels in fp32).  The gradients of tau and T are the bits plnerf_sample_pl_bwd gives without the request."""
+    from plnerf_amd import functional as Fn
+
+    def rel(a, b):
+        return float((a.detach().cpu().double() - b).abs().max()) / (float(b.abs().max()) + 1e-300)
+
+    for (R, S, N, seed) in [(64, 64, 64, 3), (33, 192, 128, 4), (16, 21, 77, 5)]:
+        raw, z, near, far, d, _ = quad_case(R, S, seed)
+        near = near - 0.25 * torch.rand(R, 1, generator=torch.Generator().manual_seed(seed))
+        far = far + 0.25 * torch.rand(R, 1, generator=torch.Generator().manual_seed(seed + 1))
+        gen = torch.Generator().manual_seed(seed)
+        u = torch.rand(R, N, generator=gen) * 0.999
+        cot = torch.randn(R, N, generator=gen)
+        with torch.no_grad():
+            _, _, _, w, _, tau, Tr = orc.raw2outputs(raw, z, near, far, d, "linear", "midpoint")
+            tau[: R // 4, S // 3: S // 2] = tau[: R // 4, S // 3: S // 3 + 1]      # (flat stretches: the left-knot branch)
+
+        def bin_grads(dt):
+            leaves = [t.to(dt).clone().requires_grad_(True) for t in (z, near, far)]
+            s_ref = orc.sample_pdf_reformulation(leaves[0], w.to(dt), tau.to(dt), Tr.to(dt), leaves[1], leaves[2], N, u=u.to(dt))[0]
+            (s_ref * cot.to(dt)).sum().backward()
+            return [l.grad for l in leaves]
+        ref64, ref32 = bin_grads(torch.float64), bin_grads(torch.float32)
+        leaves_h = [g(t).clone().requires_grad_(True) for t in (z, near, far)]
+        tau_h, T_h = g(tau).requires_grad_(True), g(Tr).requires_grad_(True)
+        s_hip = Fn.sample_pl(leaves_h[0], g(w), tau_h, T_h, leaves_h[1], leaves_h[2], g(u), 1e-4, 1e-3)
+        (s_hip * g(cot)).sum().backward()
+        for name, lh, b64, b32 in zip(("z_vals", "near", "far"), leaves_h, ref64, ref32):
+            e_hip, e_orc = rel(lh.grad, b64), rel(b32, b64)
+            print(f"sampler bins R={R} S={S} N={N}: d/d {name} err vs fp64 oracle: HIP {e_hip:.3e}, fp32 oracle {e_orc:.3e}")
+            assert lh.grad.shape == b64.shape and e_hip <= 2 * e_orc + 1e-5, (name, e_hip, e_orc)
+        tau_2, T_2 = g(tau).requires_grad_(True), g(Tr).requires_grad_(True)
+        (Fn.sample_pl(g(z), g(w), tau_2, T_2, g(near), g(far), g(u), 1e-4, 1e-3) * g(cot)).sum().backward()
+        assert torch.equal(tau_2.grad, tau_h.grad) and torch.equal(T_2.grad, T_h.grad)
 
 
 def _query_fn(P):
@@ -321,12 +363,86 @@ def test_camera_pose_gradient_through_render(P):
     assert c_h.grad.shape == (3, 4) and err <= 2e-5
 
 
-def test_depth_variant_refuses_a_ray_batch_gradient(P):
-    """Its depth hypotheses are samples that stay attached (run_nerf_sample_based_depth.py:923-934) and the sampler's
-    backward covers weights / tau / T only, not the bins: a partial gradient would be silently wrong."""
+@pytest.mark.parametrize("Ni", [0, 40])
+def test_depth_variant_ray_batch_gradient_vs_oracle(P, Ni):
+    """The depth-supervised render_rays (run_nerf_sample_based_depth.py:792-958) on a ray batch that requires a gradient:
+    its depth hypotheses stay attached to the sampler, so d pred_hyp / d (bins) joins the chain (plnerf_sample_pl_bwd_rays).
+    A random functional of rgb_map, depth_map, pred_hyp (and rgb0) against the oracle on shared draws.
+
+    The loss runs through the sampler's ill-conditioned closed form and through ReLUs near zero, where the reference's own
+    fp32 autograd sits ~1e-2 of max |g| from fp64 (test_depth_variant_gradients_vs_oracle): yardstick = the fp64 oracle,
+    bound = twice the fp32 oracle's own distance from it + 1e-3, per column group.  With a fine pass (Ni > 0) near / far are
+    left out: their gradient depends on how the sort of :906 orders a sample that ties with a coarse depth (_both_gradients
+    explains; the single-pass case has no merge and checks them)."""
+    import sys
+    from plnerf_amd import depth as Dp
+    from test_gpu_parity import _depth_setup
+    R, Ns = 24, 32
+    Dp, kw, _, _ = _depth_setup(P, {"N_importance": 40, "N_samples": Ns, "space_carving_weight": 0.05})      # (both networks exist)
+    batch, _ = orc.synthetic_blender_rays(R, seed=13)
+    gen = torch.Generator().manual_seed(13)
+    n_hyp = Ni if Ni > 0 else Ns
+    t_rand, u_fine, u_hyp = torch.rand(R, Ns, generator=gen), torch.rand(R, max(Ni, 1), generator=gen) * 0.999, \
+        torch.rand(R, n_hyp, generator=gen) * 0.999
+    cot = {"rgb_map": torch.randn(R, 3, generator=gen), "depth_map": torch.randn(R, generator=gen),
+           "pred_hyp": torch.randn(R, n_hyp, generator=gen) * 0.2, "rgb0": torch.randn(R, 3, generator=gen)}
+    keys = [k for k in cot if Ni > 0 or k != "rgb0"]
+
+    cur = {}
+
+    def oracle(dt):
+        cur["dt"] = dt
+        sd_c = {k: v.to(dt) for k, v in orc.closed_form_state_dict_depth(0, True).items()}
+        sd_f = {k: v.to(dt) for k, v in orc.closed_form_state_dict_depth(1, True).items()}
+        b = batch.to(dt).clone().requires_grad_(True)
+        ret = orc.render_rays_depth(b, sd_c, sd_f, Ns, "linear", "midpoint", perturb=1.0, N_importance=Ni, white_bkgd=True,
+                                    t_rand=t_rand.to(dt), u_fine=u_fine.to(dt), cached_u=u_hyp.to(dt) if Ni > 0 else None)
+        sum((ret[k] * cot[k].to(dt)).sum() for k in keys).backward()
+        return b.grad.double(), ret
+    if Ni == 0:      # (the single pass draws its hypotheses' u itself: replay the oracle's)
+        orig_u = orc._draw_u_depth
+        orc._draw_u_depth = lambda R_, n, det, pyt, load_u: u_hyp.to(cur["dt"]) if load_u is None else load_u
+    try:
+        g64, ret64 = oracle(torch.float64)
+        g32, _ = oracle(torch.float32)
+    finally:
+        if Ni == 0:
+            orc._draw_u_depth = orig_u
+    dmod = sys.modules[Dp.__name__]
+    rmod = sys.modules[Dp.__name__.rsplit(".", 1)[0] + ".render"]
+    orig = dmod._draw_t_rand, rmod._draw_u, dmod._draw_u
+    b_h = g(batch).clone().requires_grad_(True)
+    try:
+        dmod._draw_t_rand = lambda *a, **k: g(t_rand)
+        rmod._draw_u = lambda *a, **k: g(u_fine)
+        if Ni == 0:
+            dmod._draw_u = lambda *a, **k: g(u_hyp)
+        ret = Dp.render_rays(b_h, cached_u=g(u_hyp) if Ni > 0 else None, **dict(kw, N_importance=Ni))
+    finally:
+        dmod._draw_t_rand, rmod._draw_u, dmod._draw_u = orig
+    assert float((ret["pred_hyp"].detach().cpu().double() - ret64["pred_hyp"].detach()).abs().max()) <= 5e-3
+    sum((ret[k] * g(cot[k])).sum() for k in keys).backward()
+    assert b_h.grad is not None and bool(torch.isfinite(b_h.grad).all())
+    got = b_h.grad.cpu().double()
+    for name, cols in GROUPS:
+        if Ni > 0 and name in ("near", "far"):
+            continue
+        scale = float(g64[:, cols].abs().max())
+        e_hip = float((got[:, cols] - g64[:, cols]).abs().max()) / scale
+        e_orc = float((g32[:, cols] - g64[:, cols]).abs().max()) / scale
+        e_32 = float((got[:, cols] - g32[:, cols]).abs().max()) / scale      # (against the reference's own arithmetic)
+        print(f"depth variant Ni={Ni} d/d {name}: max |g| {scale:.3g}; vs fp64 oracle: HIP {e_hip:.2e}, fp32 oracle {e_orc:.2e}; "
+              f"HIP vs fp32 oracle {e_32:.2e}")
+        assert scale > 0.0 and e_hip <= 2 * e_orc + 1e-3, (name, e_hip, e_orc)
+        assert e_32 <= 0.5 * e_orc + 1e-3, (name, e_32, e_orc)
+
+
+def test_depth_variant_refuses_a_ray_batch_gradient_in_constant_mode(P):
+    """Piecewise-constant mode: the hypotheses come from sample_pdf, whose backward (plnerf_sample_const_bwd) covers the
+    weights only -- a partial gradient would be silently wrong, so the call refuses."""
     from plnerf_amd import depth as D
     R = 8
     batch, _ = orc.synthetic_blender_rays(R, seed=1)
     b = g(batch).clone().requires_grad_(True)
     with pytest.raises(NotImplementedError):
-        D.render_rays(b, True, None, None, 16, "linear", "midpoint")
+        D.render_rays(b, True, None, None, 16, "constant", "midpoint")
