@@ -243,16 +243,11 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
         viewdirs = ray_batch[:, 8:11].contiguous() if use_viewdirs else None
         near, far = ray_batch[:, 6:7].contiguous(), ray_batch[:, 7:8].contiguous()
     # A ray batch that requires a gradient (no training path of the reference has one): as in render.py, the glue then runs
-    # as the reference's own torch expressions, the quadrature and the sampler return the geometry's gradient
-    # (plnerf_quad_bwd_rays; plnerf_sample_pl_bwd_rays -- here the depth hypotheses STAY attached to the sampler's bins,
-    # :923-934), the networks their inputs' (plnerf_mlp_input_grad).  Piecewise-constant mode refuses: its sampler's
-    # backward (plnerf_sample_const_bwd) covers the weights only, and a partial gradient would be silently wrong.
+    # as the reference's own torch expressions, the quadrature and the samplers return the geometry's gradient
+    # (plnerf_quad_bwd_rays; plnerf_sample_pl_bwd_rays / SampleConstFn's bins -- here the depth hypotheses STAY attached to the
+    # sampler's bins, :923-934), the networks their inputs' (plnerf_mlp_input_grad).
     rays_grad = torch.is_grad_enabled() and any(
         t is not None and t.requires_grad for t in (rays_o, rays_d, near, far, viewdirs))
-    if rays_grad and mode != "linear":
-        raise NotImplementedError(
-            "plnerf_amd: the depth-supervised render_rays has no gradient with respect to the ray batch in piecewise-"
-            "constant mode (its depth hypotheses depend on the ray geometry through sample_pdf's bins); detach the rays")
     t_vals = Fn.cpu_linspace(N_samples, dev)
     fused_glue = ray_batch.is_cuda and N_rays > 0 and not rays_grad
     draws = None if pytest else Fn.DRAWS      # counter-based draws inside the consuming kernels (functional.DrawSource)

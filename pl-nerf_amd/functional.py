@@ -670,12 +670,27 @@ class SampleConstFn(torch.autograd.Function):
             L.check(L.lib().plnerf_sample_const_bwd(
                 L.dptr(bins_c), L.dptr(w_c), L.dptr(u_c), ctx.stride, L.dptr(inds, "inds", torch.int64), L.dptr(g_c),
                 R, B, N, L.dptr(g_w), L.stream()), "plnerf_sample_const_bwd")
-        return None, g_w, None
+        g_bins = None
+        if ctx.needs_input_grad[0]:
+            # the bins carry a gradient (a ray batch that requires one): samples = b0 + t (b1 - b0) with t a function of the
+            # weights and the draw only (run_nerf_helpers.py:266-282) -> (1 - t) to the lower bin, t to the upper one.  Off
+            # every training path; a few torch launches (the two scatter-adds sum a bin's samples in no fixed order).
+            # (t = (u - cdf) / (cdf step) cancels: evaluated in fp64 from the fp32 weights, then rounded once)
+            w = w_c.double() + 1e-5
+            cdf = torch.cumsum(w / torch.sum(w, -1, keepdim=True), -1)
+            cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+            below, above = torch.clamp(inds - 1, min=0), torch.clamp(inds, max=B - 1)
+            c0 = torch.gather(cdf, -1, below)
+            denom = torch.gather(cdf, -1, above) - c0
+            denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+            t = (((u_c if u_c.dim() == 2 else u_c.expand(R, N)).double() - c0) / denom).float()
+            g_bins = torch.zeros(R, B, device=bins_c.device).scatter_add_(-1, below, g_c * (1.0 - t)).scatter_add_(-1, above, g_c * t)
+        return g_bins, g_w, None
 
 
 def sample_const(bins, weights, u, want_inds=False):
     """plnerf_sample_const: bins [R,B], weights [R,B-1], u [R,N] or shared [N].  `samples` is differentiable with
-    respect to `weights` (SampleConstFn)."""
+    respect to `weights` and, when they ask, to `bins` (SampleConstFn)."""
     out, inds = SampleConstFn.apply(bins, weights, u)
     return (out, inds) if want_inds else out
 

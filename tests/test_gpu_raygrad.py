@@ -10,8 +10,8 @@ are data -- but a drop-in must either give the same gradient or refuse, never a 
   * render_rays end to end, 64 + 128 samples, both networks: d / d ray_batch [R, 11] against the oracle's fp64 autograd on
     identical draws, in the exact fp32 mode and in the benchmarked f16x3;
   * plnerf_sample_pl_bwd_rays (SamplePlFn): d samples / d (z_vals, near, far), and with it the depth-supervised variant,
-    whose depth hypotheses depend on the geometry through a sampler that is NOT detached -- in piecewise-linear mode;
-    piecewise-constant mode refuses loudly instead of returning the part it has.
+    whose depth hypotheses depend on the geometry through a sampler that is NOT detached (both quadrature rules: the
+    piecewise-constant sampler's bins get theirs from SampleConstFn).
 
 Tolerances are stated at each assertion, as fractions of the largest |g| of the column group.
 """
@@ -363,8 +363,8 @@ def test_camera_pose_gradient_through_render(P):
     assert c_h.grad.shape == (3, 4) and err <= 2e-5
 
 
-@pytest.mark.parametrize("Ni", [0, 40])
-def test_depth_variant_ray_batch_gradient_vs_oracle(P, Ni):
+@pytest.mark.parametrize("mode,Ni", [("linear", 0), ("linear", 40), ("constant", 40)])
+def test_depth_variant_ray_batch_gradient_vs_oracle(P, mode, Ni):
     """The depth-supervised render_rays (run_nerf_sample_based_depth.py:792-958) on a ray batch that requires a gradient:
     its depth hypotheses stay attached to the sampler, so d pred_hyp / d (bins) joins the chain (plnerf_sample_pl_bwd_rays).
     A random functional of rgb_map, depth_map, pred_hyp (and rgb0) against the oracle on shared draws.
@@ -379,6 +379,12 @@ def test_depth_variant_ray_batch_gradient_vs_oracle(P, Ni):
     from test_gpu_parity import _depth_setup
     R, Ns = 24, 32
     Dp, kw, _, _ = _depth_setup(P, {"N_importance": 40, "N_samples": Ns, "space_carving_weight": 0.05})      # (both networks exist)
+    # (piecewise-constant mode on default-initialised networks, as test_depth_variant_constant_mode_vs_oracle: with the
+    # "sharpened" ones most bins are empty and sample_pdf divides by cdf steps of ~1e-5 -- fp32 noise, the reference's too)
+    sharp = mode == "linear"
+    if not sharp:
+        kw["network_fn"].load_state_dict(orc.closed_form_state_dict_depth(0, False))
+        kw["network_fine"].load_state_dict(orc.closed_form_state_dict_depth(1, False))
     batch, _ = orc.synthetic_blender_rays(R, seed=13)
     gen = torch.Generator().manual_seed(13)
     n_hyp = Ni if Ni > 0 else Ns
@@ -392,10 +398,10 @@ def test_depth_variant_ray_batch_gradient_vs_oracle(P, Ni):
 
     def oracle(dt):
         cur["dt"] = dt
-        sd_c = {k: v.to(dt) for k, v in orc.closed_form_state_dict_depth(0, True).items()}
-        sd_f = {k: v.to(dt) for k, v in orc.closed_form_state_dict_depth(1, True).items()}
+        sd_c = {k: v.to(dt) for k, v in orc.closed_form_state_dict_depth(0, sharp).items()}
+        sd_f = {k: v.to(dt) for k, v in orc.closed_form_state_dict_depth(1, sharp).items()}
         b = batch.to(dt).clone().requires_grad_(True)
-        ret = orc.render_rays_depth(b, sd_c, sd_f, Ns, "linear", "midpoint", perturb=1.0, N_importance=Ni, white_bkgd=True,
+        ret = orc.render_rays_depth(b, sd_c, sd_f, Ns, mode, "midpoint", perturb=1.0, N_importance=Ni, white_bkgd=True,
                                     t_rand=t_rand.to(dt), u_fine=u_fine.to(dt), cached_u=u_hyp.to(dt) if Ni > 0 else None)
         sum((ret[k] * cot[k].to(dt)).sum() for k in keys).backward()
         return b.grad.double(), ret
@@ -403,8 +409,8 @@ def test_depth_variant_ray_batch_gradient_vs_oracle(P, Ni):
         orig_u = orc._draw_u_depth
         orc._draw_u_depth = lambda R_, n, det, pyt, load_u: u_hyp.to(cur["dt"]) if load_u is None else load_u
     try:
-        g64, ret64 = oracle(torch.float64)
-        g32, _ = oracle(torch.float32)
+        g64, _ = oracle(torch.float64)
+        g32, ret32 = oracle(torch.float32)
     finally:
         if Ni == 0:
             orc._draw_u_depth = orig_u
@@ -417,10 +423,10 @@ def test_depth_variant_ray_batch_gradient_vs_oracle(P, Ni):
         rmod._draw_u = lambda *a, **k: g(u_fine)
         if Ni == 0:
             dmod._draw_u = lambda *a, **k: g(u_hyp)
-        ret = Dp.render_rays(b_h, cached_u=g(u_hyp) if Ni > 0 else None, **dict(kw, N_importance=Ni))
+        ret = Dp.render_rays(b_h, cached_u=g(u_hyp) if Ni > 0 else None, **dict(kw, N_importance=Ni, mode=mode))
     finally:
         dmod._draw_t_rand, rmod._draw_u, dmod._draw_u = orig
-    assert float((ret["pred_hyp"].detach().cpu().double() - ret64["pred_hyp"].detach()).abs().max()) <= 5e-3
+    assert float((ret["pred_hyp"].detach().cpu() - ret32["pred_hyp"].detach()).abs().max()) <= 5e-3      # (same hypotheses)
     sum((ret[k] * g(cot[k])).sum() for k in keys).backward()
     assert b_h.grad is not None and bool(torch.isfinite(b_h.grad).all())
     got = b_h.grad.cpu().double()
@@ -431,18 +437,35 @@ def test_depth_variant_ray_batch_gradient_vs_oracle(P, Ni):
         e_hip = float((got[:, cols] - g64[:, cols]).abs().max()) / scale
         e_orc = float((g32[:, cols] - g64[:, cols]).abs().max()) / scale
         e_32 = float((got[:, cols] - g32[:, cols]).abs().max()) / scale      # (against the reference's own arithmetic)
-        print(f"depth variant Ni={Ni} d/d {name}: max |g| {scale:.3g}; vs fp64 oracle: HIP {e_hip:.2e}, fp32 oracle {e_orc:.2e}; "
+        print(f"depth variant {mode} Ni={Ni} d/d {name}: max |g| {scale:.3g}; vs fp64 oracle: HIP {e_hip:.2e}, fp32 oracle {e_orc:.2e}; "
               f"HIP vs fp32 oracle {e_32:.2e}")
         assert scale > 0.0 and e_hip <= 2 * e_orc + 1e-3, (name, e_hip, e_orc)
         assert e_32 <= 0.5 * e_orc + 1e-3, (name, e_32, e_orc)
 
 
-def test_depth_variant_refuses_a_ray_batch_gradient_in_constant_mode(P):
-    """Piecewise-constant mode: the hypotheses come from sample_pdf, whose backward (plnerf_sample_const_bwd) covers the
-    weights only -- a partial gradient would be silently wrong, so the call refuses."""
-    from plnerf_amd import depth as D
-    R = 8
-    batch, _ = orc.synthetic_blender_rays(R, seed=1)
-    b = g(batch).clone().requires_grad_(True)
-    with pytest.raises(NotImplementedError):
-        D.render_rays(b, True, None, None, 16, "constant", "midpoint")
+def test_sample_pdf_bin_gradients_vs_oracle(P):
+    """d samples / d bins of sample_pdf (run_nerf_helpers.py:241-284: samples = b0 + t (b1 - b0)) -- SampleConstFn -- against
+    the oracle's autograd in fp64; the gradient of the weights is the bits plnerf_sample_const_bwd gives without the request."""
+    from plnerf_amd import functional as Fn
+    for (R, B, N, seed) in [(64, 63, 64, 3), (33, 191, 128, 4), (16, 20, 77, 5)]:
+        gen = torch.Generator().manual_seed(seed)
+        bins = torch.sort(2.0 + 4.0 * torch.rand(R, B, generator=gen), -1).values
+        w = torch.rand(R, B - 1, generator=gen) ** 3
+        u = torch.rand(R, N, generator=gen) * 0.999
+        cot = torch.randn(R, N, generator=gen)
+        def bin_grad(dt):
+            b_o = bins.to(dt).clone().requires_grad_(True)
+            (orc.sample_pdf(b_o, w.to(dt), N, u=u.to(dt)) * cot.to(dt)).sum().backward()
+            return b_o.grad.double()
+        ref64, ref32 = bin_grad(torch.float64), bin_grad(torch.float32)
+        b_h, w_h = g(bins).clone().requires_grad_(True), g(w).clone().requires_grad_(True)
+        (Fn.sample_const(b_h, w_h, g(u)) * g(cot)).sum().backward()
+        scale = float(ref64.abs().max())
+        err = float((b_h.grad.cpu().double() - ref64).abs().max()) / scale
+        e_orc = float((ref32 - ref64).abs().max()) / scale
+        print(f"sample_pdf bins R={R} B={B} N={N}: d/d bins vs fp64 oracle: HIP {err:.2e}, fp32 oracle {e_orc:.2e} of max |g|")
+        # (t = (u - cdf) / (cdf step) cancels in fp32: the yardstick is the fp32 oracle's own distance from fp64)
+        assert b_h.grad.shape == bins.shape and err <= 2 * e_orc + 1e-5
+        w_2 = g(w).clone().requires_grad_(True)
+        (Fn.sample_const(g(bins), w_2, g(u)) * g(cot)).sum().backward()
+        assert torch.equal(w_2.grad, w_h.grad)
