@@ -25,9 +25,19 @@ constexpr int WAVES = 4;
 // fp32 row sum with the association order of torch.sum's vectorised CPU kernel (8-lane
 // vectors, 4 interleaved accumulators, leftover vectors into accumulator 0,
 // ((a0+a1)+a2)+a3, then the scalar tail first and the 8 vector lanes after it).
-// Verified against torch 2.10 CPU for every n in {1..4, 8..510} (tests + DESIGN.md).
+// Verified against torch 2.10 CPU for every n in 1..510 (tests/test_gpu_parity.py::test_sample_pdf_every_bin_count).
+// 4 <= n <= 7 is its own case there (round 5: found by tools/fuzz_samplers.py on weights that put u ON a cdf entry -- 24
+// search indices of 32,634 differed at 5 weights): one 4-lane vector, the tail added to lane 0 in order, then the lanes in
+// order -- (((((x0 + x4) + x5) + x6) + x1) + x2) + x3.
 // Lanes 0..7 of the wave play the 8 SIMD lanes; result is broadcast to the wave.
 __device__ __forceinline__ float torch_row_sum(const float* x, int n, int lane) {
+    if (n >= 4 && n < 8) {      // (uniform)
+        float t = x[0];
+        for (int e = 4; e < n; ++e) t = t + x[e];
+        t = t + x[1];
+        t = t + x[2];
+        return t + x[3];
+    }
     const int nvec = n >> 3;
     const int g4 = nvec & ~3;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;

@@ -178,6 +178,27 @@ def test_sample_pdf_bit_exact_large(P):
         assert_close(s, s_ref, what=f"sample_pdf large B={B}")
 
 
+def test_sample_pdf_every_bin_count(P):
+    """The search indices depend on the LAST BIT of the cdf, i.e. on the association order of torch.sum / cumsum on the
+    host (the pdf's normalisation): every weight count 1..70 and a few beyond, with weights that put draws exactly ON cdf
+    entries (equal weights, u = k / (N - 1)) -- where one ulp decides the bin -- and with random ones.  (4 <= n <= 7 takes
+    its own order in torch's vectorised sum: found in round 5 by tools/fuzz_samplers.py.)"""
+    from plnerf_amd import functional as Fn
+    R = 257
+    for n in list(range(1, 71)) + [100, 127, 128, 129, 255, 256, 509, 510]:
+        gen = torch.Generator().manual_seed(n)
+        bins, _ = torch.sort(2.0 + 4.0 * torch.rand(R, n + 1, generator=gen), -1)
+        w = torch.rand(R, n, generator=gen)
+        w[: R // 3] = torch.round(w[: R // 3] * 4.0) * 0.25          # few distinct values: draws land ON cdf entries
+        w[R // 3: R // 2] = 0.5                                       # all equal
+        for N, det in ((33, True), (64, True), (50, False)):
+            u = torch.rand(R, N, generator=gen) if not det else None
+            s_ref, i_ref = orc.sample_pdf(bins, w, N, det=det, u=u, return_inds=True)
+            s, inds = Fn.sample_const(g(bins), g(w), Fn.cpu_linspace(N, dev()) if det else g(u), want_inds=True)
+            assert torch.equal(inds.cpu(), i_ref), f"n={n} N={N} det={det}: {int((inds.cpu() != i_ref).sum())} index mismatches"
+            assert float((s.cpu() - s_ref).abs().max()) <= 1e-4, (n, N, det)
+
+
 def test_sample_pl_golden(P, golden):
     from plnerf_amd import functional as Fn
     gd = golden("g4_sample_pl")
