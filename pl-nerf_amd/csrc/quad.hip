@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void quad_bwd_kernel(QuadArgs a) {
         // seg_i = (knot_{i+1} - knot_i) |d|, the depth map weighs the elements' depths: a knot collects from the two
         // elements it bounds.  Linear: knots [near, z, far], element i between knots i and i + 1, depth = their mean.
         // Constant: element i from z_i to z_{i+1} (the last one is 1e10 |d| long), depth = z_i.
-        float gdn = 0.0f;
+        double gdn = 0.0;      // (up to 1023 terms that cancel: fp64, rounded once -- off every training path)
         if (MODE == PLNERF_MODE_LINEAR) {
             for (int k = lane; k < S + 2; k += 64) {
                 const float s_lo = k > 0 ? sv[k - 1] : 0.0f, s_hi = k <= S ? sv[k] : 0.0f;
@@ -273,19 +273,19 @@ __global__ __launch_bounds__(256) void quad_bwd_kernel(QuadArgs a) {
                 if (k == 0) a.g_near[ray] = g;
                 else if (k == S + 1) a.g_far[ray] = g;
                 else a.g_z[(size_t)ray * S + k - 1] = g;
-                if (k <= S) gdn += sv[k] * (zk[k + 1] - zk[k]);
+                if (k <= S) gdn += (double)sv[k] * (double)(zk[k + 1] - zk[k]);
             }
         } else {
             for (int k = lane; k < S; k += 64) {
                 const float s_lo = k > 0 ? sv[k - 1] : 0.0f, s_hi = k < S - 1 ? sv[k] : 0.0f;
                 a.g_z[(size_t)ray * S + k] = dnorm * (s_lo - s_hi) + gdep * wv[k];
-                gdn += sv[k] * (k < S - 1 ? zk[k + 2] - zk[k + 1] : 1e10f);
+                gdn += (double)sv[k] * (double)(k < S - 1 ? zk[k + 2] - zk[k + 1] : 1e10f);
             }
             if (lane == 0) { a.g_near[ray] = 0.0f; a.g_far[ray] = 0.0f; }
         }
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) gdn += __shfl_xor(gdn, d);
-        if (lane == 0) a.g_dnorm[ray] = gdn;
+        if (lane == 0) a.g_dnorm[ray] = (float)gdn;
     }
     if (a.absmax_out) {
         // One plain store per workgroup, no atomic: 4096 atomicMax on one address cost the launch 46 us of serialised L2
