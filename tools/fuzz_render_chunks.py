@@ -74,7 +74,7 @@ for case in range(a.cases):
                     bad.append(f"draws={draws}: {k} differs between chunk {chunks[0]} and chunk {chunks[j]}")
         if not draws and static is None:
             # (the oracle on the rays this device computed: torch's own get_rays expression differs by an ulp between host
-            # and device -- fused multiply-adds in the 3-term sum -- and the encoding's top frequency turns an ulp of a
+            # and device -- the 3-term sum is associated differently by the device's reduction kernel -- and the encoding's top frequency turns an ulp of a
             # direction into 1e-4 of a map; the first version of this campaign measured exactly that)
             o, dd = (t.cpu() for t in P.get_rays(H, W_, K, c2w))
             ref = orc.render_rays(orc.pack_ray_batch(o, dd, 2.0, 6.0), sds[0], sds[1], Ns, mode, "midpoint", perturb=0.0, N_importance=Ni,
