@@ -633,7 +633,7 @@ def main(argv=None):
             "vs_baseline": None, "dtype": DTYPE[a.precision], "data": "synthetic",
             "config": {"workload": f"{a.workload} -- {desc}; N_rand={R}/GPU, N_samples={a.n_samples}, "
                                    f"N_importance={a.n_importance}, mode=linear/midpoint; full step = device-side pixel "
-                                   f"choice + ray generation + render + backward + per-network grad all-reduce + Adam",
+                                   f"choice + ray generation + render + backward + one gradient all-reduce for both networks + Adam",
                        "global_rays": R * world, "precision": a.precision, "parallelism": f"dp{world}",
                        "rccl_world_size": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
                        "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
