@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("tool,cases", [("fuzz_render_rays.py", 12), ("fuzz_render_rays_depth.py", 8), ("fuzz_train_step.py", 8),
-                                        ("fuzz_samplers.py", 40), ("fuzz_quadrature.py", 40), ("fuzz_mlp.py", 24), ("fuzz_glue.py", 30), ("fuzz_render_chunks.py", 6)])
+                                        ("fuzz_samplers.py", 40), ("fuzz_quadrature.py", 40), ("fuzz_mlp.py", 24), ("fuzz_glue.py", 30), ("fuzz_render_chunks.py", 6), ("fuzz_train_step_depth.py", 8)])
 def test_campaign(tool, cases):
     run = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "--cases", str(cases), "--seed", "2026"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT)

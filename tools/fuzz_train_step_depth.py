@@ -1,0 +1,146 @@
+"""Gradient campaign for the depth-supervised step (depth_supervised_exps/run_nerf_sample_based_depth.py:1126-1157): loss =
+img2mse(rgb) + w * space_carving(pred_hyp, target hypotheses) + img2mse(rgb0) and all 48 parameter gradients (before clipping)
+against the CPU oracle's autograd -- the sampler's backward (plnerf_sample_pl_bwd), g_tau / g_T into the quadrature's, the
+softplus density's derivative, the 57 | 3-channel network -- over random configurations (3-130 rays, 8-64 + 4-64 samples,
+colour rules, background, density noise), exact fp32 and f16x3.
+
+As tools/fuzz_train_step.py: the oracle's fine pass runs on the path's own merged depths and draws (the importance samples are
+detached on both sides), and the networks' ReLU units are decisively on or off, so that neither a sample in another cdf bin nor a
+flipped unit masks a kernel error.  What remains between two fp32 evaluations is the sampler's closed form, which cancels
+(tests/test_gpu_parity.py::test_sampler_backward_vs_oracle_autograd: fp32 sits 1e-3 ... 1e-2 of max |g| from fp64): bounds
+5e-3 (fp32) / 1e-2 (f16x3) of a tensor's max |g| or of a tenth of the network's largest entry (the density head's bias is a sum that
+cancels: 9.9e-3 of its own largest entry in fp32 on one case, cosine 0.99999997), cosine >= 0.9999, loss 2e-5.
+python tools/fuzz_train_step_depth.py --cases 80 --seed 31 > out.json"""
+import argparse, json, os, sys
+from argparse import Namespace
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import plnerf_amd as P
+from plnerf_amd import depth as Dp
+from oracle import plnerf_oracle as orc
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", type=int, default=80)
+ap.add_argument("--seed", type=int, default=31)
+a = ap.parse_args()
+torch.set_num_threads(min(16, os.cpu_count() or 1))
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(a.seed)
+F = torch.nn.functional
+TOL = {"fp32": 5e-3, "f16x3": 1e-2}
+W_SC = 0.05
+
+
+def decisive_depth(seed, box=4.5, n_probe=8000, margin=1.5):
+    """closed_form_state_dict_depth with every hidden unit pushed decisively on or off over the scene box, the density
+    (before its softplus) rescaled to N(0.3, 0.06^2) and the colours to unit spread (tests/test_gpu_raygrad.py explains)."""
+    sd = {k: v.double().clone() for k, v in orc.closed_form_state_dict_depth(seed, True).items()}
+    gen = torch.Generator().manual_seed(2000 + seed)
+    pts = (torch.rand(n_probe, 3, generator=gen, dtype=torch.float64) * 2 - 1) * box
+    vd = F.normalize(torch.randn(n_probe, 3, generator=gen, dtype=torch.float64), dim=-1)
+    enc_xyz, enc_dir = orc.positional_encoding_pi(pts, orc.DEPTH_XYZ_FREQS), orc.positional_encoding_pi(vd, orc.DEPTH_DIR_FREQS)
+
+    def decide(z, key):
+        lo, hi = z.min(0).values, z.max(0).values
+        sign = torch.where(torch.rand(z.shape[1], generator=gen) < 0.5, 1.0, -1.0).double()
+        shift = -0.5 * (hi + lo) + sign * (margin * 0.5 * (hi - lo) + 0.05)
+        sd[key] += shift
+        return z + shift
+    h = enc_xyz
+    for i in range(orc.DEPTH):
+        h = F.relu(decide(F.linear(h, sd[f"pts_linears.{i}.weight"], sd[f"pts_linears.{i}.bias"]), f"pts_linears.{i}.bias"))
+        if i == orc.SKIP_AFTER:
+            h = torch.cat([enc_xyz, h], -1)
+    alpha = F.linear(h, sd["alpha_linear.weight"], sd["alpha_linear.bias"])
+    feat = F.linear(h, sd["feature_linear.weight"], sd["feature_linear.bias"])
+    hv = F.relu(decide(F.linear(torch.cat([feat, enc_dir], -1), sd["views_linears.0.weight"], sd["views_linears.0.bias"]),
+                       "views_linears.0.bias"))
+    rgb = F.linear(hv, sd["rgb_linear.weight"], sd["rgb_linear.bias"])
+    k_s = 0.06 / float(alpha.std())
+    sd["alpha_linear.weight"] *= k_s
+    sd["alpha_linear.bias"] = (sd["alpha_linear.bias"] - alpha.mean()) * k_s + 0.3
+    k_c = 1.5 / rgb.std(0)
+    sd["rgb_linear.weight"] *= k_c[:, None]
+    sd["rgb_linear.bias"] = (sd["rgb_linear.bias"] - rgb.mean(0)) * k_c
+    return {k: v.float() for k, v in sd.items()}
+
+
+SDS = {s: decisive_depth(s) for s in range(4)}
+
+
+def setup(precision):
+    args = Namespace(multires=9, i_embed=0, use_viewdirs=True, multires_views=0, input_ch_cam=0, N_importance=32, N_samples=32,
+                     netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256, netchunk=65536, lrate=5e-4, perturb=1.0,
+                     white_bkgd=True, raw_noise_std=0.0, mode="linear", color_mode="midpoint", lindisp=False, no_reload=True,
+                     space_carving_weight=W_SC, warm_start_nerf=0, is_joint=False, norm_p=2, space_carving_threshold=0.0,
+                     precision=precision, bb_center=0.0, bb_scale=1.0)
+    so = sys.stdout; sys.stdout = open(os.devnull, "w")
+    try:
+        kw = Dp.create_nerf(args, device=dev)[0]
+    finally:
+        sys.stdout = so
+    return kw
+
+
+kws = {p: setup(p) for p in TOL}
+worst = {p: {"loss": 0.0, "coarse": 0.0, "fine": 0.0, "cos_coarse": 1.0, "cos_fine": 1.0} for p in TOL}
+violations = []
+for case in range(a.cases):
+    s_c, s_f = int(rng.integers(2)), 2 + int(rng.integers(2))
+    cfg = dict(N_samples=int(rng.choice([8, 17, 32, 64])), N_importance=int(rng.choice([4, 9, 32, 64])), mode="linear",
+               color_mode=["midpoint", "left"][int(rng.integers(2))], white_bkgd=bool(rng.integers(2)),
+               raw_noise_std=float(rng.choice([0.0, 1.0])), perturb=1.0)
+    R = int(rng.choice([3, 33, 64, 130]))
+    batch, target = orc.synthetic_blender_rays(R, seed=13000 + case)
+    gen = torch.Generator().manual_seed(13000 + case)
+    target_h = 2.0 + 4.0 * torch.rand(3, R, 1, generator=gen)
+    near, far = batch[:, 6:7], batch[:, 7:8]
+    for prec, kw in kws.items():
+        kw["network_fn"].load_state_dict(SDS[s_c]); kw["network_fine"].load_state_dict(SDS[s_f])
+        kw["network_fn"].zero_grad(); kw["network_fine"].zero_grad()
+        ret = Dp.render_rays(batch.to(dev), retraw=True, pytest=True, **dict(kw, **cfg))
+        sc = Dp.compute_space_carving_loss(ret["pred_hyp"], target_h.to(dev))
+        loss = P.img2mse(ret["rgb_map"], target.to(dev)) + W_SC * sc + P.img2mse(ret["rgb0"], target.to(dev))
+        loss.backward()
+        p_c = {k: v.clone().requires_grad_(True) for k, v in SDS[s_c].items()}
+        p_f = {k: v.clone().requires_grad_(True) for k, v in SDS[s_f].items()}
+        ref = orc.render_rays_depth(batch, p_c, p_f, cfg["N_samples"], "linear", cfg["color_mode"], perturb=1.0,
+                                    N_importance=cfg["N_importance"], white_bkgd=cfg["white_bkgd"], raw_noise_std=cfg["raw_noise_std"],
+                                    pytest=True)
+        z_fine = ret["z_vals"].detach().cpu()
+        fs = orc.fine_stage(batch, p_f, z_fine, "linear", cfg["color_mode"], cfg["white_bkgd"], cfg["raw_noise_std"], True,
+                            depth_variant=True)
+        hyp = orc.sample_pdf_reformulation(z_fine, fs["weights"], fs["tau"], fs["T"], near, far, cfg["N_importance"],
+                                           u=ret["u"].detach().cpu())[0]
+        ref_loss = torch.mean((fs["rgb_map"] - target) ** 2) + W_SC * orc.compute_space_carving_loss(hyp, target_h) \
+            + torch.mean((ref["rgb0"] - target) ** 2)
+        ref_loss.backward()
+        bad = []
+        e_loss = abs(float(loss.detach()) - float(ref_loss.detach()))
+        worst[prec]["loss"] = max(worst[prec]["loss"], e_loss)
+        if e_loss > 2e-5:
+            bad.append(f"loss {e_loss:.2e}")
+        for net, prm_ref, tag in ((kw["network_fn"], p_c, "coarse"), (kw["network_fine"], p_f, "fine")):
+            grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in prm_ref.items()}
+            g_max = max(float(x.abs().max()) for x in grads.values())
+            e_w, which = 0.0, None
+            for name, prm in net.named_parameters():
+                r = grads[name]
+                scale = max(float(r.abs().max()), 0.1 * g_max, 1e-12)      # (a density bias sums terms that cancel: judged against a tenth of the network's largest entry)
+                e = float((prm.grad.cpu() - r).abs().max()) / scale
+                if e > e_w:
+                    e_w, which = e, name
+            fh = torch.cat([p.grad.cpu().double().reshape(-1) for _, p in net.named_parameters()])
+            fo = torch.cat([grads[name].double().reshape(-1) for name, _ in net.named_parameters()])
+            cos = float(torch.dot(fh, fo) / (fh.norm() * fo.norm())) if float(fo.norm()) > 0 else float(float(fh.norm()) == 0.0)
+            worst[prec][tag], worst[prec]["cos_" + tag] = max(worst[prec][tag], e_w), min(worst[prec]["cos_" + tag], cos)
+            if e_w > TOL[prec]:
+                bad.append(f"{tag} {which}: {e_w:.2e}")
+            if cos < 0.9999:
+                bad.append(f"{tag} cosine {cos:.6f}")
+        if bad:
+            violations.append({"case": case, "precision": prec, "R": R, "cfg": cfg, "what": bad})
+print(json.dumps({"what": "depth-supervised step: gradient campaign vs the CPU oracle's autograd on identical samples, decisive networks",
+                  "cases": a.cases, "seed": a.seed, "bounds": TOL, "worst": worst, "violations": violations}))
+sys.exit(1 if violations else 0)
