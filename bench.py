@@ -43,7 +43,7 @@ TRAIN_FLOP_PER_ROW = 3489024    # forward + wgrad + dgrad
 TRAFFIC_FILE = "r05_traffic.json"   # refreshed per round by tools/pmc_traffic.sh
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s HBM3E
 # training forward, algorithmic bytes per row: saved state written + xyz read (12) + raw written (16)
-FWD_TRAIN_BYTES_PER_ROW = {"fp32": 2596 * 4 + 28, "h16": 2528 * 2 + 272 + 28}   # fp32 planes | half planes + relu masks
+FWD_TRAIN_BYTES_PER_ROW = {"fp32": 2596 * 4 + 28, "h16": 2272 * 2 + 272 + 28}   # fp32 planes | half planes + relu masks
 PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "f16x3": 2500.0, "f16": 2500.0}   # MI355X_MICROARCH.md, dense
 MFMA_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "bf16": 1, "f16x3": 3, "f16": 1}
 DTYPE = {"fp32": "f32", "bf16x3": "bf16x3 (3-term bf16 split, f32 accumulate)", "bf16": "bf16 (f32 accumulate)",

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PLNERF_VERSION 502 /* major*10000 + minor*100 + patch */
+#define PLNERF_VERSION 600 /* major*10000 + minor*100 + patch */
 
 /* error codes */
 #define PLNERF_OK 0

@@ -18,6 +18,7 @@ COLOR = {"midpoint": 0, "left": 1}
 PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3, "f16": 4}
 GUARDED_PRECISIONS = ("f16x3", "f16", "bf16x3", "bf16")      # modes whose kernels can set a bit of the range status word
 N_PARAM_TENSORS = 24
+ABI_VERSION = 600                      # PLNERF_VERSION of include/plnerf_hip.h this binding was written against
 QUAD_RAYS_PER_GROUP = 4                # PLNERF_QUAD_RAYS_PER_GROUP: rays per workgroup of plnerf_quad_bwd (its absmax_out)
 DEPTH_LOSS_WORKSPACE_BYTES = 4096      # PLNERF_DEPTH_LOSS_WORKSPACE_BYTES
 IMAGE_LOSS_WORKSPACE_BYTES = 4096      # PLNERF_IMAGE_LOSS_WORKSPACE_BYTES
@@ -99,6 +100,14 @@ def lib():
             fn = getattr(handle, name)   # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
+        # The argument lists above are positional: a library of another ABI (a stale build, a variant linked from old
+        # objects) would be called with shifted pointers -- compare before the first call.  tools/ A/B legs
+        # against an older library whose signatures are known to match set PLNERF_ALLOW_TOOLS_BUILD=1.
+        version = handle.plnerf_version()
+        if version != ABI_VERSION and os.environ.get("PLNERF_ALLOW_TOOLS_BUILD") != "1":
+            raise ImportError(
+                f"{LIB_PATH} reports plnerf_version() = {version}, this binding is written against {ABI_VERSION} "
+                "(include/plnerf_hip.h): rebuild with `make -C pl-nerf_amd/csrc clean all`.")
         flags = handle.plnerf_build_flags()
         if flags and os.environ.get("PLNERF_ALLOW_TOOLS_BUILD") != "1":
             raise ImportError(

@@ -49,6 +49,10 @@ inline unsigned* status_word(void* packed, int precision) {
     return ns_of(precision) ? (unsigned*)((unsigned char*)packed + sections_bytes(precision)) : nullptr;      // every 16-bit mode
 }
 
+inline float* compose_block(const void* packed, int precision) {      // (16-bit modes)
+    return (float*)((unsigned char*)const_cast<void*>(packed) + impl::bf16_compose_offset(ns_of(precision)));
+}
+
 extern "C" size_t plnerf_mlp_packed_bytes(int precision) {
     const size_t n = known(precision) ? sections_bytes(precision) : 0;
     return n ? n + 16 : 0;
@@ -63,12 +67,16 @@ extern "C" int plnerf_mlp_pack_weights(const float* const* params, int precision
     for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i)
         if (!params[i]) return PLNERF_EINVAL;
     if (precision == PLNERF_PREC_FP32) return impl::f32_pack(params, input_ch, input_ch_views, packed, (hipStream_t)stream);
-    const int rc = impl::bf16_pack(params, input_ch, input_ch_views, ns_of(precision), f16_of(precision), packed,
-                                   status_word(packed, precision), (hipStream_t)stream);
+    // 16-bit modes: the composed view layer first (W_c = W_vf W_f, b_c; mlp_layout.h) -- the operand sections are packed from it
+    float* cb = compose_block(packed, precision);
+    int rc = impl::compose_pack(params, input_ch_views, cb, (hipStream_t)stream);
+    if (rc) return rc;
+    rc = impl::bf16_pack(params, input_ch, input_ch_views, ns_of(precision), f16_of(precision), packed,
+                         status_word(packed, precision), (hipStream_t)stream);
     if (rc) return rc;
     void* rr_section = (unsigned char*)packed + impl::bf16_packed_bytes(ns_of(precision));
-    return f16_of(precision) ? impl::rr_pack(params, input_ch, input_ch_views, ns_of(precision), rr_section, (hipStream_t)stream)
-                             : impl::rr_pack_bf16(params, input_ch, input_ch_views, ns_of(precision), rr_section, (hipStream_t)stream);
+    return f16_of(precision) ? impl::rr_pack(params, input_ch, input_ch_views, ns_of(precision), cb, rr_section, (hipStream_t)stream)
+                             : impl::rr_pack_bf16(params, input_ch, input_ch_views, ns_of(precision), cb, rr_section, (hipStream_t)stream);
 }
 
 // fp32 mode: fp32 planes; 16-bit MFMA modes: half planes (mlp_layout.h)
@@ -89,8 +97,8 @@ extern "C" int plnerf_mlp_saved_layout(int precision, int has_embedded, int fwd_
 
 extern "C" size_t plnerf_mlp_bwd_workspace_bytes(int n_rows, int precision) {
     if (!known(precision) || n_rows < 0) return 0;
-    const size_t partials = ((size_t)lay::MAX_SPLITS * lay::PART_PER_SPLIT + (size_t)lay::MAX_HEAD_WGS * lay::HEAD_PART) *
-                            sizeof(float);
+    const size_t partials = ((size_t)lay::MAX_SPLITS * lay::PART_PER_SPLIT + (size_t)lay::MAX_HEAD_WGS * lay::HEAD_PART +
+                             (size_t)lay::GRED_FLOATS) * sizeof(float);      // (+ the reduced G and s of the composed view layer)
     const size_t g_eff = (size_t)n_rows * 16;      // the upstream gradient after the density activation's derivative
     if (precision == PLNERF_PREC_FP32) return (size_t)lay::DZ_PER_ROW * (size_t)n_rows * sizeof(float) + partials + g_eff;
     return impl::h16_dz_bytes(n_rows) + lay::WSH_SCALARS_BYTES + partials + g_eff;
@@ -153,7 +161,8 @@ extern "C" int plnerf_mlp_bwd_multi(int n_jobs, const void* const* packed, int p
             if (!grads[j * PLNERF_N_PARAM_TENSORS + i]) return PLNERF_EINVAL;
     }
     hipStream_t st = (hipStream_t)stream;
-    const size_t part_bytes = ((size_t)lay::MAX_SPLITS * lay::PART_PER_SPLIT + (size_t)lay::MAX_HEAD_WGS * lay::HEAD_PART) * sizeof(float);
+    const size_t part_only = ((size_t)lay::MAX_SPLITS * lay::PART_PER_SPLIT + (size_t)lay::MAX_HEAD_WGS * lay::HEAD_PART) * sizeof(float);
+    const size_t part_bytes = part_only + (size_t)lay::GRED_FLOATS * sizeof(float);
     if (precision == PLNERF_PREC_FP32) {
         for (int j = 0; j < n_jobs; ++j) {
             float* dz = (float*)workspace[j];
@@ -200,7 +209,8 @@ extern "C" int plnerf_mlp_bwd_multi(int n_jobs, const void* const* packed, int p
         dj[j] = impl::DgradJob{packed[j], ns_of(precision), g, n_rows[j], saved[j], ws, gmax, cand, n_cand};
         wj[j] = impl::WgradJob{g, n_rows[j], saved[j], ws, gmax, partials, grads + j * PLNERF_N_PARAM_TENSORS, input_ch,
                                input_ch_views, saved_layout[j], status_word(const_cast<void*>(packed[j]), precision),
-                               status_out ? status_out[j] : nullptr};
+                               status_out ? status_out[j] : nullptr, compose_block(packed[j], precision),
+                               (float*)((unsigned char*)partials + part_only)};
     }
     const int rc = impl::bf16_dgrad(n_jobs, dj, st);
     if (rc) return rc;

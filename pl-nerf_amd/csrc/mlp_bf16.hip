@@ -56,6 +56,7 @@ namespace plnerf {
 namespace impl {
 
 size_t bf16_packed_bytes(int ns) { return plnerf_h16_bf16::h16_packed_bytes(ns); }
+size_t bf16_compose_offset(int ns) { return plnerf_h16_bf16::h16_compose_offset(ns); }
 
 int bf16_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, int f16, void* packed, unsigned* status,
               hipStream_t st) {

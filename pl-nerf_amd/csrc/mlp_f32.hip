@@ -473,7 +473,7 @@ size_t f32_packed_bytes() { return (size_t)PACKED_FLOATS * sizeof(float); }
 
 int f32_pack(const float* const* params, int xyz_ch, int dir_ch, void* packed, hipStream_t st) {
     ParamPtrs P;
-    P.xyz_ch = xyz_ch; P.dir_ch = dir_ch;
+    P.xyz_ch = xyz_ch; P.dir_ch = dir_ch; P.cb = nullptr;
     for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i) {
         if (!params[i]) return PLNERF_EINVAL;
         P.p[i] = params[i];

@@ -43,6 +43,8 @@ struct WgradJob {
     int xyz_ch, dir_ch, saved_layout;
     const unsigned* status;
     float* status_out;
+    const float* cb;          // the compose block of the job's packed weights (mlp_layout.h: CB_*): the factors W_vf, W_f, b_f
+    float* gred;              // lay::GRED_FLOATS floats of workspace: the reduced G and s on their way to the factors' gradients
 };
 int wgrad_h16_multi(int n, const WgradJob* jobs, hipStream_t st);
 // one network's share of the dgrad grid (mlp_bwd_h16_kernel, two networks per grid)
@@ -57,6 +59,18 @@ struct DgradJob {
     const unsigned* cand;     // n_cand candidates whose maximum is that word, or nullptr / 0
     int n_cand;
 };
+// The composed view layer of the 16-bit modes (mlp_layout.h; mlp_compose.hip).
+//   compose_pack: cb <- W_c = W_vf W_f, b_c = W_vf b_f + b_v (fp64 accumulation, rounded once) and copies of W_vf, W_f, b_f
+//   compose_grads (per job, after the split-K reduction left G and s in `gred`): grads[P_WF] = W_vf^T G, grads[P_BF] = W_vf^T s,
+//                 the feature columns of grads[P_WV] = G W_f^T + s b_f^T
+int compose_pack(const float* const* params, int dir_ch, float* cb, hipStream_t st);
+struct ComposeGradJob {
+    const float* cb;
+    const float* gred;
+    float* const* grads;
+    int dir_ch;
+};
+int compose_grads(int n, const ComposeGradJob* jobs, hipStream_t st);
 // gradient with respect to the embedded input rows, from the dz planes a finished plnerf_mlp_bwd left in its workspace
 int input_grad(const float* const* params, int n_rows, const void* dz, const unsigned* gmax, bool h16, int xyz_ch,
                int dir_ch, float* g_emb, hipStream_t st);
@@ -70,12 +84,13 @@ int absmax(const float* x, size_t n, unsigned* out, hipStream_t st);
 #define PLNERF_BWD_TM 192
 #endif
 inline size_t h16_dz_bytes(int n_rows) {      // (lay::dz_rows)
-    return (size_t)4864 * (((size_t)n_rows + PLNERF_BWD_TM - 1) / PLNERF_BWD_TM * PLNERF_BWD_TM);
+    return (size_t)4352 * (((size_t)n_rows + PLNERF_BWD_TM - 1) / PLNERF_BWD_TM * PLNERF_BWD_TM);
 }
 
 // 16-bit-operand MFMA modes.  ns = 1: plain operands; ns = 2: 3-term split (hi/lo planes).
 // f16 = 0: bf16 elements; f16 = 1: IEEE half elements.
 size_t bf16_packed_bytes(int ns);
+size_t bf16_compose_offset(int ns);      // byte offset of the compose block (lay::CB_FLOATS floats) inside the packed buffer
 int bf16_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, int f16, void* packed, unsigned* status,
               hipStream_t st);
 int bf16_fwd(const void* packed, int ns, int f16, const float* pts, const float* viewdirs, const float* embedded,
@@ -84,9 +99,9 @@ int bf16_fwd(const void* packed, int ns, int f16, const float* pts, const float*
 int bf16_dgrad(int n, const DgradJob* jobs, hipStream_t st);
 
 // Register-resident forward kernel (mlp_rr.hip; IEEE-half elements): its own weight section (k order permuted to the
-// accumulator layout) appended to the packed buffer of the half modes.
+// accumulator layout) appended to the packed buffer of the half modes.  (cb: the compose block, written before the call)
 size_t rr_packed_bytes(int ns);
-int rr_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, void* section, hipStream_t st);
+int rr_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, const float* cb, void* section, hipStream_t st);
 struct RrFwdArgs {
     const void* packed;     // head block at the start
     const void* wrr;        // the register-resident section of the packed weights
@@ -107,7 +122,7 @@ int rr_fwd(const void* packed, const void* section, int ns, const float* pts, co
            unsigned* status, hipStream_t st);
 // the same kernel on bf16 elements (mlp_rr_body.inc compiled with RR_BF16): inference, and -- split mode only -- the
 // training forward and caller-embedded inputs
-int rr_pack_bf16(const float* const* params, int xyz_ch, int dir_ch, int ns, void* section, hipStream_t st);
+int rr_pack_bf16(const float* const* params, int xyz_ch, int dir_ch, int ns, const float* cb, void* section, hipStream_t st);
 int rr_fwd_bf16(const void* packed, const void* section, int ns, const float* pts, const float* viewdirs,
                 const float* embedded, int in_ch, int view_ch, int n_rows, int samples_per_ray, FwdOpt opt,
                 float* raw_out, void* saved, unsigned* status, hipStream_t st);

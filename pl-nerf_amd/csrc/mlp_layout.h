@@ -70,6 +70,45 @@ constexpr int bwd_off(int g) {
 }
 constexpr int PACKED_FLOATS = bwd_off(N_BWD);
 
+// ---- the network as the 16-bit MFMA modes evaluate it: feature_linear composed into the view layer ------------------
+// run_nerf_helpers.py:115-121 puts NO activation between feature_linear and views_linears[0], so
+//     hv_pre = W_vf (W_f h7 + b_f) + W_vd dir + b_v  =  W_c h7 + W_vd dir + b_c,   W_c = W_vf W_f (128 x 256), b_c = W_vf b_f + b_v
+// (W_vf / W_vd: the feature / direction columns of views_linears.0.weight).  The 16-bit modes evaluate the right-hand side
+// (round 6): the 256 x 256 feature GEMM (65,536 of the row's 593,408 MACs), its dgrad GEMM, its weight-gradient job, the
+// `feature` saved plane and the dz_feature plane disappear.  The backward recovers the two factors' gradients exactly from
+// G = dz_view^T h7 (128 x 256) and s = column sums of dz_view:  dW_f = W_vf^T G,  db_f = W_vf^T s,  dW_vf = G W_f^T + s b_f^T
+// (mlp_compose.hip).  The exact-fp32 mode keeps the reference's two layers op for op (tables above).
+enum FwdGemmC { GC_L0 = 0, GC_L1, GC_L2, GC_L3, GC_L4, GC_L5, GC_L6, GC_L7, GC_VIEWS, N_FWDC };
+constexpr int fwdc_K[N_FWDC] = {64, 256, 256, 256, 256, 320, 256, 256, 288};
+constexpr int fwdc_N[N_FWDC] = {256, 256, 256, 256, 256, 256, 256, 256, 128};
+constexpr int fwdc_off(int g) {
+    int o = 0;
+    for (int i = 0; i < g; ++i) o += fwdc_K[i] * fwdc_N[i];
+    return o;
+}
+constexpr int FWDC_FLOATS = fwdc_off(N_FWDC);  // 528,384
+// dgrad: d h7 = dz_view W_c (K = 128), then the trunk as before
+enum BwdGemmC { DC_VIEWS = 0, DC_L7, DC_L6, DC_L5, DC_L4, DC_L3, DC_L2, DC_L1, N_BWDC };
+constexpr int bwdc_K[N_BWDC] = {128, 256, 256, 256, 256, 256, 256, 256};
+constexpr int bwdc_N[N_BWDC] = {256, 256, 256, 256, 256, 256, 256, 256};
+constexpr int bwdc_off(int g) {      // (relative to the dgrad section's start)
+    int o = 0;
+    for (int i = 0; i < g; ++i) o += bwdc_K[i] * bwdc_N[i];
+    return o;
+}
+constexpr int BWDC_FLOATS = bwdc_off(N_BWDC);
+// The compose block of the packed buffer (fp32, written by plnerf_mlp_pack_weights before the operand sections are packed
+// from it): W_c and b_c for the packing kernels; the factors themselves for the backward's last step, which has the
+// packed buffer but not the parameter tensors.
+constexpr int CB_WC = 0;                     // [128][256]
+constexpr int CB_BC = CB_WC + HV * W;        // [128]
+constexpr int CB_WVF = CB_BC + HV;           // [128][256]  views_linears.0.weight[:, :256]
+constexpr int CB_WF = CB_WVF + HV * W;       // [256][256]  feature_linear.weight
+constexpr int CB_BF = CB_WF + W * W;         // [256]       feature_linear.bias
+constexpr int CB_FLOATS = CB_BF + W;         // 131,456
+// the reduced G (128 x 256) and s (128) between the weight-gradient reduction and the factors' gradients (workspace)
+constexpr int GRED_FLOATS = HV * W + HV;
+
 // ---- forward state saved for backward (floats per row, plane-major: plane p starts at
 // plane_off(p) * n_rows) ---------------------------------------------------------------
 // planes 0..7 = h0..h7 (post-relu), 8 = feature, then hv [128], pe [64], dpe [32]
@@ -144,8 +183,16 @@ __host__ __device__ constexpr size_t sv_tiled_index(size_t row, int col, int wid
 #endif
 constexpr int DZ_ROW_PAD = PLNERF_BWD_TM;
 __host__ __device__ constexpr size_t dz_rows(size_t n_rows) { return (n_rows + DZ_ROW_PAD - 1) / DZ_ROW_PAD * DZ_ROW_PAD; }
-constexpr int SVH_BYTES_PER_ROW = SV_FLOATS * 2 + SV_MASK_BYTES;   // 5328
-constexpr int DZH_BYTES_PER_ROW = DZ_PER_ROW * 2;                  // 4864
+// planes of the half state (the composed network has no feature plane and no dz_feature plane): h0..h7, then hv [128], pe [64],
+// dpe [32]; dz0..dz7, then dz_view [128]
+constexpr int SVC_HV_OFF = 8 * W;
+constexpr int SVC_PE_OFF = SVC_HV_OFF + HV;
+constexpr int SVC_DPE_OFF = SVC_PE_OFF + PE_K;
+constexpr int SVC_FLOATS = SVC_DPE_OFF + DPE_K;                    // 2272 halves per row
+constexpr int DZC_V_OFF = 8 * W;
+constexpr int DZC_PER_ROW = DZC_V_OFF + HV;                        // 2176 halves per row
+constexpr int SVH_BYTES_PER_ROW = SVC_FLOATS * 2 + SV_MASK_BYTES;  // 4816
+constexpr int DZH_BYTES_PER_ROW = DZC_PER_ROW * 2;                 // 4352
 constexpr int WSH_SCALARS_BYTES = 16;                              // max |g_raw| (fp32 bits) + pad
 #ifndef PLNERF_DZH_TARGET_EXP
 #define PLNERF_DZH_TARGET_EXP 4

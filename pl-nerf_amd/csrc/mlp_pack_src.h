@@ -8,7 +8,8 @@ namespace plnerf {
 
 // xyz_ch / dir_ch: the network's input_ch / input_ch_views (63 / 27 at the reference's default flags,
 // 57 / 3 for the depth-supervised variant); the GEMMs' K ranges are padded to PE_K / DPE_K with zeros.
-struct ParamPtrs { const float* p[PLNERF_N_PARAM_TENSORS]; int xyz_ch, dir_ch; };
+// cb: the compose block of the packed buffer (mlp_layout.h: CB_*; the 16-bit modes' packing kernels), else unused
+struct ParamPtrs { const float* p[PLNERF_N_PARAM_TENSORS]; int xyz_ch, dir_ch; const float* cb; };
 struct GradPtrs { float* p[PLNERF_N_PARAM_TENSORS]; int xyz_ch, dir_ch; };
 
 using namespace lay;
@@ -44,5 +45,18 @@ __device__ __forceinline__ float bwd_src(const ParamPtrs& P, int g, int o, int i
     }
 }
 
+// The same for the composed network of the 16-bit modes (FwdGemmC / BwdGemmC): the view layer reads h7 through
+// W_c = W_vf W_f, which plnerf_mlp_pack_weights left in the compose block (P.cb) before the packing kernels run.
+__device__ __forceinline__ float fwdc_src(const ParamPtrs& P, int g, int k, int j) {
+    if (g == GC_VIEWS) {
+        if (k < W) return P.cb[CB_WC + j * W + k];
+        return (k - W) < P.dir_ch ? P.p[P_WV][j * (W + P.dir_ch) + k] : 0.0f;
+    }
+    return fwd_src(P, g, k, j);      // GC_L0..GC_L7 = G_L0..G_L7
+}
+__device__ __forceinline__ float bwdc_src(const ParamPtrs& P, int g, int o, int i) {
+    if (g == DC_VIEWS) return P.cb[CB_WC + o * W + i];
+    return bwd_src(P, g + 1, o, i);   // DC_L7.. = D_L7.. shifted by the feature GEMM that is not there
+}
 
 }  // namespace plnerf

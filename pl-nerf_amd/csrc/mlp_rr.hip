@@ -35,13 +35,13 @@ RR_LAUNCH(rr_launch_2_infer_emb, 2, false, true)
 RR_LAUNCH(rr_launch_2_train_emb, 2, true, true)
 #undef RR_LAUNCH
 
-size_t rr_packed_bytes(int ns) { return (size_t)lay::FWD_FLOATS * ns * 2; }
+size_t rr_packed_bytes(int ns) { return (size_t)lay::FWDC_FLOATS * ns * 2; }
 
-int rr_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, void* section, hipStream_t st) {
+int rr_pack(const float* const* params, int xyz_ch, int dir_ch, int ns, const float* cb, void* section, hipStream_t st) {
     ParamPtrs P;
-    P.xyz_ch = xyz_ch; P.dir_ch = dir_ch;
+    P.xyz_ch = xyz_ch; P.dir_ch = dir_ch; P.cb = cb;
     for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i) P.p[i] = params[i];
-    const int groups = lay::FWD_FLOATS / 8, threads = 256, blocks = (groups + threads - 1) / threads;
+    const int groups = lay::FWDC_FLOATS / 8, threads = 256, blocks = (groups + threads - 1) / threads;
     if (ns == 1) hipLaunchKernelGGL(plnerf_rr::rr_pack_kernel<1>, dim3(blocks), dim3(threads), 0, st, P, (unsigned char*)section);
     else hipLaunchKernelGGL(plnerf_rr::rr_pack_kernel<2>, dim3(blocks), dim3(threads), 0, st, P, (unsigned char*)section);
     PLNERF_CHECK_LAUNCH();

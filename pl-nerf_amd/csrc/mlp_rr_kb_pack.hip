@@ -12,11 +12,11 @@ int rr_launch_bf16_2_train(const RrFwdArgs& a, hipStream_t st);
 int rr_launch_bf16_2_infer_emb(const RrFwdArgs& a, hipStream_t st);
 int rr_launch_bf16_2_train_emb(const RrFwdArgs& a, hipStream_t st);
 
-int rr_pack_bf16(const float* const* params, int xyz_ch, int dir_ch, int ns, void* section, hipStream_t st) {
+int rr_pack_bf16(const float* const* params, int xyz_ch, int dir_ch, int ns, const float* cb, void* section, hipStream_t st) {
     ParamPtrs P;
-    P.xyz_ch = xyz_ch; P.dir_ch = dir_ch;
+    P.xyz_ch = xyz_ch; P.dir_ch = dir_ch; P.cb = cb;
     for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i) P.p[i] = params[i];
-    const int groups = lay::FWD_FLOATS / 8, threads = 256, blocks = (groups + threads - 1) / threads;
+    const int groups = lay::FWDC_FLOATS / 8, threads = 256, blocks = (groups + threads - 1) / threads;
     if (ns == 1) hipLaunchKernelGGL(plnerf_rr_bf16::rr_pack_kernel<1>, dim3(blocks), dim3(threads), 0, st, P, (unsigned char*)section);
     else hipLaunchKernelGGL(plnerf_rr_bf16::rr_pack_kernel<2>, dim3(blocks), dim3(threads), 0, st, P, (unsigned char*)section);
     PLNERF_CHECK_LAUNCH();

@@ -23,12 +23,13 @@
 using namespace plnerf;
 using namespace plnerf::lay;
 
-// row ranges of the 256-wide weight-gradient jobs.  Half planes: 9 tiles x 28 = 252 workgroups, ONE round on the
+// row ranges of the 256-wide weight-gradient jobs.  Half planes: 8 tiles (L1..L7 and the composed view layer, mlp_layout.h;
+// 9 tiles x 28 = 252 until round 5, when feature_linear had a job of its own) x 32 = 256 workgroups, ONE round on the
 // 256 CUs (each keeps its 256 x 256 partial in registers for twice as many rows as with 56, and the partial sums
 // written and re-read by the reduction halve: 134 -> 67 MB per network; step -1.5 %).  The fp32 kernel (17 tiles of
 // 256 threads, several workgroups per CU) wants the 56 it was tuned with (28: +8 % step).
 #ifndef PLNERF_WG_SPLITS
-#define PLNERF_WG_SPLITS 28
+#define PLNERF_WG_SPLITS 32
 #endif
 #ifndef PLNERF_WG_SPLITS_F32
 #define PLNERF_WG_SPLITS_F32 56
@@ -700,6 +701,9 @@ struct ReduceArgs {
     float* status_out;      // nullptr, or where this launch leaves (float)(*status != 0): the tail of the caller's flat gradient
     int enc_tiled;          // the encoding planes were tiled (mlp_layout.h): column c of the thin jobs' results = channel sv_enc_channel(c);
                             // the view layer's direction columns then come from the MAIN launch's row ranges (its view job)
+    float* gred;            // 16-bit modes (composed view layer, mlp_layout.h): the view job's 128 x 256 result is G = dz_view^T h7 and goes
+                            // here with s = the job's bias sums behind it (compose_grads turns them into the factors' gradients);
+                            // nullptr: fp32 mode, the reference's two layers
     GradPtrs G;
 };
 
@@ -731,6 +735,8 @@ __global__ void wgrad_reduce_kernel(ReduceArgs2 p) {
     // the thin jobs (encoding columns of L0 / L5, direction columns of the view layer, and L0's bias, which
     // rides on them) are launched over their own number of row ranges
     const bool thin = (idx >= PART_PE0 && idx < (a.enc_tiled ? PART_VDIR : PART_BIAS)) || (idx >= PART_BIAS && idx < PART_BIAS + W);
+    // composed view layer: the feature layer's job and bias slots are not used
+    if (a.gred && ((idx >= PART_MAIN + 7 * W * W && idx < PART_VMAIN) || (idx >= PART_BIAS + 8 * W && idx < PART_BIAS + 9 * W))) return;
     const int ns = thin ? a.splits_thin : a.splits;
     float s = 0.0f;
     {   // a batch's loads all in flight before its first add (one dependent load per add held the kernel at 33 us;
@@ -763,7 +769,8 @@ __global__ void wgrad_reduce_kernel(ReduceArgs2 p) {
         else a.G.p[P_WF][o * W + i] = s;
     } else if (idx < PART_PE0) {
         const int r = idx - PART_VMAIN, o = r >> 8, i = r & 255;
-        a.G.p[P_WV][o * (W + a.G.dir_ch) + i] = s;
+        if (a.gred) a.gred[r] = s;      // G[o][i]
+        else a.G.p[P_WV][o * (W + a.G.dir_ch) + i] = s;
     } else if (idx < PART_PE5) {
         const int r = idx - PART_PE0, o = r >> 6, i = a.enc_tiled ? sv_enc_channel(r & 63, false) : (r & 63);
         if (i < a.G.xyz_ch) a.G.p[0][o * a.G.xyz_ch + i] = s;
@@ -777,7 +784,10 @@ __global__ void wgrad_reduce_kernel(ReduceArgs2 p) {
         const int r = idx - PART_BIAS;
         if (r < 8 * W) a.G.p[2 * (r >> 8) + 1][r & 255] = s;
         else if (r < 9 * W) a.G.p[P_BF][r - 8 * W] = s;
-        else a.G.p[P_BV][r - 9 * W] = s;
+        else {
+            a.G.p[P_BV][r - 9 * W] = s;
+            if (a.gred) a.gred[HV * W + (r - 9 * W)] = s;
+        }
     }
 }
 
@@ -920,15 +930,17 @@ int plan_job(const plnerf::impl::WgradJob& jb, bool h16, int cap_main, int cap_t
     auto splane = [&](int p) { return (const void*)(sv + (size_t)p * W * NS_ * es); };
     const size_t ND = h16 ? dz_rows(N) : N;        // row stride of the dz planes (half: padded to the dgrad kernel's tiles)
     auto dplane = [&](int p) { return (const void*)(dz + (size_t)p * W * ND * es); };
-    const void* pe_plane = sv + (size_t)SV_PE_OFF * NS_ * es;
-    const void* dpe_plane = sv + (size_t)SV_DPE_OFF * NS_ * es;
-    const void* dzv_plane = dz + (size_t)DZ_V_OFF * ND * es;
+    // (half state: the composed network's planes -- no feature plane, no dz_feature plane; mlp_layout.h)
+    const void* pe_plane = sv + (size_t)(h16 ? SVC_PE_OFF : SV_PE_OFF) * NS_ * es;
+    const void* dpe_plane = sv + (size_t)(h16 ? SVC_DPE_OFF : SV_DPE_OFF) * NS_ * es;
+    const void* dzv_plane = dz + (size_t)(h16 ? DZC_V_OFF : DZ_V_OFF) * ND * es;
     {
-        // main: 256 x 256 layer jobs + the view layer's feature columns
+        // main: 256 x 256 layer jobs + the view layer's feature columns (half: G = dz_view^T h7 of the composed view layer, and no
+        // feature job)
         WgradArgs a{};
         const int layer_of_job[8] = {1, 2, 3, 4, 5, 6, 7, -1};
         int nt = 0;
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < (h16 ? 7 : 8); ++j) {
             WJob& jw = a.jobs[j];
             if (j < 7) {
                 const int l = layer_of_job[j];
@@ -947,7 +959,7 @@ int plan_job(const plnerf::impl::WgradJob& jb, bool h16, int cap_main, int cap_t
             if (!h16) { a.tile_job[nt] = j; a.tile_o0[nt++] = 128; }   // f32 kernel: 128-row o tiles
         }
         WJob& jv = a.jobs[8];
-        jv.A = dzv_plane; jv.lda = HV; jv.B = splane(SV_FEAT); jv.ldb = W; jv.O = HV; jv.I = W;
+        jv.A = dzv_plane; jv.lda = HV; jv.B = splane(h16 ? 7 : SV_FEAT); jv.ldb = W; jv.O = HV; jv.I = W;
         jv.part_off = PART_VMAIN; jv.bias_off = PART_BIAS + 9 * W; jv.b_tiled = tiled;
         if (tiled) { jv.B2 = dpe_plane; jv.part2_off = PART_VDIR; }      // (the direction columns on the job's idle waves)
         a.tile_job[nt] = 8; a.tile_o0[nt++] = 0;
@@ -978,6 +990,8 @@ int plan_job(const plnerf::impl::WgradJob& jb, bool h16, int cap_main, int cap_t
         a.gmax = h16 ? jb.gmax : nullptr;
         a.status = jb.status; a.status_out = jb.status_out;
         a.enc_tiled = tiled;
+        a.gred = h16 ? jb.gred : nullptr;
+        if (h16 && (!jb.gred || !jb.cb)) return PLNERF_EINVAL;
         a.G.xyz_ch = jb.xyz_ch; a.G.dir_ch = jb.dir_ch;
         for (int i = 0; i < PLNERF_N_PARAM_TENSORS; ++i) {
             if (!jb.grads[i]) return PLNERF_EINVAL;
@@ -1075,8 +1089,8 @@ int wgrad_h16_multi(int n, const WgradJob* jobs, hipStream_t st) {
         for (int j = 0; j < 2; ++j) {
             const int q = j < n ? j : 0;
             const size_t NS_ = sv_rows((size_t)jobs[q].n_rows);
-            h.n[j] = HeadArgs<_Float16>{jobs[q].g_raw, (const _Float16*)P[q].main_args.jobs[7].B,
-                                        (const _Float16*)((const unsigned char*)jobs[q].saved + (size_t)SV_HV_OFF * NS_ * sizeof(_Float16)),
+            h.n[j] = HeadArgs<_Float16>{jobs[q].g_raw, (const _Float16*)P[q].main_args.jobs[8].B,      // (h7: the composed view job's B plane)
+                                        (const _Float16*)((const unsigned char*)jobs[q].saved + (size_t)SVC_HV_OFF * NS_ * sizeof(_Float16)),
                                         jobs[q].n_rows, P[q].rows_per_head_wg, P[q].head_part,
                                         jobs[q].saved_layout == SV_LAYOUT_TILED};
         }
@@ -1084,7 +1098,12 @@ int wgrad_h16_multi(int n, const WgradJob* jobs, hipStream_t st) {
         hipLaunchKernelGGL(wgrad_head_kernel<_Float16>, dim3(P[0].n_head + (n == 2 ? P[1].n_head : 0)), dim3(256), 0, st, h);
         PLNERF_CHECK_LAUNCH();
     }
-    return launch_reduce(P, n, st);
+    const int rc = launch_reduce(P, n, st);
+    if (rc) return rc;
+    // the composed view layer's factors: dW_f, db_f and the feature columns of dW_v from the reduced G and s
+    ComposeGradJob cj[MAX_BWD_JOBS];
+    for (int j = 0; j < n; ++j) cj[j] = ComposeGradJob{jobs[j].cb, jobs[j].gred, jobs[j].grads, jobs[j].dir_ch};
+    return compose_grads(n, cj, st);
 }
 
 int input_grad(const float* const* params, int n_rows, const void* dzv, const unsigned* gmax, bool h16, int xyz_ch,
@@ -1095,7 +1114,7 @@ int input_grad(const float* const* params, int n_rows, const void* dzv, const un
     const unsigned char* dz = (const unsigned char*)dzv;
     InGradArgs a{};
     a.w0 = params[0]; a.w5 = params[10]; a.wv = params[P_WV];
-    a.dz0 = dz; a.dz5 = dz + (size_t)5 * W * ND * es; a.dzv = dz + (size_t)DZ_V_OFF * ND * es;
+    a.dz0 = dz; a.dz5 = dz + (size_t)5 * W * ND * es; a.dzv = dz + (size_t)(h16 ? DZC_V_OFF : DZ_V_OFF) * ND * es;
     a.gmax = h16 ? gmax : nullptr;
     a.xyz_ch = xyz_ch; a.dir_ch = dir_ch; a.n_rows = n_rows; a.g_emb = g_emb;
     const size_t lds = ((size_t)2 * W * PE_K + (size_t)HV * DPE_K) * sizeof(float);

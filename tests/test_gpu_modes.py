@@ -729,13 +729,25 @@ def test_half_modes_flag_range_overflow_and_withhold_the_step(P):
             assert net.range_status() == 0                                   # cleared by the check
         else:
             net.check_range()
-    # weights beyond the range are caught at packing time
-    sd_w = orc.closed_form_state_dict(2, False)
-    sd_w["feature_linear.weight"][3, 5] = 1.0e5
-    net = make_net(P, sd_w, "f16x3")
-    with torch.no_grad():
-        net.query(g(pts), g(vd))
-    assert net.range_status() & _lib.RANGE_WEIGHT
+    # weights beyond the range are caught at packing time.  What is packed for the view layer is W_c = W_vf W_f (the
+    # composed layer of the 16-bit modes, mlp_layout.h): feature_linear's own entries never become halves, so a large one
+    # is flagged exactly when it takes an entry of W_c out of the range -- and computed exactly when it does not.
+    def weight_flag(key, value):
+        sd_w = orc.closed_form_state_dict(2, False)
+        sd_w[key][3, 5] = value
+        net = make_net(P, sd_w, "f16x3")
+        with torch.no_grad():
+            raw = net.query(g(pts), g(vd))
+        return net.range_status() & _lib.RANGE_WEIGHT, raw, sd_w
+    assert weight_flag("pts_linears.3.weight", 1.0e5)[0]
+    assert weight_flag("feature_linear.weight", 1.0e9)[0]
+    sd_c = orc.closed_form_state_dict(2, False)
+    wc_big = float((sd_c["views_linears.0.weight"][:, 3].abs().max() * 1.0e5))
+    assert wc_big < 6.0e4, wc_big                                             # (this entry of feature_linear stays inside W_c's range)
+    flag, raw, sd_w = weight_flag("feature_linear.weight", 1.0e5)
+    assert not flag
+    ref_w = orc.query_network(sd_w, pts, vd)
+    assert maxdiff(raw, ref_w) <= 2e-5 * (1.0 + float(ref_w.abs().max()))
     # the guarded optimizer: a step computed from a clamped forward does not reach the weights
     for prec, bit in (("f16x3", _lib.RANGE_ACTIVATION), ("bf16x3", _lib.RANGE_SAVED)):
         net = make_net(P, sd, prec)

@@ -125,14 +125,14 @@ def test_buffer_size_queries(built):
     L = _lib.lib()
     assert L.plnerf_mlp_packed_bytes(0) > 595844 * 4          # padded fwd + bwd layouts
     assert L.plnerf_mlp_saved_bytes(1000, 0) == 1000 * 2596 * 4
-    assert L.plnerf_mlp_saved_bytes(1000, 3) == 1024 * (2528 * 2 + 272)      # 16-bit modes: half planes + relu masks, rows padded to whole 256-row workgroup tiles
+    assert L.plnerf_mlp_saved_bytes(1000, 3) == 1024 * (2272 * 2 + 272)      # 16-bit modes: half planes + relu masks, rows padded to whole 256-row workgroup tiles
     assert L.plnerf_mlp_bwd_workspace_bytes(1000, 3) < L.plnerf_mlp_bwd_workspace_bytes(1000, 0)
     assert L.plnerf_mlp_bwd_workspace_bytes(1000, 0) > 1000 * 2432 * 4
     # half dz planes: rows padded to the dgrad kernel's 192-row tiles (tiled planes, mlp_layout.h; 64 rows until round 3)
     # (+ 16 B per row: the upstream gradient after the density activation's derivative, plnerf_mlp_bwd's g_eff)
     assert L.plnerf_mlp_bwd_workspace_bytes(961, 3) - 961 * 16 == L.plnerf_mlp_bwd_workspace_bytes(1152, 3) - 1152 * 16      # 6 x 192
-    assert L.plnerf_mlp_bwd_workspace_bytes(1153, 3) - L.plnerf_mlp_bwd_workspace_bytes(1152, 3) == 192 * 2432 * 2 + 16
-    assert L.plnerf_mlp_saved_bytes(1025, 3) - L.plnerf_mlp_saved_bytes(1024, 3) == 256 * (2528 * 2 + 272)
+    assert L.plnerf_mlp_bwd_workspace_bytes(1153, 3) - L.plnerf_mlp_bwd_workspace_bytes(1152, 3) == 192 * 2176 * 2 + 16
+    assert L.plnerf_mlp_saved_bytes(1025, 3) - L.plnerf_mlp_saved_bytes(1024, 3) == 256 * (2272 * 2 + 272)
     # the layout tag a caller hands back to plnerf_mlp_bwd: the split modes write tiled planes (with or without a
     # caller-embedded input); exact fp32 and the plain 16-bit modes row-major
     # the saved layout is a pure function of (precision, embedded input, forward-kernel argument): no environment
