@@ -305,7 +305,10 @@ int plnerf_image_loss(const float* rgb, const float* rgb0, const float* target, 
  * distances[h, r, p] = mask[r] * |pred_hyp[r, p] - target_h[h, r, p]|, zeroed below `threshold` (> 0); then
  * is_joint = 0 (:79-84): min over the n_hyp hypotheses per ray and point, mean over points and rays;
  * is_joint != 0 (:72-77): mean over the rays first, min over the hypotheses per POINT column (the hypothesis is chosen
- * per image), mean over the points.
+ * per image), mean over the points.  joint_choice (is_joint only; NULL = choose from this call's rays): [n_points] hypothesis
+ * indices chosen by the caller -- a batch SHARDED over ranks must choose per global batch, as the reference does on its gathered
+ * output (run_nerf_sample_based_depth.py:564, 585: nn.DataParallel): plnerf_depth_joint_sums on every shard, the sums added
+ * over the shards, argmin over the hypotheses of (float)(sum / global rays) per column, first minimum on ties (ABI 600).
  * pred_hyp [R, n_points]; target_h [n_hyp, R, target_points] with target_points = 1 or n_points; mask [R] or NULL.
  * loss5 [5] = {total, image (fine), image (coarse), space carving (unweighted), psnr of the fine image term};
  * g_rgb, g_rgb0 [R, 3], g_hyp [R, n_points] = d total / d (rgb, rgb0, pred_hyp).  rgb0 and pred_hyp may be NULL
@@ -315,8 +318,14 @@ int plnerf_image_loss(const float* rgb, const float* rgb0, const float* target, 
 #define PLNERF_DEPTH_LOSS_WORKSPACE_BYTES 4096
 int plnerf_depth_loss(const float* rgb, const float* rgb0, const float* target, const float* pred_hyp,
                       const float* target_h, const float* mask, int R, int n_points, int n_hyp, int target_points,
-                      int is_joint, float space_carving_weight, float threshold, float* loss5, float* g_rgb,
-                      float* g_rgb0, float* g_hyp, void* workspace, plnerf_stream_t stream);
+                      int is_joint, const int* joint_choice, float space_carving_weight, float threshold, float* loss5,
+                      float* g_rgb, float* g_rgb0, float* g_hyp, void* workspace, plnerf_stream_t stream);
+
+/* The is_joint branch's column sums over THIS call's rays (model/run_nerf_helpers.py:72-75 before the mean's division):
+ * sums [n_hyp, n_points] (fp64) = sum over r of mask[r] * |pred_hyp[r, p] - target_h[h, r, p]| (zeroed below threshold).
+ * Fixed summation order: deterministic.  For plnerf_depth_loss's joint_choice (ABI 600). */
+int plnerf_depth_joint_sums(const float* pred_hyp, const float* target_h, const float* mask, int R, int n_points,
+                            int n_hyp, int target_points, float threshold, double* sums, plnerf_stream_t stream);
 
 /* run_network's input assembly for a caller-side encoding (depth_supervised_exps/run_nerf_sample_based_depth.py:52-68
  * with the Embedder of depth_supervised_exps/model/run_nerf_helpers.py:100-130; input_scale = 1 gives the NVS

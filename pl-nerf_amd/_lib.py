@@ -61,7 +61,8 @@ SIGNATURES = {
     "plnerf_ndc_rays": (c_i, [c_i, c_i, ctypes.c_double, ctypes.c_double, c_f, c_f, c_i, c_f, c_f, c_s]),
     "plnerf_coarse_samples": (c_i, [c_f] * 6 + [ctypes.c_uint64, ctypes.c_uint32] + [c_i] * 5 + [c_f] * 2 + [c_s]),
     "plnerf_image_loss": (c_i, [c_f] * 3 + [c_i] + [c_f] * 5 + [c_s]),
-    "plnerf_depth_loss": (c_i, [c_f] * 6 + [c_i] * 5 + [ctypes.c_float] * 2 + [c_f] * 5 + [c_s]),
+    "plnerf_depth_loss": (c_i, [c_f] * 6 + [c_i] * 5 + [c_f] + [ctypes.c_float] * 2 + [c_f] * 5 + [c_s]),
+    "plnerf_depth_joint_sums": (c_i, [c_f] * 3 + [c_i] * 4 + [ctypes.c_float, c_f, c_s]),
     "plnerf_embed_rows": (c_i, [c_f] * 3 + [c_i] * 5 + [ctypes.c_float, ctypes.POINTER(ctypes.c_float), ctypes.c_float,
                                 c_f, c_s]),
     "plnerf_mlp_packed_bytes": (ctypes.c_size_t, [c_i]),
@@ -96,15 +97,20 @@ def lib():
                 "`make -C pl-nerf_amd/csrc` (hipcc --offload-arch=gfx950). "
                 "plnerf_amd has no CPU fallback.")
         handle = ctypes.CDLL(LIB_PATH)
+        tools_build = os.environ.get("PLNERF_ALLOW_TOOLS_BUILD") == "1"
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(handle, name)   # AttributeError here = header/library mismatch
+            fn = getattr(handle, name, None)
+            if fn is None:
+                if tools_build:      # (tools/ab.sh against a library of an earlier commit: entry points it lacks stay unbound)
+                    continue
+                raise AttributeError(f"{LIB_PATH} does not export {name}: header / library mismatch")
             fn.restype = res
             fn.argtypes = args
         # The argument lists above are positional: a library of another ABI (a stale build, a variant linked from old
         # objects) would be called with shifted pointers -- compare before the first call.  tools/ A/B legs
         # against an older library whose signatures are known to match set PLNERF_ALLOW_TOOLS_BUILD=1.
         version = handle.plnerf_version()
-        if version != ABI_VERSION and os.environ.get("PLNERF_ALLOW_TOOLS_BUILD") != "1":
+        if version != ABI_VERSION and not tools_build:
             raise ImportError(
                 f"{LIB_PATH} reports plnerf_version() = {version}, this binding is written against {ABI_VERSION} "
                 "(include/plnerf_hip.h): rebuild with `make -C pl-nerf_amd/csrc clean all`.")

@@ -28,41 +28,61 @@ struct ComposePackArgs {
     float* cb;
 };
 
-// blocks [0, 64): two rows o of W_c each, thread = column k; block 64: b_c; blocks 65..: the copies
+// blocks [0, 64): two rows o of W_c each -- thread = (quarter q of the j range, column k), the quarters added in a fixed
+// order through LDS (one thread walking all 256 j with its loads eight deep measured 13.5 us per launch: latency of the
+// 256 dependent trips, not arithmetic); block 64: b_c; blocks 65..: the copies
 constexpr int CP_ROWS = 2;
+constexpr int CP_THREADS = 1024, CP_Q = CP_THREADS / W, CP_JQ = W / CP_Q;
 constexpr int CP_WC_BLOCKS = HV / CP_ROWS;
 constexpr int CP_COPY_FLOATS = HV * W + W * W + W;
-constexpr int CP_COPY_BLOCKS = (CP_COPY_FLOATS / 4 + 255) / 256;
+constexpr int CP_COPY_BLOCKS = (CP_COPY_FLOATS / 4 + CP_THREADS - 1) / CP_THREADS;
 static_assert(CP_COPY_FLOATS % 4 == 0, "copies in float4");
 
-__global__ __launch_bounds__(256) void compose_pack_kernel(ComposePackArgs a) {
+__global__ __launch_bounds__(CP_THREADS) void compose_pack_kernel(ComposePackArgs a) {
     const int tid = threadIdx.x, b = blockIdx.x;
     const int ldv = W + a.dir_ch;
     if (b < CP_WC_BLOCKS) {
         __shared__ float rows[CP_ROWS][W];
-        const int o0 = b * CP_ROWS;
-#pragma unroll
-        for (int r = 0; r < CP_ROWS; ++r) rows[r][tid] = a.wv[(size_t)(o0 + r) * ldv + tid];
+        __shared__ double part[CP_Q][CP_ROWS][W];
+        const int o0 = b * CP_ROWS, q = tid >> 8, k = tid & (W - 1);
+        if (tid < CP_ROWS * W) rows[tid >> 8][k] = a.wv[(size_t)(o0 + (tid >> 8)) * ldv + k];
         __syncthreads();
         double acc[CP_ROWS];
 #pragma unroll
         for (int r = 0; r < CP_ROWS; ++r) acc[r] = 0.0;
-#pragma unroll 8
-        for (int j = 0; j < W; ++j) {
-            const double w = (double)a.wf[(size_t)j * W + tid];
 #pragma unroll
-            for (int r = 0; r < CP_ROWS; ++r) acc[r] = fma((double)rows[r][j], w, acc[r]);
+        for (int j0 = 0; j0 < CP_JQ; j0 += 32) {
+            float w[32];
+#pragma unroll
+            for (int t = 0; t < 32; ++t) w[t] = a.wf[(size_t)(q * CP_JQ + j0 + t) * W + k];      // (32 loads in flight)
+#pragma unroll
+            for (int t = 0; t < 32; ++t)
+#pragma unroll
+                for (int r = 0; r < CP_ROWS; ++r) acc[r] = fma((double)rows[r][q * CP_JQ + j0 + t], (double)w[t], acc[r]);
         }
 #pragma unroll
-        for (int r = 0; r < CP_ROWS; ++r) a.cb[CB_WC + (o0 + r) * W + tid] = (float)acc[r];
+        for (int r = 0; r < CP_ROWS; ++r) part[q][r][k] = acc[r];
+        __syncthreads();
+        if (tid < CP_ROWS * W) {
+            const int r = tid >> 8;
+            double s = part[0][r][k];
+#pragma unroll
+            for (int qq = 1; qq < CP_Q; ++qq) s += part[qq][r][k];
+            a.cb[CB_WC + (o0 + r) * W + k] = (float)s;
+        }
     } else if (b == CP_WC_BLOCKS) {
-        if (tid < HV) {
+        // b_c[o] = W_vf[o, :] . b_f + b_v[o]: a wavefront per output (coalesced along j), 16 waves x 8 outputs
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int o = wave; o < HV; o += CP_THREADS / 64) {
             double acc = 0.0;
-            for (int j = 0; j < W; ++j) acc = fma((double)a.wv[(size_t)tid * ldv + j], (double)a.bf[j], acc);
-            a.cb[CB_BC + tid] = (float)(acc + (double)a.bv[tid]);
+#pragma unroll
+            for (int t = 0; t < W / 64; ++t)
+                acc = fma((double)a.wv[(size_t)o * ldv + lane + 64 * t], (double)a.bf[lane + 64 * t], acc);
+            acc = wave_sum(acc);
+            if (lane == 0) a.cb[CB_BC + o] = (float)(acc + (double)a.bv[o]);
         }
     } else {
-        const int q = (b - CP_WC_BLOCKS - 1) * 256 + tid;      // float4 index into [W_vf | W_f | b_f]
+        const int q = (b - CP_WC_BLOCKS - 1) * CP_THREADS + tid;      // float4 index into [W_vf | W_f | b_f]
         if (q >= CP_COPY_FLOATS / 4) return;
         const int e = 4 * q;
         float4 v;
@@ -164,7 +184,7 @@ namespace impl {
 
 int compose_pack(const float* const* params, int dir_ch, float* cb, hipStream_t st) {
     const ComposePackArgs a{params[P_WV], params[P_BV], params[P_WF], params[P_BF], dir_ch, cb};
-    hipLaunchKernelGGL(compose_pack_kernel, dim3(CP_WC_BLOCKS + 1 + CP_COPY_BLOCKS), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(compose_pack_kernel, dim3(CP_WC_BLOCKS + 1 + CP_COPY_BLOCKS), dim3(CP_THREADS), 0, st, a);
     PLNERF_CHECK_LAUNCH();
     return PLNERF_OK;
 }

@@ -313,6 +313,8 @@ struct DepthLossArgs {
     const float* mask;         // [R] or nullptr
     int R, P, H, PT;
     int is_joint;              // the hypothesis is chosen per IMAGE (per point column), not per ray (model/run_nerf_helpers.py:72-77)
+    const int* joint_choice;   // is_joint: nullptr = choose here, from this call's rays; else [P] hypothesis per column, chosen by the
+                               // caller from the column sums of EVERY shard of the batch (plnerf_depth_joint_sums + one all-reduce)
     float weight, threshold;
     float* loss5;              // {total, img, img0, space carving (unweighted), psnr of img}
     float* g_rgb; float* g_rgb0; float* g_hyp;
@@ -352,7 +354,8 @@ __global__ __launch_bounds__(DL_THREADS) void depth_loss_kernel(const DepthLossA
         // so the choice needs no second launch and the result is deterministic; its partial is the chosen column sum.
         const float gs = a.weight / ((float)a.R * (float)a.P);
         for (int p = b; p < a.P; p += DL_BLOCKS) {
-            for (int h = 0; h < a.H; ++h) {
+            const int h_lo = a.joint_choice ? a.joint_choice[p] : 0, h_hi = a.joint_choice ? h_lo + 1 : a.H;
+            for (int h = h_lo; h < h_hi; ++h) {
                 double sum = 0.0;
                 for (int r = tid; r < a.R; r += DL_THREADS) {
                     const float m = a.mask ? a.mask[r] : 1.0f;
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(DL_THREADS) void depth_loss_kernel(const DepthLossA
                     for (int w = 0; w < DL_THREADS / 64; ++w) tot += jred[w];
                     // (compared as the reference compares them: fp32 means; first minimum on ties, like torch.min)
                     const float mean = (float)(tot / (double)a.R);
-                    if (h == 0 || mean < (float)(jbest / (double)a.R)) { jbest = tot; jarg = h; }
+                    if (h == h_lo || mean < (float)(jbest / (double)a.R)) { jbest = tot; jarg = h; }
                 }
                 __syncthreads();
             }
@@ -615,16 +618,58 @@ extern "C" int plnerf_image_loss(const float* rgb, const float* rgb0, const floa
     return PLNERF_OK;
 }
 
+// ---- is_joint over a sharded batch: the column sums sum[h, p] = sum over this call's rays of distances[h, r, p] (fp64, fixed
+// order), which the caller adds over the shards before choosing the hypothesis of each column ----
+struct JointSumsArgs {
+    const float* hyp; const float* target_h; const float* mask;
+    int R, P, H, PT;
+    float threshold;
+    double* sums;      // [H, P]
+};
+__global__ __launch_bounds__(DL_THREADS) void depth_joint_sums_kernel(const JointSumsArgs a) {
+    __shared__ double jred[DL_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = blockIdx.x % a.P, h = blockIdx.x / a.P;
+    double sum = 0.0;
+    for (int r = tid; r < a.R; r += DL_THREADS) {      // (the arithmetic of depth_loss_kernel's is_joint branch)
+        const float m = a.mask ? a.mask[r] : 1.0f;
+        const float t = a.target_h[((size_t)h * a.R + r) * a.PT + (a.PT == 1 ? 0 : p)];
+        float d = fabsf(a.hyp[(size_t)r * a.P + p] - t) * m;
+        if (a.threshold > 0.0f && d < a.threshold) d = 0.0f;
+        sum += (double)d;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) jred[wave] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < DL_THREADS / 64; ++w) tot += jred[w];
+        a.sums[(size_t)h * a.P + p] = tot;
+    }
+}
+
+extern "C" int plnerf_depth_joint_sums(const float* pred_hyp, const float* target_h, const float* mask, int R, int n_points,
+                                       int n_hyp, int target_points, float threshold, double* sums, plnerf_stream_t stream) {
+    if (R < 1 || !pred_hyp || !target_h || !sums || n_points < 1 || n_hyp < 1 ||
+        (target_points != 1 && target_points != n_points))
+        return PLNERF_EINVAL;
+    JointSumsArgs a{pred_hyp, target_h, mask, R, n_points, n_hyp, target_points, threshold, sums};
+    hipLaunchKernelGGL(depth_joint_sums_kernel, dim3(n_points * n_hyp), dim3(DL_THREADS), 0, (hipStream_t)stream, a);
+    PLNERF_CHECK_LAUNCH();
+    return PLNERF_OK;
+}
+
 extern "C" int plnerf_depth_loss(const float* rgb, const float* rgb0, const float* target, const float* pred_hyp,
                                  const float* target_h, const float* mask, int R, int n_points, int n_hyp,
-                                 int target_points, int is_joint, float space_carving_weight, float threshold, float* loss5,
+                                 int target_points, int is_joint, const int* joint_choice, float space_carving_weight,
+                                 float threshold, float* loss5,
                                  float* g_rgb, float* g_rgb0, float* g_hyp, void* workspace, plnerf_stream_t stream) {
     static_assert(DL_BLOCKS * 3 * sizeof(double) + sizeof(unsigned) <= PLNERF_DEPTH_LOSS_WORKSPACE_BYTES, "workspace");
     if (R < 1 || !rgb || !target || !loss5 || !g_rgb || (rgb0 && !g_rgb0) || !workspace) return PLNERF_EINVAL;
     if (pred_hyp && (!target_h || !g_hyp || n_points < 1 || n_hyp < 1 || (target_points != 1 && target_points != n_points)))
         return PLNERF_EINVAL;
     DepthLossArgs a{rgb, rgb0, target, pred_hyp, target_h, mask, R, n_points, n_hyp, target_points, is_joint ? 1 : 0,
-                    space_carving_weight, threshold, loss5, g_rgb, g_rgb0, g_hyp, (double*)workspace,
+                    is_joint ? joint_choice : nullptr, space_carving_weight, threshold, loss5, g_rgb, g_rgb0, g_hyp, (double*)workspace,
                     (unsigned*)((double*)workspace + DL_BLOCKS * 3)};
     hipLaunchKernelGGL(depth_loss_kernel, dim3(DL_BLOCKS), dim3(DL_THREADS), 0, (hipStream_t)stream, a);
     PLNERF_CHECK_LAUNCH();

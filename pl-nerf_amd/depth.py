@@ -586,7 +586,8 @@ class DepthTrainStep:
             loss5, g_rgb, g_rgb0, g_hyp = Fn.depth_loss_and_grads(
                 rgb, rgb0, target_s, hyp, target_h if carve else None, getattr(a, "space_carving_weight", 0.),
                 threshold=getattr(a, "space_carving_threshold", 0.0), mask=space_carving_mask if carve else None,
-                is_joint=getattr(a, "is_joint", False))
+                is_joint=getattr(a, "is_joint", False), sharded=self.bucket is not None,
+                group=self.bucket.group if self.bucket is not None else None)
             loss, img_loss, sc = loss5[0], loss5[1], loss5[3]
             roots = [(rgb, g_rgb)] + ([(rgb0, g_rgb0)] if rgb0 is not None else []) + ([(hyp, g_hyp)] if carve else [])
             from .train import backward_merged, merged_backward_ok
@@ -599,6 +600,11 @@ class DepthTrainStep:
             loss = img_loss
             sc = torch.zeros((), device=ray_batch.device)
             if carve:
+                if getattr(a, "is_joint", False) and self.bucket is not None:
+                    # (is_joint chooses the hypothesis from the mean over the WHOLE batch: a rank's shard alone would choose
+                    # its own -- the fused path adds the shards' column sums first, functional.joint_choice)
+                    raise NotImplementedError("plnerf_amd: is_joint=True under data parallelism needs the fused loss "
+                                              "(CUDA tensors, rgb [R, 3]); this call took the torch expressions")
                 sc = compute_space_carving_loss(out["pred_hyp"], target_h, is_joint=getattr(a, "is_joint", False),
                                                 norm_p=getattr(a, "norm_p", 2),
                                                 threshold=getattr(a, "space_carving_threshold", 0.0),

@@ -855,10 +855,35 @@ def embed_rows(pts, viewdirs, cam, n_freqs_xyz, n_freqs_dir, input_scale=1.0, bb
     return out
 
 
-def depth_loss_and_grads(rgb, rgb0, target, pred_hyp, target_h, weight, threshold=0.0, mask=None, is_joint=False):
+def joint_choice(pred_hyp, target_h, mask, threshold=0.0, group=None):
+    """The is_joint hypothesis per point column for a batch sharded over `group`: [n_points] int32.  Column sums of this
+    shard (plnerf_depth_joint_sums), ONE all-reduce (SUM, fp64 [n_hyp, n_points]), then the reference's comparison: fp32
+    means over the global rays, first minimum on ties (torch.min).  Identical on every rank."""
+    hyp_c, th_c = _f32c(pred_hyp), _f32c(target_h)
+    R, P, H, PT = hyp_c.shape[0], hyp_c.shape[1], th_c.shape[0], th_c.shape[-1]
+    sums = torch.empty(H, P, device=hyp_c.device, dtype=torch.float64)
+    L.check(L.lib().plnerf_depth_joint_sums(L.dptr(hyp_c, "pred_hyp"), L.dptr(th_c, "target_h"), L.dptr(mask, "mask"), R, P, H,
+                                            PT, float(threshold), L.dptr(sums, "sums", torch.float64), L.stream()),
+            "plnerf_depth_joint_sums")
+    rays = torch.tensor([float(R)], device=hyp_c.device, dtype=torch.float64)
+    if torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
+        both = torch.cat([sums.reshape(-1), rays])
+        torch.distributed.all_reduce(both, op=torch.distributed.ReduceOp.SUM, group=group)
+        sums, rays = both[:-1].reshape(H, P), both[-1:]
+    return (sums / rays).float().argmin(0).to(torch.int32).contiguous()
+
+
+def depth_loss_and_grads(rgb, rgb0, target, pred_hyp, target_h, weight, threshold=0.0, mask=None, is_joint=False,
+                         group=None, sharded=False):
     """plnerf_depth_loss: the depth-supervised loop's loss and its three gradients in one launch (is_joint: the
     hypothesis is chosen per image -- per point column -- instead of per ray, model/run_nerf_helpers.py:72-77).
-    Returns (loss5 = [total, img, img0, space carving, psnr], g_rgb, g_rgb0, g_hyp); rgb0 / pred_hyp may be None."""
+    Returns (loss5 = [total, img, img0, space carving, psnr], g_rgb, g_rgb0, g_hyp); rgb0 / pred_hyp may be None.
+
+    sharded (is_joint only): these rays are one rank's shard of a global batch.  The reference chooses the hypothesis
+    from the mean over ALL rays of the batch (nn.DataParallel gathers the outputs before the loss,
+    run_nerf_sample_based_depth.py:564, 585), so the shards' column sums (plnerf_depth_joint_sums, fp64 [n_hyp, n_points],
+    a few KB) are added over `group` before the minimum is taken -- every rank then differentiates the same hypotheses,
+    and the ranks' averaged loss is the one-rank loss of the global batch."""
     rgb_c, t_c = _f32c(rgb), _f32c(target)
     rgb0_c = None if rgb0 is None else _f32c(rgb0)
     _expect(rgb_c.shape == t_c.shape and rgb_c.dim() == 2 and rgb_c.shape[1] == 3, "rgb / target must be [R, 3]")
@@ -877,9 +902,13 @@ def depth_loss_and_grads(rgb, rgb0, target, pred_hyp, target_h, weight, threshol
     g1 = torch.empty_like(rgb_c)
     g0 = None if rgb0_c is None else torch.empty_like(rgb_c)
     ws = _loss_workspace(rgb_c.device, L.DEPTH_LOSS_WORKSPACE_BYTES, "depth")
+    choice = None
+    if is_joint and sharded and pred_hyp is not None:
+        choice = joint_choice(hyp_c, th_c, mask_c, threshold, group)
     L.check(L.lib().plnerf_depth_loss(L.dptr(rgb_c, "rgb"), L.dptr(rgb0_c, "rgb0"), L.dptr(t_c, "target"),
                                       L.dptr(hyp_c, "pred_hyp"), L.dptr(th_c, "target_h"), L.dptr(mask_c, "mask"), R, P, H,
-                                      PT, int(bool(is_joint)), float(weight), float(threshold), L.dptr(loss5), L.dptr(g1),
+                                      PT, int(bool(is_joint)), L.dptr(choice, "joint_choice", torch.int32), float(weight),
+                                      float(threshold), L.dptr(loss5), L.dptr(g1),
                                       L.dptr(g0),
                                       L.dptr(g_h), L.dptr(ws, "workspace", torch.float64), L.stream()), "plnerf_depth_loss")
     return loss5, g1, g0, g_h

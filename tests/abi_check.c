@@ -31,7 +31,8 @@ int main(void) {
     int (*p_ndc_rays)(int, int, double, double, const float*, const float*, int, float*, float*, plnerf_stream_t) = plnerf_ndc_rays;
     int (*p_coarse_samples)(const float*, const float*, const float*, const float*, const float*, const float*, uint64_t, uint32_t, int, int, int, int, int, float*, float*, plnerf_stream_t) = plnerf_coarse_samples;
     int (*p_image_loss)(const float*, const float*, const float*, int, float*, float*, float*, const float*, void*, plnerf_stream_t) = plnerf_image_loss;
-    int (*p_depth_loss)(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, float, float, float*, float*, float*, float*, void*, plnerf_stream_t) = plnerf_depth_loss;
+    int (*p_depth_loss)(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, const int*, float, float, float*, float*, float*, float*, void*, plnerf_stream_t) = plnerf_depth_loss;
+    int (*p_depth_joint_sums)(const float*, const float*, const float*, int, int, int, int, float, double*, plnerf_stream_t) = plnerf_depth_joint_sums;
     int (*p_embed_rows)(const float*, const float*, const float*, int, int, int, int, int, float, const float*, float, float*, plnerf_stream_t) = plnerf_embed_rows;
     size_t (*p_mlp_packed_bytes)(int) = plnerf_mlp_packed_bytes;
     size_t (*p_mlp_status_offset)(int) = plnerf_mlp_status_offset;
@@ -49,7 +50,7 @@ int main(void) {
         (const void*)&p_quad_bwd, (const void*)&p_quad_bwd_rays, (const void*)&p_sample_const, (const void*)&p_sample_const_bwd, (const void*)&p_sample_pl,
         (const void*)&p_sample_pl_bwd, (const void*)&p_sample_pl_bwd_rays, (const void*)&p_stratified_z, (const void*)&p_ray_points, (const void*)&p_merge_sort,
         (const void*)&p_coarse_epilogue, (const void*)&p_fine_epilogue, (const void*)&p_uniform, (const void*)&p_normal,
-        (const void*)&p_select_rays, (const void*)&p_ndc_rays, (const void*)&p_coarse_samples, (const void*)&p_image_loss, (const void*)&p_depth_loss,
+        (const void*)&p_select_rays, (const void*)&p_ndc_rays, (const void*)&p_coarse_samples, (const void*)&p_image_loss, (const void*)&p_depth_loss, (const void*)&p_depth_joint_sums,
         (const void*)&p_embed_rows, (const void*)&p_mlp_packed_bytes, (const void*)&p_mlp_status_offset, (const void*)&p_mlp_pack_weights,
         (const void*)&p_mlp_saved_bytes, (const void*)&p_mlp_bwd_workspace_bytes, (const void*)&p_mlp_saved_layout, (const void*)&p_mlp_fwd,
         (const void*)&p_mlp_bwd, (const void*)&p_mlp_bwd_multi, (const void*)&p_mlp_input_grad, (const void*)&p_adam_step,

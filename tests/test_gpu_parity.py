@@ -1131,6 +1131,22 @@ def test_fused_adam_matches_torch(P):
             L.check(L.lib().plnerf_adam_step(L.dptr(p), L.dptr(g(gr * step)), L.dptr(m), L.dptr(v), n, 5e-4, 0.9, 0.999,
                                              1e-8, step, 1.0, clip, None, None, None, L.stream()), "adam")
         assert_close(p, ref.detach(), atol=1e-6, rtol=1e-6, what=f"adam params (clip {clip})")
+    # data parallel: the buffer holds the SUM over `world` ranks, the launch takes 1 / world -- and clip_value bounds the
+    # AVERAGED gradient (clip_grad_value_ after the mean, as one rank stepping the global batch does), not the sum
+    world, clip = 8, 7e-4
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=5e-4, betas=(0.9, 0.999))
+    p, m, v = g(p0.clone()), g(torch.zeros(n)), g(torch.zeros(n))
+    for step in range(1, 4):
+        total = gr * step * world * 0.5          # averaged: entries on both sides of the clip value
+        ref.grad = total / world
+        assert 0.05 < float((ref.grad.abs() > clip).float().mean()) < 0.95
+        torch.nn.utils.clip_grad_value_([ref], clip)
+        opt.step()
+        L.check(L.lib().plnerf_adam_step(L.dptr(p), L.dptr(g(total)), L.dptr(m), L.dptr(v), n, 5e-4, 0.9, 0.999, 1e-8, step,
+                                         1.0 / world, clip, None, None, None, L.stream()), "adam")
+    assert_close(p, ref.detach(), atol=1e-6, rtol=1e-6, what="adam params (1 / world, then clip)")
+    assert_close(m, opt.state[ref]["exp_avg"], atol=1e-9, rtol=1e-5, what="adam first moment (1 / world, then clip)")
     # guards: either word set -> nothing changes, the launch is counted
     words = g(torch.zeros(2)).to(torch.int32)
     count = g(torch.zeros(1)).to(torch.int32)

@@ -2,7 +2,7 @@
 # Build a kernel-variant library for a same-box A/B: ONE source file recompiled with extra -D switches, linked with the tree's
 # other objects (run `make -C pl-nerf_amd/csrc` first), written to tools/_head/lib<name>.so (git-ignored; it travels with gpurun).
 #   bash tools/build_variant.sh rrPFD3 mlp_rr_k_2_train.hip "-DRR_PFD=3"
-#   gpurun -- 'bash tools/ab_libs_step.sh "rrPFD3" 3'
+#   gpurun -- 'bash tools/ab.sh "default lib:rrPFD3"'
 # (how profiles/r05_forward_knobs_ab.txt and r05_dgrad_prefetch_ab.txt were made; replaces tools/ab_define.sh, whose
 # hard-wired source list predated the split of csrc/ into per-kernel files)
 set -e

@@ -1,5 +1,5 @@
 """Shader-clock / wall-clock stamps of one workgroup of the register-resident forward kernel (a library built with
--DRR_TRACE=<block>, see tools/ab_libs.sh): cycles per tile, time per tile, effective shader clock."""
+-DRR_TRACE=<block>, see tools/ab.sh -m mlp): cycles per tile, time per tile, effective shader clock."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
