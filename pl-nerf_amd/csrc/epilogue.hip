@@ -200,11 +200,17 @@ __global__ __launch_bounds__(256) void coarse_epilogue_kernel(const EpiArgs a) {
         }
     }
     __syncthreads();
-    int rank_s[KS];
+    int rank_s[KS], rank_z[KPL];
     uint32_t x[KPL];
     if (merge) {
 #pragma unroll
         for (int r = 0; r < KS; ++r) rank_s[r] = 64 * r + lane + count_le(zkey, S, xs[r]);
+        // (the z elements' ranks read skey, which the sorted row may overwrite: all of them before the barrier)
+#pragma unroll
+        for (int r = 0; r < KPL; ++r) {
+            const int p = 64 * r + lane;
+            rank_z[r] = p < S ? p + count_lt(skey, N, zkey[p]) : -1;
+        }
     } else {
 #pragma unroll
         for (int r = 0; r < KPL; ++r) {
@@ -217,15 +223,11 @@ __global__ __launch_bounds__(256) void coarse_epilogue_kernel(const EpiArgs a) {
         bitonic_sort_regs<KPL>(x, lane);
     }
     float* zs = col;                  // NF <= 3 S + K + K + N floats from col on (col, Tr, cdf, smp are contiguous)
+    // ONE barrier for both arms (`merge` is decided per wave = per ray: a barrier inside each arm was reached at different
+    // program points by the waves of one workgroup -- the counts matched, the HIP programming model calls it undefined):
+    // every read of col / smp / tau is done, the sorted row may overwrite them
+    __syncthreads();
     if (merge) {
-        // (the z elements' ranks read skey, which the sorted row may overwrite: all of them before the barrier)
-        int rank_z[KPL];
-#pragma unroll
-        for (int r = 0; r < KPL; ++r) {
-            const int p = 64 * r + lane;
-            rank_z[r] = p < S ? p + count_lt(skey, N, zkey[p]) : -1;
-        }
-        __syncthreads();              // every read of col / smp / tau is done: the sorted row may overwrite them
 #pragma unroll
         for (int r = 0; r < KPL; ++r)
             if (rank_z[r] >= 0) zs[rank_z[r]] = zk[64 * r + lane + 1];
@@ -233,7 +235,6 @@ __global__ __launch_bounds__(256) void coarse_epilogue_kernel(const EpiArgs a) {
         for (int r = 0; r < KS; ++r)
             if (64 * r + lane < N) zs[rank_s[r]] = sort_unkey(xs[r]);
     } else {
-        __syncthreads();
 #pragma unroll
         for (int r = 0; r < KPL; ++r) {
             const int p = 64 * r + lane;

@@ -246,9 +246,9 @@ __global__ __launch_bounds__(256) void coarse_samples_kernel(const CoarseArgs a)
 // one; the caller scales).  n = 3 R elements (12,288 at N_rand 4096) over IL_BLOCKS workgroups: fp64 partial sums per
 // workgroup, the last one to finish (ticket counter in the caller's zeroed workspace, which it resets) adds them in
 // workgroup order -> deterministic.  (One workgroup walking the batch measured 14 us of serialised load latency.)
-// `coarse_in`: the loss4 of an earlier launch on the coarse image alone (its [1] = mean((rgb0 - t)^2)): the two-stream
-// step (functional.CoarseChain) computes the coarse term first, on its own stream; total = fine + that, as one launch
-// over both images computes it.
+// `coarse_in`: the loss4 of an earlier launch on the coarse image alone (its [1] = mean((rgb0 - t)^2)): a caller that starts
+// the coarse network's backward before the fine pass exists (rounds 3-4's two-stream schedules did; no caller in the package
+// since round 5) computes the coarse term first; total = fine + that, as one launch over both images computes it.
 constexpr int IL_BLOCKS = 16, IL_THREADS = 256;
 __global__ __launch_bounds__(IL_THREADS) void image_loss_kernel(const float* __restrict__ rgb, const float* __restrict__ rgb0,
                                                                  const float* __restrict__ target, const int n,

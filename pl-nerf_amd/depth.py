@@ -543,6 +543,7 @@ class DepthTrainStep:
         self.draws = Fn.DrawSource(seed=seed) if counter_rng else None
         # both networks' backward as one launch sequence, as train.TrainStep (train.backward_merged)
         self.merged_backward = os.environ.get("PLNERF_MERGED_BWD", "1") != "0"
+        self.merged_steps = 0      # steps that took it (the rest went through torch.autograd.backward)
         if distributed and torch.distributed.get_world_size() > 1:
             dp.broadcast_parameters(nets)      # replicas start from rank 0's weights (see train.TrainStep)
             dp.broadcast_optimizer_state([optimizer])
@@ -593,6 +594,7 @@ class DepthTrainStep:
             from .train import backward_merged, merged_backward_ok
             if tape is not None and rgb0 is not None and merged_backward_ok(tape, self.nets):
                 backward_merged(tape, self.nets, [r for r, _ in roots], [gr for _, gr in roots], self.bucket)
+                self.merged_steps += 1
             else:
                 torch.autograd.backward(tuple(r for r, _ in roots), tuple(gr for _, gr in roots))
         else:

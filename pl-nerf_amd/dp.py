@@ -5,10 +5,10 @@ The reference has no distributed path in run_plnerf.py (its depth variant wraps 
 in single-process nn.DataParallel, run_nerf_sample_based_depth.py:564,585); SURVEY.md
 section 8e specifies this design instead: every op on the path is per ray, the only
 cross-ray coupling is the mean in img2mse, so with equal shards the global gradient is the
-average of the per-rank gradients.  Payload: 2 networks x 595,844 fp32 = 4.77 MB, sent as ONE
-in-place all-reduce per network (2.38 MB each, latency-bound on the point-to-point xGMI links:
-few large messages, not 48 small ones), the fine network's issued while the coarse network's
-backward is still running.
+average of the per-rank gradients.  Payload: 2 networks x 595,844 fp32 = 4.77 MB: ONE in-place
+all-reduce over both networks' gradient buffers after the merged backward (they lie back to back;
+latency-bound on the point-to-point xGMI links), or -- on the autograd-order route -- one per network
+(2.38 MB each), the fine network's issued while the coarse network's backward is still running.
 """
 import os
 
@@ -65,9 +65,9 @@ class GradientBucket:
         tail means "some rank's forward left the half range" on every rank alike.  `tails()` hands those words to the
         optimizer as its guards -- no separate collective, no write-back launch.
 
-    With train.TrainStep's two streams the coarse network's exchange and the fine network's are finished
-    independently, each on its chain's stream.  Gradients in any other layout (another module, a CPU test) fall back
-    to one gathered bucket per call."""
+    train.TrainStep's merged backward (both networks' backward as one launch sequence) assigns the gradients itself and
+    calls `gradients_ready`: the two flat buffers lie back to back and go out as ONE collective.  Gradients in any other
+    layout (another module, a CPU test) fall back to one gathered bucket per call."""
 
     TAIL = 4      # floats appended to a network's flat gradient by functional.MlpFn.backward ([0] = range status)
 
@@ -200,6 +200,8 @@ class GradientBucket:
         idx = list(range(len(self.modules))) if modules is None else [self._index(m) for m in modules]
         self.collectives = 0
         if world == 1 and not (force and dist.is_initialized()):
+            for mi in idx:      # (nothing to exchange: let go of the backward's flat buffers, as the exchange below would)
+                self.modules[mi].__dict__.pop("_grad_flat", None)
             return 1.0
         for mi in idx:
             if mi not in self._works and not self._hooks:     # single rank with force=True, or overlap disabled

@@ -118,8 +118,8 @@ class QuadratureFn(torch.autograd.Function):
 
 
 # Armed (a list) by a caller that runs plnerf_quad_bwd and the MLP backward itself, back to back (train.TrainStep's merged
-# backward): every plnerf_quad_bwd then leaves its by-product and logs (g_raw.data_ptr(), the int32 tensor of maxima) here, and
-# the caller hands the matching tensors to mlp_backward_multi.  None: no by-product is asked for.  (The by-product: one
+# backward): every plnerf_quad_bwd then leaves its by-product and logs (g_raw, its version counter, the int32 tensor of maxima)
+# here, and the caller hands the matching tensors to mlp_backward_multi.  None: no by-product is asked for.  (The by-product: one
 # uint32 per workgroup of the launch = the fp32 bits of the largest |g_raw| among its rays; plnerf_mlp_bwd takes the array
 # as `g_absmax` and skips its own pass over g_raw and its memset.)
 ABSMAX_LOG = None
@@ -171,7 +171,7 @@ def _quad_backward(saved, cfg, g_rgb, g_disp, g_acc, g_w, g_depth, g_tau, g_T, g
           int(white_bkgd), int(farcolorfix), L.dptr(g_rgb), L.dptr(g_depth), L.dptr(g_acc), L.dptr(g_w),
           L.dptr(g_tau), L.dptr(g_T), L.dptr(g_raw), L.dptr(cand, "absmax_out", torch.int32), L.stream()), "plnerf_quad_bwd")
         if cand is not None:
-            ABSMAX_LOG.append((g_raw.data_ptr(), cand))
+            ABSMAX_LOG.append((g_raw, g_raw._version, cand))
     return g_raw
 
 
@@ -434,7 +434,7 @@ def _grad_buffer(ctx, dev, zero=False, block=None):
 
 def _mlp_backward_launch(ctxs, g_raws, absmax_log=None):
     """plnerf_mlp_bwd_multi over the saved state of one or two MlpFn forwards (the same precision, input widths and
-    density activation): one launch sequence for all of them.  absmax_log: [(g_raw.data_ptr(), maxima tensor)] of the
+    density activation): one launch sequence for all of them.  absmax_log: [(g_raw, version, maxima tensor)] of the
     plnerf_quad_bwd launches that produced these g_raws in THIS backward pass (ABSMAX_LOG), or None.  Returns ([the 24
     gradient views per job], [workspace per job]); with a dp.GradientBucket attached, each job's flat buffer is left on its network as `_grad_flat` until the exchange."""
     n = len(ctxs)
@@ -452,8 +452,12 @@ def _mlp_backward_launch(ctxs, g_raws, absmax_log=None):
     for j, (c, g_raw) in enumerate(zip(ctxs, g_raws)):
         g = _f32c(g_raw)
         gs.append(g)
-        # (the producer's by-product: the word of the plnerf_quad_bwd launch that wrote exactly this buffer)
-        am = next((v for ptr, v in (absmax_log or ()) if ptr == g.data_ptr()), None)
+        # (the producer's by-product: the word of the plnerf_quad_bwd launch that wrote exactly this buffer -- and nothing has
+        # written to it since: if `raw` ever gets a second consumer, autograd accumulates the second gradient INTO the first
+        # one's buffer (same pointer, version counter bumped), and the maximum of the first alone would understate the scale
+        # of the sum; the absmax pass then runs instead.  ADVICE r05)
+        am = next((v for t, ver, v in (absmax_log or ())
+                   if t.data_ptr() == g.data_ptr() and t.numel() == g.numel() and t._version == ver), None)
         absmax.append(am if (am is not None and c.beta == 0.0 and g.numel() == 4 * c.n_rows) else None)
         wss.append(torch.empty(L.lib().plnerf_mlp_bwd_workspace_bytes(c.n_rows, c.prec) // 4, device=dev, dtype=torch.float32))
         grads, full = _grad_buffer(c, dev, block=None if block is None else block[offs[j]:offs[j] + sizes[j]])

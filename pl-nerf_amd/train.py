@@ -154,12 +154,16 @@ class TrainStep:
     renders it or N ranks render a shard each.  `counter_rng=False` restores torch.rand."""
 
     def __init__(self, args, render_kwargs_train, optimizer, optimizer_coarse, start=0, distributed=None, seed=0,
-                 counter_rng=True, range_check_every=100):
+                 counter_rng=True, range_check_every=100, pipeline=None):
         """The step runs on ONE stream in the reference's order: render, loss, backward, both optimizers.  (Rounds 3-4
         also carried two-stream schedules -- the coarse network's chain beside the fine pass, and across step boundaries;
         bit-identical, measured +1.4 % / -0.8 % with twice the step jitter, profiles/r04_pipeline_ab.txt -- removed in
         round 5: the forward kernels and the weight-gradient kernel each fill a CU on their own, so two kernels "overlap"
         only by taking CUs from each other.)"""
+        if pipeline is not None:      # (rounds 3-4's schedule argument: a caller written against them keeps working)
+            import warnings
+            warnings.warn("TrainStep(pipeline=...) is ignored: the two-stream schedules were removed in round 5 (one stream, "
+                          "the reference's order)", DeprecationWarning, stacklevel=2)
         self.args = args
         self.kw = render_kwargs_train
         self.optimizer = optimizer
@@ -182,6 +186,7 @@ class TrainStep:
         # mode (_merged_backward_ok); anything else goes through torch.autograd.backward as before.  PLNERF_MERGED_BWD=0 in
         # the environment switches it off (A/B measurements).
         self.merged_backward = os.environ.get("PLNERF_MERGED_BWD", "1") != "0"
+        self.merged_steps = 0      # steps that took the merged backward (the rest went through torch.autograd.backward)
         self.bucket = None
         if distributed and self.world > 1:
             # replicas must start from the same weights (create_nerf initialises from each process's own RNG, and a
@@ -191,6 +196,9 @@ class TrainStep:
             dp.broadcast_optimizer_state([self.optimizer, self.optimizer_coarse])      # (moments, step counts)
             self.global_step = dp.broadcast_scalar(self.global_step, device=next(self.nets[0].parameters()).device)
             self.bucket = dp.GradientBucket(self.nets)
+
+    def drain(self):
+        """No-op (rounds 3-4: waited for the side streams' work in flight; everything is on the caller's stream now)."""
 
     def learning_rate(self):
         decay_rate, decay_steps = 0.1, self.args.lrate_decay * 1000
@@ -268,6 +276,7 @@ class TrainStep:
             loss, psnr = loss4[0], loss4[3]
             if tape is not None and rgb0 is not None and merged_backward_ok(tape, self.nets):
                 backward_merged(tape, self.nets, (rgb, rgb0), (g_rgb, g_rgb0), self.bucket)
+                self.merged_steps += 1
             else:
                 torch.autograd.backward((rgb,) if rgb0 is None else (rgb, rgb0),
                                         (g_rgb,) if rgb0 is None else (g_rgb, g_rgb0))

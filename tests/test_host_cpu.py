@@ -725,6 +725,30 @@ def test_bench_spawns_its_own_ranks(built, n):
     rk = out["ranks"]
     assert rk["ms_per_step"]["min"] <= rk["ms_per_step"]["max"] and rk["allreduce_exposed_ms_max_over_ranks"] > 0
     assert "NOT a measurement" in out["metric"]
+    # launch hygiene: every self-launched rank runs with a bounded OpenMP / intra-op thread count (the logical
+    # CPUs shared out over the ranks, at most 8) instead of one thread per CPU per rank, and reports how long its host needed
+    # to ENQUEUE a step -- what tells a slow launch loop from an exposed collective on the first multi-GPU run
+    import bench
+    assert rk["omp_num_threads"] == bench.rank_threads(n) and 1 <= rk["omp_num_threads"] <= 8
+    assert 0 < rk["host_ms_per_step"]["min"] <= rk["host_ms_per_step"]["max"] <= rk["ms_per_step"]["max"] * 1.001
+
+
+def test_bench_rank_pinning_is_silent_without_topology(built, monkeypatch):
+    """bench.pin_rank: binds a rank to the cores of its GPU's NUMA node when the KFD topology says which (read from sysfs), and
+    does nothing -- silently -- when it cannot be read (this container: no /sys/class/kfd).  The affinity mask only ever
+    shrinks to a subset of the current one."""
+    import bench
+    before = os.sched_getaffinity(0)
+    try:
+        info = bench.pin_rank(0, 8)
+        after = os.sched_getaffinity(0)
+        assert after <= before and len(after) >= 1
+        assert info["omp_num_threads"] >= 1
+        if bench.gpu_numa_node(0) is None:
+            assert after == before and info["numa_node"] is None
+        assert bench.pin_rank(0, 1)["numa_node"] is None          # a single rank is never pinned
+    finally:
+        os.sched_setaffinity(0, before)
 
 
 def test_bench_launcher_refuses_without_devices_and_propagates_failures(built):
