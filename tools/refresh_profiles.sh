@@ -1,9 +1,9 @@
 #!/bin/bash
-# One gpurun call that regenerates round 5's evidence from the working tree:
-#   gpurun --timeout 3000 -- 'COMMIT=<git rev-parse --short HEAD> bash tools/refresh_profiles_r05.sh'
-# then, in the build container: copy gpurun_out/r05p/* over the matching profiles/r05_* files.
+# One gpurun call that regenerates a round's evidence from the working tree:
+#   gpurun --timeout 3000 -- 'ROUND=r06 COMMIT=<git rev-parse --short HEAD> bash tools/refresh_profiles.sh'
+# then, in the build container:  for f in gpurun_out/r06p/*; do cp $f profiles/r06_$(basename $f); done
 R=${GRAFT_REPO_ROOT:-/root/repo}
-out=$R/gpurun_out/r05p
+out=$R/gpurun_out/${ROUND:-r06}p
 mkdir -p $out
 cd $R
 echo "${COMMIT:-unknown}" > $out/commit.txt
