@@ -714,7 +714,8 @@ def main(argv=None):
         flop_exec = FWD_FLOP_PER_ROW_EXECUTED["h16" if h16 else "fp32"]
         ach_exec = rows_fine * flop_exec / (fwd_ms * 1e-3) / 1e12 if fwd_ms else None
         issued = (ach_exec * MFMA_PER_PRODUCT[a.precision]) if ach_exec else None
-        sustained = mfma_sustained_tflops() if (h16 and world == 1) else None
+        # (not under --no-extra-legs: the profiling runs of tools/ use that flag, and a 0.2 s MFMA stream would head their kernel stats)
+        sustained = mfma_sustained_tflops() if (h16 and world == 1 and not a.no_extra_legs) else None
         took_merged = bool(merged_steps) and merged_steps >= a.warmup + a.steps
         bytes_per_row = FWD_TRAIN_BYTES_PER_ROW["h16" if h16 else "fp32"]
         ach_gbs = rows_fine * bytes_per_row / (fwd_ms * 1e-3) / 1e9 if fwd_ms else None
