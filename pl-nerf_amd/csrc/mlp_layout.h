@@ -208,7 +208,8 @@ constexpr int PART_PE0 = PART_VMAIN + HV * W;                  // L0:  [256][64]
 constexpr int PART_PE5 = PART_PE0 + W * PE_K;                  // L5 encoding part: [256][64]
 constexpr int PART_VDIR = PART_PE5 + W * PE_K;                 // view layer direction part [128][32]
 constexpr int PART_BIAS = PART_VDIR + HV * DPE_K;              // b0..b7, bf: 9 x 256, bv: 128
-constexpr int PART_PER_SPLIT = PART_BIAS + 9 * W + HV;
+constexpr int PART_SIGMA = PART_BIAS + 9 * W + HV;             // alpha_linear.weight [256] (tiled half planes: the view job's idle waves sum it, mlp_wgrad.hip)
+constexpr int PART_PER_SPLIT = PART_SIGMA + W;
 constexpr int MAX_SPLITS = 128;
 constexpr int HEAD_PART = 648;               // per-workgroup partial of the sigma/rgb heads
 #ifndef PLNERF_MAX_HEAD_WGS

@@ -49,6 +49,8 @@ struct WJob {
     int b_tiled;      // half planes: B is in SV_LAYOUT_TILED (mlp_layout.h) instead of row-major
     const void* B2;   // view job of the tiled layout only (else nullptr): the direction-encoding plane (32 wide, tiled) --
     int part2_off;    //   dz_view^T dpe rides on the job's four idle waves instead of re-reading dz_view in a thin job
+    const float* g_raw;       // the same job (round 6): the upstream gradient [n_rows][4] and the launch scale's word -- the job's B operand
+    const unsigned* gmax;     //   IS h7, so the idle waves also sum alpha_linear.weight's gradient g_sigma^T h7 (PART_SIGMA): h7 is read once per step
 };
 constexpr int MAX_WTILES = 20;
 struct WgradArgs {
@@ -228,6 +230,20 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
     static_assert(!X2 || (O == HV && I == W && TILED && !DEEP), "the second B operand rides on the view job's idle waves");
     constexpr int I2 = DPE_K, B2_CT = 4 * I2, B2_CHUNKS = SROWS * I2 / 8, B2_BLOCK = SROWS * 8 + TRB_PAD;
     _Float16* lds2 = lds + (size_t)4 * SPLANE;
+    // ... and (round 6) the sigma head: a third "A" operand of which only column 0 lives, g_sigma under the launch scale -- the
+    // stage's LDS image is [row][4 halves] = {g_sigma, 0, 0, 0} (+ 8 zero bytes every lane whose fragment columns are not 0..3 reads)
+    constexpr int G_STAGE = SROWS * 4 + 4;                  // halves per buffer (the zero quad at the end)
+    _Float16* lds3 = lds2 + (size_t)2 * 4 * B2_BLOCK;
+    float g_scale = 1.0f;
+    if constexpr (X2) {
+        const float gm = __uint_as_float(*job.gmax);       // (written by the gradient chain's launch, or the absmax pass, before this one)
+        if (gm > 0.0f && gm < __builtin_inff()) {
+            int e;
+            (void)frexpf(gm, &e);
+            g_scale = ldexpf(1.0f, (int)DZH_TARGET_EXP - e);
+        }
+        g_scale = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(g_scale)));      // (uniform: a scalar register)
+    }
     const _Float16* B2g = (const _Float16*)job.B2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int q2 = tid % B2_CHUNKS, b2_row = (q2 / B2_CT) * 32 + (q2 & 31), b2_col = (q2 % B2_CT) >> 5;
@@ -258,7 +274,7 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
     }
     const int last_tile = (a.n_rows + 31) / 32 - 1;      // the last tile that holds a real row
     const bool b_owner = tid < B_THREADS;
-    struct Set { wh8 a[SA]; wh8 b[SB]; wh8 b2; };
+    struct Set { wh8 a[SA]; wh8 b[SB]; wh8 b2; float g; };
     Set s0, s1;      // (s1 only in the DEEP variant)
     // bias partial = column sums of the dz stage.  Row-major A: a thread's chunks share one chunk column.  Tiled A: its
     // chunks alternate between two piece blocks (q and q + 512: blocks pb and pb + 16), one set of sums each.
@@ -270,27 +286,32 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
     const wh8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     // (the zeroing select lives in stash, not here: a consumer right behind the load would put the new stage's
     // latency back in front of this stage's MFMAs)
+    // (plain loads: non-temporal ones -- the Gate A probe's consumers reached 6.7 TB/s with them -- measured +0.7 % on the step
+    // here, backward 2.94 -> 2.98 ms, profiles/r06_sigma_fold_ab.txt's lib:wgNT legs)
+#define WG_LD(p) (*(p))
     auto fetch = [&](Set& s, const int m) {
         const int last = m_end - 1;
 #pragma unroll
         for (int j = 0; j < SA; ++j) {
             if (ATILED)     // (m is a multiple of 32; a tile past the plane re-reads the last one and is zeroed in stash)
-                s.a[j] = *reinterpret_cast<const wh8*>(
-                    Ag + ((size_t)min((m >> 5) + (a_row[j] >> 5), last_tile) * 1024 + a_col[j] * 32 + (a_row[j] & 31)) * 8);
+                s.a[j] = WG_LD(reinterpret_cast<const wh8*>(
+                    Ag + ((size_t)min((m >> 5) + (a_row[j] >> 5), last_tile) * 1024 + a_col[j] * 32 + (a_row[j] & 31)) * 8));
             else
-                s.a[j] = *reinterpret_cast<const wh8*>(Ag + (size_t)min(m + a_row[j], last) * O + a_col[j]);
+                s.a[j] = WG_LD(reinterpret_cast<const wh8*>(Ag + (size_t)min(m + a_row[j], last) * O + a_col[j]));
         }
 #pragma unroll
         for (int j = 0; j < SB; ++j) {
             if (TILED)      // (m is a multiple of 64: a stage is two whole tiles; a tile past the plane re-reads the last one)
-                s.b[j] = *reinterpret_cast<const wh8*>(
-                    Bg + ((size_t)min((m >> 5) + (b_row[j] >> 5), last_tile) * B_CT + b_col[j] * 32 + (b_row[j] & 31)) * 8);
+                s.b[j] = WG_LD(reinterpret_cast<const wh8*>(
+                    Bg + ((size_t)min((m >> 5) + (b_row[j] >> 5), last_tile) * B_CT + b_col[j] * 32 + (b_row[j] & 31)) * 8));
             else
-                s.b[j] = *reinterpret_cast<const wh8*>(Bg + (size_t)min(m + b_row[j], last) * I + b_col[j]);
+                s.b[j] = WG_LD(reinterpret_cast<const wh8*>(Bg + (size_t)min(m + b_row[j], last) * I + b_col[j]));
         }
-        if constexpr (X2)      // (every thread, like B: threads past the chunk count reload a neighbour's -- static load counts)
-            s.b2 = *reinterpret_cast<const wh8*>(
-                B2g + ((size_t)min((m >> 5) + (b2_row >> 5), last_tile) * B2_CT + b2_col * 32 + (b2_row & 31)) * 8);
+        if constexpr (X2) {    // (every thread, like B: threads past the chunk count reload a neighbour's -- static load counts)
+            s.b2 = WG_LD(reinterpret_cast<const wh8*>(
+                B2g + ((size_t)min((m >> 5) + (b2_row >> 5), last_tile) * B2_CT + b2_col * 32 + (b2_row & 31)) * 8));
+            s.g = job.g_raw[4 * (size_t)min(m + (tid & (SROWS - 1)), last) + 3];
+        }
     };
     auto stash = [&](const Set& s, const int buf, const int m) {
         _Float16* A0 = lds + (size_t)buf * 2 * SPLANE;
@@ -314,6 +335,12 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
         if constexpr (X2) {
             if (tid < B2_CHUNKS)
                 *reinterpret_cast<wh8*>(lds2 + (size_t)(buf * 4 + b2_col) * B2_BLOCK + b2_row * 8) = m + b2_row < m_end ? s.b2 : zero8;
+            if (tid < SROWS) {
+                typedef _Float16 wh4 __attribute__((ext_vector_type(4)));
+                const float gs = m + tid < m_end ? __builtin_amdgcn_fmed3f(s.g * g_scale, -H16_MAX, H16_MAX) : 0.0f;
+                const wh4 q = {(_Float16)gs, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+                *reinterpret_cast<wh4*>(lds3 + (size_t)buf * G_STAGE + tid * 4) = q;
+            }
         }
     };
     f32x16 acc[NO][NI];
@@ -322,11 +349,31 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
         if (!live) {
             if constexpr (X2) {      // waves 4..7: output tile (wave - 4) of dz_view^T dpe, in acc[0][0] (theirs is otherwise unused)
                 const _Float16* A0 = lds + (size_t)buf * 2 * SPLANE;
+                const _Float16* B0 = A0 + SPLANE;
                 const _Float16* B2s = lds2 + (size_t)buf * 4 * B2_BLOCK;
+                const _Float16* G0 = lds3 + (size_t)buf * G_STAGE;
 #pragma unroll
-                for (int k = 0; k < KST; ++k)
+                for (int k = 0; k < KST; ++k) {
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tr_frag(A0 + k * TR_PLANE, lane, 32 * (wave - 4)),
                                                                        tr_frag_tiled(B2s, SROWS, k, lane, 0), acc[0][0], 0, 0, 0);
+                    // ... and two 32-column tiles of g_sigma^T h7 (row 0 of the tile lives): the fragment of the one-column operand
+                    // (g_lane / g_step: the lane's quad in the stage image, or the zero quad for lanes whose fragment columns are not 0..3)
+                    // (addresses rebuilt per k-step from an opaque copy of the lane id: kept across the stage loop they cost the
+                    // kernel the registers it does not have -- 256 VGPR and 56 bytes of scratch in the first form)
+                    typedef __attribute__((address_space(3))) v4s16* lds_v4;
+                    int ln = lane;
+                    asm volatile("" : "+v"(ln));
+                    const bool col0 = (ln & 0x13) == 0;                       // fragment columns 16 (gam & 1) + 4 (lam & 3) .. + 3 are 0..3
+                    const int quad = col0 ? (TR_ROWS * k + 8 * (ln >> 5) + ((ln & 15) >> 2)) * 4 : SROWS * 4;
+                    const _Float16* gp = G0 + quad;
+                    union { v4s16 h[2]; wh8 v; } gf;
+                    gf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)gp);
+                    gf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(gp + (col0 ? 16 : 0)));
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        acc[0][1 + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf.v, tr_frag_tiled(B0, SROWS, k, lane, 32 * (2 * (wave - 4) + t)),
+                                                                               acc[0][1 + t], 0, 0, 0);
+                }
             }
             return;
         }
@@ -399,6 +446,10 @@ __device__ __forceinline__ void wgrad_half_body(const WgradArgs& a, const WJob& 
             float* c2 = part + job.part2_off;
 #pragma unroll
             for (int r = 0; r < 16; ++r) c2[(size_t)(32 * (wave - 4) + frag_row(r, lane)) * I2 + (lane & 31)] = acc[0][0][r];
+            if (lane < 32) {      // row 0 of the sigma tiles = register 0 of lanes 0..31
+#pragma unroll
+                for (int t = 0; t < 2; ++t) part[PART_SIGMA + 32 * (2 * (wave - 4) + t) + lane] = acc[0][1 + t][0];
+            }
         }
     }
     if (job.bias_off >= 0) {
@@ -470,6 +521,7 @@ struct HeadArgs {
     int n_rows, rows_per_wg;
     float* part;  // [n_wg][HEAD_PART]
     int tiled;    // half planes in SV_LAYOUT_TILED (rows_per_wg is then a multiple of 32)
+    int skip_alpha;   // dW_alpha comes from the main launch's view job (PART_SIGMA): h7 is not read here
 };
 
 template <typename PT>
@@ -499,7 +551,9 @@ __global__ __launch_bounds__(256) void wgrad_head_kernel(HeadArgs2<PT> p) {
     // Tiled half planes (mlp_layout.h): a 16-byte piece = 8 features {4 g + 0..3, 8 + 4 g + 0..3} + 32 j + 16 f of one row,
     // 32 rows of a piece block contiguous.  Thread = (piece block, row class): eight lanes read one 128-byte line.
     const bool tiled = sizeof(PT) == 2 && a.tiled;
-    {   // dW_alpha[c] = sum_m g_sigma[m] h7[m][c]
+    if (a.skip_alpha) {      // (uniform)
+        for (int r = 0; r < R7; ++r) acc7[r][tid] = 0.0f;
+    } else {   // dW_alpha[c] = sum_m g_sigma[m] h7[m][c]
         const int c = tiled ? tid / R7 : tid % T7, r = tiled ? tid % R7 : tid / T7;
         float w[VEC];
 #pragma unroll
@@ -701,6 +755,7 @@ struct ReduceArgs {
     float* status_out;      // nullptr, or where this launch leaves (float)(*status != 0): the tail of the caller's flat gradient
     int enc_tiled;          // the encoding planes were tiled (mlp_layout.h): column c of the thin jobs' results = channel sv_enc_channel(c);
                             // the view layer's direction columns then come from the MAIN launch's row ranges (its view job)
+    int sig_main;           // alpha_linear.weight's gradient comes from the main launch's view job (PART_SIGMA), not from the head partials
     float* gred;            // 16-bit modes (composed view layer, mlp_layout.h): the view job's 128 x 256 result is G = dz_view^T h7 and goes
                             // here with s = the job's bias sums behind it (compose_grads turns them into the factors' gradients);
                             // nullptr: fp32 mode, the reference's two layers
@@ -726,7 +781,7 @@ __global__ void wgrad_reduce_kernel(ReduceArgs2 p) {
         for (int w = lane; w < a.n_head; w += 64) s += a.head_part[(size_t)w * HEAD_PART + h];
         s = wave_sum(s);
         if (lane != 0) return;
-        if (h < 256) a.G.p[P_WA][h] = s;
+        if (h < 256) { if (!a.sig_main) a.G.p[P_WA][h] = s; }
         else if (h < 640) a.G.p[P_WR][h - 256] = s;
         else if (h == 640) a.G.p[P_BA][0] = s;
         else a.G.p[P_BR][h - 641] = s;
@@ -737,6 +792,7 @@ __global__ void wgrad_reduce_kernel(ReduceArgs2 p) {
     const bool thin = (idx >= PART_PE0 && idx < (a.enc_tiled ? PART_VDIR : PART_BIAS)) || (idx >= PART_BIAS && idx < PART_BIAS + W);
     // composed view layer: the feature layer's job and bias slots are not used
     if (a.gred && ((idx >= PART_MAIN + 7 * W * W && idx < PART_VMAIN) || (idx >= PART_BIAS + 8 * W && idx < PART_BIAS + 9 * W))) return;
+    if (idx >= PART_SIGMA && !a.sig_main) return;
     const int ns = thin ? a.splits_thin : a.splits;
     float s = 0.0f;
     {   // a batch's loads all in flight before its first add (one dependent load per add held the kernel at 33 us;
@@ -780,6 +836,8 @@ __global__ void wgrad_reduce_kernel(ReduceArgs2 p) {
     } else if (idx < PART_BIAS) {
         const int r = idx - PART_VDIR, o = r >> 5, i = a.enc_tiled ? sv_enc_channel(r & 31, true) : (r & 31);
         if (i < a.G.dir_ch) a.G.p[P_WV][o * (W + a.G.dir_ch) + W + i] = s;
+    } else if (idx >= PART_SIGMA) {
+        a.G.p[P_WA][idx - PART_SIGMA] = s;
     } else {
         const int r = idx - PART_BIAS;
         if (r < 8 * W) a.G.p[2 * (r >> 8) + 1][r & 255] = s;
@@ -961,7 +1019,7 @@ int plan_job(const plnerf::impl::WgradJob& jb, bool h16, int cap_main, int cap_t
         WJob& jv = a.jobs[8];
         jv.A = dzv_plane; jv.lda = HV; jv.B = splane(h16 ? 7 : SV_FEAT); jv.ldb = W; jv.O = HV; jv.I = W;
         jv.part_off = PART_VMAIN; jv.bias_off = PART_BIAS + 9 * W; jv.b_tiled = tiled;
-        if (tiled) { jv.B2 = dpe_plane; jv.part2_off = PART_VDIR; }      // (the direction columns on the job's idle waves)
+        if (tiled) { jv.B2 = dpe_plane; jv.part2_off = PART_VDIR; jv.g_raw = jb.g_raw; jv.gmax = jb.gmax; }      // (the direction columns and the sigma head on the job's idle waves)
         a.tile_job[nt] = 8; a.tile_o0[nt++] = 0;
         a.n_rows = n_rows; a.rows_per_split = rps; a.part = part;
         P.main_args = a; P.nt = nt;
@@ -990,6 +1048,7 @@ int plan_job(const plnerf::impl::WgradJob& jb, bool h16, int cap_main, int cap_t
         a.gmax = h16 ? jb.gmax : nullptr;
         a.status = jb.status; a.status_out = jb.status_out;
         a.enc_tiled = tiled;
+        a.sig_main = tiled;
         a.gred = h16 ? jb.gred : nullptr;
         if (h16 && (!jb.gred || !jb.cb)) return PLNERF_EINVAL;
         a.G.xyz_ch = jb.xyz_ch; a.G.dir_ch = jb.dir_ch;
@@ -1033,7 +1092,7 @@ int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dzv, co
     PLNERF_CHECK_LAUNCH();
     HeadArgs2<float> h{};
     h.n[0] = h.n[1] = HeadArgs<float>{g_raw, (const float*)P.main_args.jobs[7].B, (const float*)((const unsigned char*)saved + (size_t)SV_HV_OFF * (size_t)n_rows * sizeof(float)),
-                                      n_rows, P.rows_per_head_wg, P.head_part, 0};
+                                      n_rows, P.rows_per_head_wg, P.head_part, 0, 0};
     h.wgs0 = P.n_head;
     hipLaunchKernelGGL(wgrad_head_kernel<float>, dim3(P.n_head), dim3(256), 0, st, h);
     PLNERF_CHECK_LAUNCH();
@@ -1065,8 +1124,9 @@ int wgrad_h16_multi(int n, const WgradJob* jobs, hipStream_t st) {
     }
     const size_t lds = (size_t)2 * 2 * TR_STEPS * TR_PLANE * sizeof(_Float16);
     {
-        // (+ the view job's second B operand, two buffers of four piece blocks)
-        const size_t lds_main = lds + (size_t)2 * 4 * (TR_ROWS * TR_STEPS * 8 + TRB_PAD) * sizeof(_Float16);
+        // (+ the view job's second B operand, two buffers of four piece blocks, and its one-column sigma operand)
+        const size_t lds_main = lds + (size_t)2 * 4 * (TR_ROWS * TR_STEPS * 8 + TRB_PAD) * sizeof(_Float16) +
+                                (size_t)2 * (TR_ROWS * TR_STEPS * 4 + 4) * sizeof(_Float16);
         WgradArgs2 a{};
         for (int j = 0; j < 2; ++j) a.n[j] = P[j < n ? j : 0].main_args;
         a.splits0 = P[0].splits;
@@ -1092,7 +1152,7 @@ int wgrad_h16_multi(int n, const WgradJob* jobs, hipStream_t st) {
             h.n[j] = HeadArgs<_Float16>{jobs[q].g_raw, (const _Float16*)P[q].main_args.jobs[8].B,      // (h7: the composed view job's B plane)
                                         (const _Float16*)((const unsigned char*)jobs[q].saved + (size_t)SVC_HV_OFF * NS_ * sizeof(_Float16)),
                                         jobs[q].n_rows, P[q].rows_per_head_wg, P[q].head_part,
-                                        jobs[q].saved_layout == SV_LAYOUT_TILED};
+                                        jobs[q].saved_layout == SV_LAYOUT_TILED, jobs[q].saved_layout == SV_LAYOUT_TILED};
         }
         h.wgs0 = P[0].n_head;
         hipLaunchKernelGGL(wgrad_head_kernel<_Float16>, dim3(P[0].n_head + (n == 2 ? P[1].n_head : 0)), dim3(256), 0, st, h);

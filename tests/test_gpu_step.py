@@ -812,8 +812,10 @@ def test_merged_backward_equals_two_backwards(P):
                     scale = float(a.abs().max()) + 1e-30
                     err = float((a - b).abs().max()) / scale
                     worst = max(worst, err)
-                    if name.endswith("bias") or name.startswith("alpha_linear") or name.startswith("rgb_linear"):
-                        assert torch.equal(a, b) or err <= 2e-6, (sizes, k, name, err)      # (column sums: per-range partials, other ranges)
+                    # (column sums: per-range partials, other ranges.  alpha_linear.weight is a split-K MFMA product like the 256-wide
+                    # weights since round 6 -- g_sigma^T h7 on the view job's idle waves -- and takes their bound)
+                    if name.endswith("bias") or name == "alpha_linear.bias" or name.startswith("rgb_linear"):
+                        assert torch.equal(a, b) or err <= 2e-6, (sizes, k, name, err)
                     assert err <= 2e-5, (sizes, k, name, err)
             print(f"merged vs separate backward, rows {sizes}, g_absmax handed in {with_absmax}: worst gradient difference "
                   f"{worst:.2e} of max|g| (fp32 summation order of the split-K partials)")
