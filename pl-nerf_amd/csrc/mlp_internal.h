@@ -29,7 +29,7 @@ int wgrad(const float* g_raw, int n_rows, const void* saved, const void* dz, con
           float* const* grads, int xyz_ch, int dir_ch, bool h16, int saved_layout, const unsigned* status,
           float* status_out, hipStream_t st);
 // The weight-gradient stage of the 16-bit modes for up to MAX_BWD_JOBS networks at once (plnerf_mlp_bwd_multi): the
-// main / thin / head / reduce launches each cover every job -- the one round of 252 (255) workgroups is dealt out over
+// main / thin / head / reduce launches each cover every job -- the one round of 256 (254) workgroups is dealt out over
 // the jobs in proportion to their rows -- instead of running once per network.  One job = what wgrad() takes.
 constexpr int MAX_BWD_JOBS = 2;
 struct WgradJob {

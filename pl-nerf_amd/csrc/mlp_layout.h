@@ -122,7 +122,7 @@ constexpr int SV_FLOATS = SV_DPE_OFF + DPE_K;       // 2528 plane elements per r
 constexpr int SV_MASK_BYTES = 8 * (W / 8) + HV / 8; // 272 B per row
 constexpr int SAVED_PER_ROW = SV_FLOATS + SV_MASK_BYTES / 4;   // fp32 mode: 2596 floats per row
 
-// ---- backward workspace: pre-activation gradients, planes 0..7 = dz0..dz7, 8 = dz_feature,
+// ---- backward workspace (fp32 mode; the 16-bit modes' planes: DZC_* below): pre-activation gradients, planes 0..7 = dz0..dz7, 8 = dz_feature,
 // then dz_view [128] ----------------------------------------------------------------------
 constexpr int DZ_FEAT = 8;
 constexpr int DZ_V_OFF = 9 * W;
@@ -140,7 +140,7 @@ constexpr int DZ_PER_ROW = DZ_V_OFF + HV;    // 2432
 // plane_off(p) * sv_rows(n_rows)), so that the TILED layout below never runs from one plane into the next and every
 // wave of the forward kernel that writes it owns a whole tile (rows past n_rows: padding, written, never read).
 //
-// Layouts of the planes h0..h7, feature (256 wide), hv (128) and -- since round 5 -- the two encoding planes (64 / 32 wide, in
+// Layouts of the planes h0..h7 (256 wide), hv (128) and -- since round 5 -- the two encoding planes (64 / 32 wide, in
 // the register-resident forward's own column order: sv_enc_channel); the relu bits are always row-major:
 //   SV_LAYOUT_ROWS   [row][width]: written by the ping-pong forward (its LDS tile is in this order)
 //   SV_LAYOUT_TILED  32-row tiles in the register-resident forward's own order: tile t = row / 32 holds
@@ -175,8 +175,8 @@ __host__ __device__ constexpr size_t sv_tiled_index(size_t row, int col, int wid
            ((size_t)((((col >> 5) * 2 + ((col >> 4) & 1)) * 2 + ((col >> 2) & 1)) * 32) + (row & 31)) * 8 +
            (size_t)(((col >> 3) & 1) * 4 + (col & 3));
 }
-// The half dz planes (backward workspace): rows padded to the dgrad kernel's 64-row tiles; the 256-wide planes dz0..dz7
-// and dz_feature in the TILED order above (the dgrad kernel's accumulators leave as contiguous KiB fragments, no LDS ->
+// The half dz planes (backward workspace): rows padded to the dgrad kernel's tiles; the 256-wide planes dz0..dz7
+// in the TILED order above (the dgrad kernel's accumulators leave as contiguous KiB fragments, no LDS ->
 // HBM copy pass; the weight-gradient kernels read them as they are), dz_view (128 wide, not an MFMA product) row-major.
 #ifndef PLNERF_BWD_TM
 #define PLNERF_BWD_TM 192     // rows per workgroup tile of the half dgrad kernel (mlp_h16_body.inc)

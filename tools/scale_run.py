@@ -17,6 +17,8 @@ ap.add_argument("--gpus", default="1,2,4,8")
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--warmup", type=int, default=10)
 ap.add_argument("--bench-json", default=None, help="the driver's BENCH_rNN.json (or a bench.py line) to check N = 1 against")
+ap.add_argument("--workload", default="blender_64_128",
+                help="bench.py's workload (depth_128_64 = BASELINE configs[4], the depth-supervised step, an 8-GPU configuration)")
 a = ap.parse_args()
 import torch
 have = torch.cuda.device_count()
@@ -36,14 +38,15 @@ def last_json(text):
 env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
 for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
     env.pop(k, None)
-out = {"what": "training rays/s at N GPUs of one node, weak scaling (4096 rays per GPU), f16x3; tools/scale_run.py",
+out = {"what": f"training rays/s at N GPUs of one node, weak scaling (4096 rays per GPU), f16x3, workload {a.workload}; tools/scale_run.py",
        "visible_devices": have, "runs": {}}
 for n in [int(x) for x in a.gpus.split(",")]:
     if n > have:
         out["runs"][str(n)] = {"skipped": f"needs {n} visible devices, this host has {have}"}
         continue
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", str(a.steps), "--warmup",
-                        str(a.warmup), "--no-extra-legs", "--no-cpu-baseline", "--no-strict-fp32"] + (["--force-dist"] if n == 1 else []),
+                        str(a.warmup), "--workload", a.workload, "--no-extra-legs", "--no-cpu-baseline", "--no-strict-fp32"] +
+                       (["--force-dist"] if n == 1 else []),
                        env=env, text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     line = last_json(r.stdout)
     if r.returncode != 0 or line is None:
