@@ -45,6 +45,7 @@ TRAIN_FLOP_PER_ROW = 3489024    # forward + wgrad + dgrad
 # the reference's layers.  `roofline.frac` prices the algorithmic figure (SURVEY's contract), `frac_executed` this one.
 FWD_FLOP_PER_ROW_EXECUTED = {"fp32": 1186816, "h16": 1186816 - 2 * 65536}
 TRAFFIC_FILE = "r06_traffic.json"   # refreshed per round by tools/pmc_traffic.sh
+PSNR_FILE = "r06_psnr_plain_modes.jsonl"      # tools/psnr_plain_modes.py on the round's kernels (the throughput mode's dB figure)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s HBM3E
 # training forward, algorithmic bytes per row: saved state written + xyz read (12) + raw written (16)
 FWD_TRAIN_BYTES_PER_ROW = {"fp32": 2596 * 4 + 28, "h16": 2272 * 2 + 272 + 28}   # fp32 planes | half planes + relu masks
@@ -638,7 +639,7 @@ def main(argv=None):
                   "what": "plain IEEE-half operands on single MFMAs, forward and backward (raw error 7.5e-4 on the sharpened "
                           "network, tests/test_gpu_modes.py); secondary to the headline"}
             try:
-                for line in open(os.path.join(ROOT, "profiles", "r05_psnr_plain_modes.jsonl")):
+                for line in open(os.path.join(ROOT, "profiles", PSNR_FILE)):
                     d = json.loads(line)
                     if d.get("summary"):
                         g = d["f16"]["gap_db_train"]
@@ -646,7 +647,7 @@ def main(argv=None):
                         tm.update({"psnr_gap_db": g["mean"], "psnr_gap_db_std": g["std"], "psnr_gap_db_seeds": len(g["values"]),
                                    "psnr_noise_floor_db": {"mean": nf["mean"], "std": nf["std"]},
                                    "psnr_gap_tolerance_db": 0.3,
-                                   "psnr_source": "profiles/r05_psnr_plain_modes.jsonl (tools/psnr_plain_modes.py: 2000 steps x 4096 "
+                                   "psnr_source": f"profiles/{PSNR_FILE} (tools/psnr_plain_modes.py: 2000 steps x 4096 "
                                                   "rays x 6 seeds against exact fp32; offline, not measured in this run); bf16: "
                                                   f"{d['bf16']['gap_db_train']['mean']:+.2f} dB (std {d['bf16']['gap_db_train']['std']:.2f})"})
             except Exception:
