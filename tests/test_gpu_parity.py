@@ -466,7 +466,8 @@ def test_c_host_without_torch(P, precision, tmp_path):
         for t in [sd[n] for n in names] + [pts, vd, z, near, far, d, g_rgb, g_depth, g_acc]:
             f.write(t.contiguous().float().numpy().tobytes())
     prec = {"fp32": 0, "f16x3": 3}[precision]      # PLNERF_PREC_*
-    run = subprocess.run([exe, str(prec), str(R), str(S), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")],
+    from plnerf_amd import _lib as L_
+    run = subprocess.run([exe, str(prec), str(R), str(S), str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(L_.FWD_KERNEL)],
                          capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, (run.returncode, run.stderr[-2000:])
     out = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
