@@ -340,6 +340,18 @@ int plnerf_embed_rows(const float* pts, const float* viewdirs, const float* cam,
                       int n_freqs_xyz, int n_freqs_dir, int n_cam, float input_scale, const float* bb_center_host,
                       float bb_scale, float* embedded, plnerf_stream_t stream);
 
+/* A generic dense product on the exact-fp32 MFMA (ABI 600) -- the layers of NeRF shapes the fused MLP entries below are
+ * not compiled for (run_nerf_helpers.py:76-128 builds any netdepth / netwidth / skip list; pl-nerf_amd/generic.py runs
+ * them layer by layer through this call):
+ *   C[M,N] (row stride ldc) = gate(A)[M,K] . B[K,N] (+ bias[N]) (+ C if accumulate) (relu last if relu)
+ * element (i,k) of A at a[i a_row_stride + k a_col_stride], (k,j) of B at b[k b_row_stride + j b_col_stride] (a transposed
+ * view is a stride swap); gate (NULL, or indexed like A): A(i,k) counts only where gate(i,k) > 0 (the ReLU's derivative in
+ * the two backward products); ones_col: B's LAST column (j = N - 1) is not read from memory but taken as all ones (the bias
+ * gradient as an extra column of dW = gate(G)^T [X | 1]).  fp32 accumulation, k ascending: deterministic.  M <= 4,194,240. */
+int plnerf_gemm_f32(const float* a, int64_t a_row_stride, int64_t a_col_stride, const float* b, int64_t b_row_stride,
+                    int64_t b_col_stride, const float* bias, const float* gate, int M, int N, int K, int relu, int accumulate,
+                    int ones_col, float* c, int64_t ldc, plnerf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * The MLP: run_network (run_plnerf.py:78-92) = Embedder (run_nerf_helpers.py:24-54) +
  * NeRF.forward (:105-128), fused: positional encoding -> 8x256 trunk with skip ->

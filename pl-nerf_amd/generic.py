@@ -1,0 +1,90 @@
+"""NeRF shapes outside the compiled trunk, layer by layer on the HIP path.
+
+The reference's `NeRF` (run_nerf_helpers.py:76-128) builds any netdepth / netwidth / skip list / encoding width
+(flags run_plnerf.py:784-825).  The fused kernels serve the trunk every shipped configuration uses and what maps onto it
+exactly (nerf.NeRF.param_list); a network that does not -- netwidth > 256, netdepth > 8, several live skips, multires > 10,
+multires_views > 4 -- runs here: every nn.Linear as ONE exact-fp32 MFMA product (plnerf_gemm_f32: bias and ReLU in its
+epilogue), its backward as two more (the ReLU's derivative gated into their first operand, the bias gradient as an extra
+column of the weight gradient), the concatenations as torch.cat (autograd splits their gradients), the positional encoding
+as plnerf_embed_rows.  Unfused -- every layer's activations make a round trip through HBM -- and fp32 whatever `precision`
+says: a correct native route for shapes no shipped configuration uses, several times slower per row than the fused
+kernels.  No CPU fallback here either."""
+import torch
+
+from . import _lib as L
+
+
+def _gemm(a, a_rs, a_cs, b, b_rs, b_cs, M, N, K, bias=None, gate=None, relu=False, ones_col=False, out=None):
+    c = torch.empty(M, N, device=a.device, dtype=torch.float32) if out is None else out
+    if M == 0 or N == 0:
+        return c
+    L.check(L.lib().plnerf_gemm_f32(L.dptr(a, "a"), a_rs, a_cs, L.dptr(b, "b"), b_rs, b_cs, L.dptr(bias, "bias"), L.dptr(gate, "gate"),
+                                    M, N, K, int(relu), 0, int(ones_col), L.dptr(c, "c"), c.stride(0), L.stream()), "plnerf_gemm_f32")
+    return c
+
+
+class LinearFn(torch.autograd.Function):
+    """y = relu?(x W^T + b) as one plnerf_gemm_f32; backward: dx = (g * [y > 0]) W, [dW | db] = (g * [y > 0])^T [x | 1]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        x = x.detach().to(torch.float32).contiguous()
+        w = weight.detach().to(torch.float32).contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        if w.shape[1] != K:      # (as F.linear: e.g. a skip after the LAST trunk layer, whose concatenation no head layer takes)
+            raise RuntimeError(f"plnerf_amd: a layer with {w.shape[1]} input features got rows of {K}")
+        # B(k, j) = W[j, k]: row stride 1, column stride K
+        y = _gemm(x, K, 1, w, 1, K, M, N, K, bias=bias.detach().to(torch.float32).contiguous(), relu=relu)
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y = ctx.saved_tensors
+        g = g.to(torch.float32).contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        gx = gwb = None
+        if ctx.needs_input_grad[0]:
+            # dx[M, K] = gate(g)[M, N] . W[N, K]
+            gx = _gemm(g, N, 1, w, K, 1, M, K, N, gate=y)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            # [dW | db][N, K + 1] = gate(g)^T[N, M] . [x | 1][M, K + 1]: A(i = n, k = m) = g[m, n]
+            gwb = _gemm(g, 1, N, x, K, 1, N, K + 1, M, gate=y, ones_col=True)
+        gw = gwb[:, :K].contiguous() if gwb is not None and ctx.needs_input_grad[1] else None
+        gb = gwb[:, K].contiguous() if gwb is not None and ctx.needs_input_grad[2] else None
+        return gx, gw, gb, None
+
+
+def linear(x, layer, relu):
+    if not x.is_cuda:
+        raise RuntimeError(f"plnerf_amd: the generic NeRF route got a tensor on {x.device}; the HIP path needs a GPU tensor "
+                           "(there is no CPU fallback)")
+    return LinearFn.apply(x, layer.weight, layer.bias, relu)
+
+
+def forward(net, flat):
+    """NeRF.forward (run_nerf_helpers.py:105-128; the depth-supervised variant's camera columns and softplus density,
+    depth_supervised_exps/model/run_nerf_helpers.py:164-205) on embedded rows `flat` [N, input_ch + view_ch], any shape."""
+    input_pts, input_views = flat[:, :net.input_ch], flat[:, net.input_ch:net.input_ch + net.view_ch]
+    h = input_pts
+    for i, layer in enumerate(net.pts_linears):
+        h = linear(h, layer, True)
+        if i in net.skips:
+            h = torch.cat([input_pts, h], -1)
+    if net.use_viewdirs:
+        alpha = linear(h, net.alpha_linear, False)
+        feature = linear(h, net.feature_linear, False)
+        hv = torch.cat([feature, input_views], -1)
+        for layer in net.views_linears:
+            hv = linear(hv, layer, True)
+        rgb = linear(hv, net.rgb_linear, False)
+        if net.density_activation == "softplus":
+            alpha = torch.nn.functional.softplus(alpha, beta=10)
+        return torch.cat([rgb, alpha], -1)
+    out = linear(h, net.output_linear, False)
+    if net.density_activation == "softplus":
+        out = torch.cat([out[:, :3], torch.nn.functional.softplus(out[:, 3:4], beta=10), out[:, 4:]], -1)
+    return out

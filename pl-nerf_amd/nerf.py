@@ -337,11 +337,15 @@ class NeRF(nn.Module):
         """x [..., input_ch + input_ch_views + input_ch_cam] embedded rows (the reference module's signature).  `cam`
         (extension): the camera code the caller has repeated into the last input_ch_cam columns of every row, when it
         is to receive a gradient (functional.MlpFn); x itself carries none."""
-        self._require_supported()
         lead = x.shape[:-1]
         flat = x.reshape(-1, x.shape[-1])
         if flat.shape[-1] != self.input_ch + self.view_ch:
             raise ValueError(f"NeRF.forward expects {self.input_ch + self.view_ch} embedded channels, got {flat.shape[-1]}")
+        if not self.is_supported():      # a shape outside the compiled trunk: layer by layer (generic.py), exact fp32
+            from . import generic
+            if cam is not None and cam.requires_grad:
+                raise NotImplementedError("plnerf_amd: a trainable camera code needs the fused route (a supported trunk)")
+            return generic.forward(self, flat).reshape(*lead, -1)
         if not self.use_viewdirs:      # the kernels' direction channels: zeros (their weights are zero as well)
             flat = torch.cat([flat[:, :self.input_ch], flat.new_zeros(flat.shape[0], self.hip_view_ch)], -1)
         out = MlpFn.apply(None, None, flat, cam, 1, self, torch.is_grad_enabled(), *self.param_list())
@@ -352,7 +356,9 @@ class NeRF(nn.Module):
     def query(self, pts, viewdirs, input_scale=1.0):
         """Fused entry: pts [R,S,3], viewdirs [R,3] -> raw [R,S,4]; the encoding gamma(x) = [x, sin / cos(x s 2^k)] with
         s = input_scale happens in the kernel prologue (what run_network does on the hot path)."""
-        self._require_supported()
+        if not self.is_supported():
+            raise NotImplementedError("NeRF.query is the fused entry (in-kernel encoding) of the compiled trunk; a shape outside "
+                                      "it embeds on the caller side and uses forward() -- run_network does")
         if not self.has_fused_encoding():
             raise NotImplementedError("the in-kernel encoding covers 3 + 6 L | 3 + 6 M channels (L <= 10, M <= 4) without "
                                       "a camera code; embed on the caller side and use forward()")

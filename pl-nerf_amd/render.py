@@ -43,6 +43,21 @@ def _fusable(fn, embed_fn, embeddirs_fn, viewdirs):
         embeddirs_fn.is_standard((fn.input_ch_views - 3) // 6)
 
 
+def _hip_embedding(inputs, viewdirs, embed_fn, embeddirs_fn):
+    """The reference's Embedder pair at ANY frequency count up to 16 (multires 11..16 included: outside the fused kernel's
+    in-register encoding) as one plnerf_embed_rows launch: [R * S, 3 + 6 L (+ 3 + 6 M)] rows, the view direction encoded per
+    sample as run_plnerf.py:85-88 does.  None when the encoders are not the standard ones or the rays need a gradient."""
+    if not (inputs.is_cuda and inputs.dim() == 3 and inputs.shape[-1] == 3 and not inputs.requires_grad and
+            isinstance(embed_fn, Embedder) and embed_fn.is_standard(embed_fn.num_freqs) and 0 <= embed_fn.num_freqs <= 16):
+        return None
+    if viewdirs is None:
+        return Fn.embed_rows(inputs, None, None, embed_fn.num_freqs, 0)
+    if not (isinstance(embeddirs_fn, Embedder) and embeddirs_fn.is_standard(embeddirs_fn.num_freqs) and
+            0 <= embeddirs_fn.num_freqs <= 16 and not viewdirs.requires_grad):
+        return None
+    return Fn.embed_rows(inputs, viewdirs, None, embed_fn.num_freqs, embeddirs_fn.num_freqs)
+
+
 def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64):
     """run_plnerf.py:78-92: encode sample positions / view directions and apply the MLP.
 
@@ -64,11 +79,13 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
         per = -(-R // n_launches)
         outs = [fn.query(inputs[i:i + per], None if viewdirs is None else viewdirs[i:i + per]) for i in range(0, R, per)]
         return torch.cat(outs, 0)
-    inputs_flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
-    embedded = embed_fn(inputs_flat)
-    if viewdirs is not None:
-        input_dirs = viewdirs[:, None].expand(inputs.shape)
-        embedded = torch.cat([embedded, embeddirs_fn(torch.reshape(input_dirs, [-1, input_dirs.shape[-1]]))], -1)
+    embedded = _hip_embedding(inputs, viewdirs, embed_fn, embeddirs_fn)
+    if embedded is None:      # (another encoder: its own torch expressions)
+        inputs_flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
+        embedded = embed_fn(inputs_flat)
+        if viewdirs is not None:
+            input_dirs = viewdirs[:, None].expand(inputs.shape)
+            embedded = torch.cat([embedded, embeddirs_fn(torch.reshape(input_dirs, [-1, input_dirs.shape[-1]]))], -1)
     if isinstance(fn, NeRF) and fn.is_supported() and embedded.is_cuda:
         netchunk = max(int(netchunk), MAX_ROWS_PER_LAUNCH)      # rows are independent: fewer, larger launches
     outputs_flat = batchify(fn, netchunk)(embedded)
@@ -369,12 +386,21 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedi
 
 
 def _refuse_unsupported(*nets):
-    """create_nerf's boundary check: a flag combination the compiled trunk cannot express (netdepth > 8, netwidth > 256,
-    multires > 10, ... -- INTEGRATION.md has the table) raises HERE, before any data is loaded, not at the first network
-    query minutes into a reference-style run.  NeRF.__init__ itself stays permissive (same state_dict as the reference)."""
+    """create_nerf's boundary check.  Until round 5 a flag combination the compiled trunk cannot express (netdepth > 8,
+    netwidth > 256, several live skips, multires > 10 -- INTEGRATION.md has the table) raised here; since round 6 such a
+    network is SERVED, layer by layer on exact-fp32 MFMA products (generic.py) -- several times slower per row than the fused
+    kernels and fp32 whatever `precision` says, which the caller is told once, here, before any data is loaded.  What still
+    raises: a shape the reference's own forward cannot run either (a skip after the last trunk layer)."""
+    import warnings
     for net in nets:
-        if net is not None:
-            net._require_supported()
+        if net is None or net.is_supported():
+            continue
+        if any(k == net.D - 1 for k in net.skips):
+            raise NotImplementedError(f"skips={net.skips} concatenates after the last trunk layer (netdepth {net.D}): the "
+                                      "reference's head layers cannot consume that either (run_nerf_helpers.py:109-116)")
+        warnings.warn(f"plnerf_amd: D={net.D}, W={net.W}, skips={net.skips}, input_ch={net.input_ch}, input_ch_views="
+                      f"{net.input_ch_views} is outside the fused kernels' trunk: it runs layer by layer on exact-fp32 "
+                      "products (generic.py), unfused and fp32 in every precision mode", RuntimeWarning, stacklevel=3)
 
 
 def create_nerf(args, device=None):

@@ -34,6 +34,7 @@ int main(void) {
     int (*p_depth_loss)(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, const int*, float, float, float*, float*, float*, float*, void*, plnerf_stream_t) = plnerf_depth_loss;
     int (*p_depth_joint_sums)(const float*, const float*, const float*, int, int, int, int, float, double*, plnerf_stream_t) = plnerf_depth_joint_sums;
     int (*p_embed_rows)(const float*, const float*, const float*, int, int, int, int, int, float, const float*, float, float*, plnerf_stream_t) = plnerf_embed_rows;
+    int (*p_gemm_f32)(const float*, int64_t, int64_t, const float*, int64_t, int64_t, const float*, const float*, int, int, int, int, int, int, float*, int64_t, plnerf_stream_t) = plnerf_gemm_f32;
     size_t (*p_mlp_packed_bytes)(int) = plnerf_mlp_packed_bytes;
     size_t (*p_mlp_status_offset)(int) = plnerf_mlp_status_offset;
     int (*p_mlp_pack_weights)(const float* const*, int, int, int, void*, plnerf_stream_t) = plnerf_mlp_pack_weights;
@@ -51,7 +52,7 @@ int main(void) {
         (const void*)&p_sample_pl_bwd, (const void*)&p_sample_pl_bwd_rays, (const void*)&p_stratified_z, (const void*)&p_ray_points, (const void*)&p_merge_sort,
         (const void*)&p_coarse_epilogue, (const void*)&p_fine_epilogue, (const void*)&p_uniform, (const void*)&p_normal,
         (const void*)&p_select_rays, (const void*)&p_ndc_rays, (const void*)&p_coarse_samples, (const void*)&p_image_loss, (const void*)&p_depth_loss, (const void*)&p_depth_joint_sums,
-        (const void*)&p_embed_rows, (const void*)&p_mlp_packed_bytes, (const void*)&p_mlp_status_offset, (const void*)&p_mlp_pack_weights,
+        (const void*)&p_embed_rows, (const void*)&p_gemm_f32, (const void*)&p_mlp_packed_bytes, (const void*)&p_mlp_status_offset, (const void*)&p_mlp_pack_weights,
         (const void*)&p_mlp_saved_bytes, (const void*)&p_mlp_bwd_workspace_bytes, (const void*)&p_mlp_saved_layout, (const void*)&p_mlp_fwd,
         (const void*)&p_mlp_bwd, (const void*)&p_mlp_bwd_multi, (const void*)&p_mlp_input_grad, (const void*)&p_adam_step,
     };

@@ -771,3 +771,111 @@ def test_half_modes_flag_range_overflow_and_withhold_the_step(P):
         assert float(opt.state[next(net.parameters())]['step']) == 1.0
         sane = list(orc.closed_form_state_dict(2, False).values())
         assert any(not torch.equal(q, p.detach().cpu()) for q, p in zip(sane, net.parameters())), prec
+
+
+# ----------------------------------------------------------------------------- shapes outside the compiled trunk: generic.py
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (37, 5, 3), (64, 64, 16), (65, 63, 17), (300, 257, 129), (1000, 1, 512), (3, 700, 90)])
+def test_generic_gemm_vs_fp64(P, M, N, K):
+    """plnerf_gemm_f32 (exact-fp32 MFMA, 64 x 64 tiles, ragged edges) in every form generic.LinearFn uses it: a layer
+    (x W^T + b, relu), its input gradient (the relu's derivative gated into A), its weight gradient with the bias gradient as
+    the ones column (A transposed by strides), and accumulation -- against fp64 torch."""
+    from plnerf_amd import _lib as L
+    gen = torch.Generator().manual_seed(M * 1000 + N * 10 + K)
+    x, w, b = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen), torch.randn(N, generator=gen)
+
+    def gemm(a, a_rs, a_cs, bm, b_rs, b_cs, m, n, k, bias=None, gate=None, relu=0, acc=0, ones=0, out=None):
+        c = torch.full((m, n), float("nan"), device=dev()) if out is None else out
+        L.check(L.lib().plnerf_gemm_f32(L.dptr(a), a_rs, a_cs, L.dptr(bm), b_rs, b_cs, L.dptr(bias), L.dptr(gate), m, n, k, relu, acc,
+                                        ones, L.dptr(c), c.stride(0), L.stream()), "plnerf_gemm_f32")
+        return c
+    tol = lambda ref: 2e-6 * (1.0 + float(ref.abs().max())) * max(1.0, K ** 0.5 / 4)
+    y_ref = torch.relu(x.double() @ w.double().T + b.double())
+    y = gemm(g(x), K, 1, g(w), 1, K, M, N, K, bias=g(b), relu=1)
+    assert maxdiff(y, y_ref.float()) <= tol(y_ref)
+    gy = torch.randn(M, N, generator=gen)
+    gated = gy.double() * (y_ref > 0)
+    gx = gemm(g(gy), N, 1, g(w), K, 1, M, K, N, gate=y)
+    gx_ref = gated @ w.double()
+    assert maxdiff(gx, gx_ref.float()) <= 2e-6 * (1.0 + float(gx_ref.abs().max())) * max(1.0, N ** 0.5 / 4)
+    gwb = gemm(g(gy), 1, N, g(x), K, 1, N, K + 1, M, gate=y, ones=1)
+    gwb_ref = torch.cat([gated.T @ x.double(), gated.sum(0)[:, None]], 1)
+    assert maxdiff(gwb, gwb_ref.float()) <= 2e-6 * (1.0 + float(gwb_ref.abs().max())) * max(1.0, M ** 0.5 / 4)
+    # accumulate into an existing C, no bias, no relu
+    c0 = torch.randn(M, N, generator=gen)
+    c = gemm(g(x), K, 1, g(w), 1, K, M, N, K, acc=1, out=g(c0).clone())
+    assert maxdiff(c, (c0.double() + x.double() @ w.double().T).float()) <= tol(y_ref)
+
+
+@pytest.mark.parametrize("shape", [dict(D=10, W=512, skips=[4, 7], L=10, Lv=4), dict(D=9, W=320, skips=[4], L=10, Lv=4),
+                                   dict(D=8, W=256, skips=[4], L=12, Lv=6), dict(D=8, W=256, skips=[2], L=10, Lv=4),
+                                   dict(D=12, W=96, skips=[3, 6, 9], L=5, Lv=2), dict(D=9, W=384, skips=[4], L=10, Lv=0)])
+def test_network_shapes_outside_the_trunk_run_layer_by_layer(P, shape):
+    """netdepth > 8, netwidth > 256, several live skips, multires > 10 / multires_views > 4 (run_nerf_helpers.py:76-128
+    builds any of them; run_plnerf.py:784-799): not expressible in the compiled trunk, served by generic.py -- one exact-fp32
+    MFMA product per nn.Linear, plnerf_embed_rows for the encoding.  Through run_network (the reference's call) against the
+    same module in fp64 torch: forward 1e-5, every parameter's gradient 2e-4 of its max |g|."""
+    F = torch.nn.functional
+    D, Wd, skips, Lx, Lv = shape["D"], shape["W"], shape["skips"], shape["L"], shape["Lv"]
+    use_viewdirs = Lv > 0
+    torch.manual_seed(47)
+    emb_fn, in_ch = P.get_embedder(Lx, 0)
+    embd_fn, in_ch_v = P.get_embedder(Lv, 0) if use_viewdirs else (None, 0)
+    net = P.NeRF(D=D, W=Wd, input_ch=in_ch, input_ch_views=in_ch_v, output_ch=5, skips=skips, use_viewdirs=use_viewdirs,
+                 precision="f16x3").to(dev())
+    assert not net.is_supported()
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in net.state_dict().items()}
+    gen = torch.Generator().manual_seed(53)
+    R, S = 7, 41
+    pts = (torch.rand(R, S, 3, generator=gen) * 2 - 1) * 1.5
+    vd = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
+    cot = torch.randn(R, S, 4, generator=gen)
+    x = emb_fn(pts.reshape(-1, 3).double())
+    h = x
+    for i in range(D):
+        h = F.relu(F.linear(h, sd[f"pts_linears.{i}.weight"], sd[f"pts_linears.{i}.bias"]))
+        if i in skips:
+            h = torch.cat([x, h], -1)
+    if use_viewdirs:
+        v = embd_fn(vd[:, None].expand(R, S, 3).reshape(-1, 3).double())
+        sigma = F.linear(h, sd["alpha_linear.weight"], sd["alpha_linear.bias"])
+        feat = F.linear(h, sd["feature_linear.weight"], sd["feature_linear.bias"])
+        hv = F.relu(F.linear(torch.cat([feat, v], -1), sd["views_linears.0.weight"], sd["views_linears.0.bias"]))
+        ref = torch.cat([F.linear(hv, sd["rgb_linear.weight"], sd["rgb_linear.bias"]), sigma], -1)
+    else:
+        ref = F.linear(h, sd["output_linear.weight"], sd["output_linear.bias"])
+    (ref[:, :4] * cot.reshape(-1, 4).double()).sum().backward()
+    out = P.run_network(g(pts), g(vd) if use_viewdirs else None, net, emb_fn, embd_fn)
+    assert out.shape == (R, S, ref.shape[-1])
+    err = maxdiff(out.reshape(-1, ref.shape[-1]), ref.detach().float())
+    (out[..., :4] * g(cot)).sum().backward()
+    worst = 0.0
+    for name, prm in net.named_parameters():
+        r = sd[name].grad
+        if r is None:      # (views_linears without view directions: not on the path, as in the reference)
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0
+            continue
+        worst = max(worst, float((prm.grad.cpu().double() - r).abs().max()) / max(float(r.abs().max()), 1e-9))
+    print(f"generic route D={D} W={Wd} skips={skips} multires={Lx}|{Lv}: forward {err:.2e}, worst gradient error / max|g| {worst:.2e}")
+    assert err <= 1e-5 * (1.0 + float(ref.abs().max())) and worst <= 2e-4
+
+
+def test_create_nerf_trains_a_shape_outside_the_trunk(P):
+    """The reference's route end to end with netwidth 512 / netdepth 10 (create_nerf warns once per network and serves them
+    on the generic route): render, loss, backward, both Adams -- finite, the weights move by an Adam step."""
+    import warnings
+    args = _args(_ckdir(), "f16x3", netdepth=10, netwidth=512, netdepth_fine=9, netwidth_fine=320)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        kw, _, _, grad_vars, opt, opt_c = P.create_nerf(args, device=dev())
+    assert sum("layer by layer" in str(w.message) for w in caught) == 2
+    batch, target = orc.synthetic_blender_rays(48, seed=4)
+    K = [[1111.111, 0, 400], [0, 1111.111, 400], [0, 0, 1]]
+    before = [p.detach().clone() for p in kw["network_fine"].parameters()]
+    rgb, disp, acc, extras = P.render(800, 800, K, chunk=32768, rays=(g(batch[:, 0:3]), g(batch[:, 3:6])), near=2.0,
+                                      far=6.0, retraw=True, **kw)
+    loss = P.img2mse(rgb, g(target)) + P.img2mse(extras["rgb0"], g(target))
+    opt.zero_grad(); opt_c.zero_grad()
+    loss.backward()
+    opt.step(); opt_c.step()
+    moved = max(float((a - b.detach()).abs().max()) for a, b in zip(before, kw["network_fine"].parameters()))
+    assert torch.isfinite(rgb).all() and torch.isfinite(loss) and 0.0 < moved <= 5.5e-4

@@ -221,9 +221,10 @@ def test_other_network_shapes_map_exactly_onto_the_compiled_network(built, shape
 
 
 def test_unsupported_network_shapes_are_refused(built):
-    """What the compiled trunk cannot express is constructible (same state_dict as the reference) and refuses to run:
-    more than three layers behind a skip or more than five before it, two live skips, a skip after the last layer (the
-    reference's own head cannot consume that one either), more than 8 layers, more than 256 units."""
+    """What the compiled trunk cannot express is constructible (same state_dict as the reference) and the FUSED entries
+    refuse it (NeRF.forward then takes the layer-by-layer route, generic.py): more than three layers behind a skip or more
+    than five before it, two live skips, a skip after the last layer (the reference's own head cannot consume that one
+    either), more than 8 layers, more than 256 units."""
     import plnerf_amd as P
     for kw in (dict(D=8, skips=[2]), dict(D=5, skips=[4]), dict(D=9, skips=[4]), dict(D=8, W=512, skips=[4]),
                dict(D=8, skips=[4, 6]), dict(D=8, skips=[5]), dict(D=6, skips=[1, 3])):
@@ -244,37 +245,51 @@ def _nvs_args(tmp, **over):
     return Namespace(**a)
 
 
-# create_nerf flag combinations: (overrides, served?).  INTEGRATION.md's table is this list.
+# create_nerf flag combinations: (overrides, route).  INTEGRATION.md's table is this list.
 CREATE_NERF_SHAPES = [
-    (dict(), True),                                                     # the reference's configs: 8 x 256, skip after 4, 63 | 27
-    (dict(netwidth=128, netwidth_fine=128), True),                      # narrower (zero-padded)
-    (dict(netdepth=6, netdepth_fine=6), True),                          # shallower behind the skip (identity layers)
-    (dict(netdepth=4, netdepth_fine=4), True),                          # the default skips=[4] is not live below 6 layers
-    (dict(use_viewdirs=False), True),                                   # output_linear on the trunk
-    (dict(multires=6, multires_views=2), True),                         # fewer frequency bands (a prefix of 63 | 27)
-    (dict(N_importance=0), True),                                       # one network, two Adams
-    (dict(netdepth=9), False), (dict(netdepth_fine=10), False),         # deeper than the compiled trunk
-    (dict(netwidth=512), False), (dict(netwidth_fine=384), False),      # wider
-    (dict(netwidth=255), False),                                        # odd width (the view layer halves it)
-    (dict(netdepth=5, netdepth_fine=5), False),                         # a skip after the LAST layer: the reference's head cannot consume it either
-    (dict(multires=11), False),                                         # 69 position channels > 64
-    (dict(multires_views=5), False),                                    # 33 direction channels > 32
+    (dict(), "fused"),                                                  # the reference's configs: 8 x 256, skip after 4, 63 | 27
+    (dict(netwidth=128, netwidth_fine=128), "fused"),                   # narrower (zero-padded)
+    (dict(netdepth=6, netdepth_fine=6), "fused"),                       # shallower behind the skip (identity layers)
+    (dict(netdepth=4, netdepth_fine=4), "fused"),                       # the default skips=[4] is not live below 6 layers
+    (dict(use_viewdirs=False), "fused"),                                # output_linear on the trunk
+    (dict(multires=6, multires_views=2), "fused"),                      # fewer frequency bands (a prefix of 63 | 27)
+    (dict(N_importance=0), "fused"),                                    # one network, two Adams
+    (dict(netdepth=9), "generic"), (dict(netdepth_fine=10), "generic"), # deeper than the compiled trunk
+    (dict(netwidth=512), "generic"), (dict(netwidth_fine=384), "generic"),   # wider
+    (dict(netwidth=255), "generic"),                                    # odd width (the view layer halves it)
+    (dict(multires=11), "generic"),                                     # 69 position channels > 64
+    (dict(multires_views=5), "generic"),                                # 33 direction channels > 32
+    (dict(netdepth=5, netdepth_fine=5), "refused"),                     # a skip after the LAST layer: the reference's head cannot consume it either
 ]
 
 
-@pytest.mark.parametrize("over,served", CREATE_NERF_SHAPES, ids=lambda v: "-".join(f"{k}{x}" for k, x in v.items()) if isinstance(v, dict) else str(v))
-def test_create_nerf_refuses_unsupported_shapes_at_the_boundary(built, tmp_path, over, served):
-    """The flags of run_plnerf.py:784-799 that the compiled trunk cannot express raise in create_nerf itself
-    (run_plnerf.py:417-447) -- before a reference-style run has loaded its data -- not at the first network query;
-    NeRF.__init__ stays permissive (same state_dict as the reference: test_unsupported_network_shapes_are_refused)."""
+@pytest.mark.parametrize("over,route", CREATE_NERF_SHAPES, ids=lambda v: "-".join(f"{k}{x}" for k, x in v.items()) if isinstance(v, dict) else str(v))
+def test_create_nerf_routes_every_shape_at_the_boundary(built, tmp_path, over, route):
+    """The flags of run_plnerf.py:784-799: what the compiled trunk expresses runs on the fused kernels; what it cannot
+    (deeper, wider, more encoding channels) is served layer by layer on exact-fp32 MFMA products (generic.py) and create_nerf
+    says so ONCE, at the boundary (run_plnerf.py:417-447), before a reference-style run has loaded its data; what the
+    reference's own forward cannot run raises there.  NeRF.__init__ stays permissive (same state_dict as the reference)."""
+    import warnings
     (tmp_path / "exp").mkdir()
     args = _nvs_args(tmp_path, **over)
-    if served:
-        kw = built.create_nerf(args, device=torch.device("cpu"))[0]
-        assert kw["network_fn"].is_supported() and (kw["network_fine"] is None or kw["network_fine"].is_supported())
-    else:
-        with pytest.raises(NotImplementedError, match="compiled for the reference's trunk"):
+    if route == "refused":
+        with pytest.raises(NotImplementedError, match="after the last trunk layer"):
             built.create_nerf(args, device=torch.device("cpu"))
+        return
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        kw = built.create_nerf(args, device=torch.device("cpu"))[0]
+    nets = [n for n in (kw["network_fn"], kw["network_fine"]) if n is not None]
+    told = [w for w in caught if issubclass(w.category, RuntimeWarning) and "layer by layer" in str(w.message)]
+    if route == "fused":
+        assert all(n.is_supported() for n in nets) and not told
+    else:
+        assert not all(n.is_supported() for n in nets)
+        assert len(told) == sum(not n.is_supported() for n in nets)
+        # (no CPU fallback on this route either)
+        net = next(n for n in nets if not n.is_supported())
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            net(torch.zeros(3, net.input_ch + net.view_ch))
 
 
 def test_no_cpu_fallback(built):
