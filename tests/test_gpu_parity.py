@@ -633,10 +633,18 @@ def test_mlp_embedded_path_grads(P):
 
 
 def test_unsupported_and_cpu_fail_loudly(P):
-    with pytest.raises(NotImplementedError):      # a live skip where the compiled trunk has none (D = 4 itself runs since round 3)
-        P.NeRF(D=8, W=128, input_ch=63, input_ch_views=27, skips=[2], use_viewdirs=True).to(dev())(g(torch.zeros(2, 90)))
-    with pytest.raises(NotImplementedError):
-        P.NeRF(D=8, W=512, input_ch=63, input_ch_views=27, use_viewdirs=True).to(dev())(g(torch.zeros(2, 90)))
+    """The FUSED entries refuse a shape outside the compiled trunk (query: the in-kernel encoding; packed_weights) -- since
+    round 6 NeRF.forward serves it layer by layer instead (generic.py; tests/test_gpu_modes.py) -- a shape the reference's own
+    forward cannot run raises, and nothing falls back to the CPU."""
+    for kw in (dict(D=8, W=128, skips=[2]), dict(D=8, W=512)):      # five layers behind a skip; wider than the trunk
+        net = P.NeRF(input_ch=63, input_ch_views=27, use_viewdirs=True, **kw).to(dev())
+        with pytest.raises(NotImplementedError):
+            net.query(g(torch.zeros(2, 3, 3)), g(torch.zeros(2, 3)))
+        with pytest.raises(NotImplementedError):
+            net.packed_weights()
+        assert net(g(torch.zeros(2, 90))).shape == (2, 4)            # (the layer-by-layer route)
+    with pytest.raises(RuntimeError, match="input features"):      # a skip after the LAST trunk layer, as F.linear would
+        P.NeRF(D=5, W=64, input_ch=63, input_ch_views=27, skips=[4], use_viewdirs=True).to(dev())(g(torch.zeros(2, 90)))
     net = P.NeRF(input_ch=63, input_ch_views=27, use_viewdirs=True)     # left on the CPU
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(torch.zeros(2, 90))
