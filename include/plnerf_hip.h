@@ -347,10 +347,13 @@ int plnerf_embed_rows(const float* pts, const float* viewdirs, const float* cam,
  * element (i,k) of A at a[i a_row_stride + k a_col_stride], (k,j) of B at b[k b_row_stride + j b_col_stride] (a transposed
  * view is a stride swap); gate (NULL, or indexed like A): A(i,k) counts only where gate(i,k) > 0 (the ReLU's derivative in
  * the two backward products); ones_col: B's LAST column (j = N - 1) is not read from memory but taken as all ones (the bias
- * gradient as an extra column of dW = gate(G)^T [X | 1]).  fp32 accumulation, k ascending: deterministic.  M <= 4,194,240. */
+ * gradient as an extra column of dW = gate(G)^T [X | 1]).  fp32 accumulation, k ascending: deterministic.  M <= 4,194,240.
+ * k_splits > 1 (a product with few output tiles and a long k, i.e. a weight gradient): the k range is dealt out over up to
+ * k_splits workgroups per tile, partial products in `partials` (k_splits * M * N floats, caller-owned), added in order by a
+ * second launch; k_splits <= 1: partials may be NULL. */
 int plnerf_gemm_f32(const float* a, int64_t a_row_stride, int64_t a_col_stride, const float* b, int64_t b_row_stride,
                     int64_t b_col_stride, const float* bias, const float* gate, int M, int N, int K, int relu, int accumulate,
-                    int ones_col, float* c, int64_t ldc, plnerf_stream_t stream);
+                    int ones_col, float* c, int64_t ldc, int k_splits, float* partials, plnerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * The MLP: run_network (run_plnerf.py:78-92) = Embedder (run_nerf_helpers.py:24-54) +

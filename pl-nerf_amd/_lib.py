@@ -66,7 +66,7 @@ SIGNATURES = {
     "plnerf_embed_rows": (c_i, [c_f] * 3 + [c_i] * 5 + [ctypes.c_float, ctypes.POINTER(ctypes.c_float), ctypes.c_float,
                                 c_f, c_s]),
     "plnerf_gemm_f32": (c_i, [c_f, ctypes.c_int64, ctypes.c_int64, c_f, ctypes.c_int64, ctypes.c_int64, c_f, c_f] + [c_i] * 6 +
-                        [c_f, ctypes.c_int64, c_s]),
+                        [c_f, ctypes.c_int64, c_i, c_f, c_s]),
     "plnerf_mlp_packed_bytes": (ctypes.c_size_t, [c_i]),
     "plnerf_mlp_pack_weights": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_i, c_i, c_i, c_f, c_s]),
     "plnerf_mlp_input_grad": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_i, c_i, c_i, c_i, c_f, c_f, c_s]),

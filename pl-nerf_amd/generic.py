@@ -18,8 +18,14 @@ def _gemm(a, a_rs, a_cs, b, b_rs, b_cs, M, N, K, bias=None, gate=None, relu=Fals
     c = torch.empty(M, N, device=a.device, dtype=torch.float32) if out is None else out
     if M == 0 or N == 0:
         return c
+    # a product with few 64 x 64 output tiles and a long k (a weight gradient: k = the rows): deal k out so that ~1000
+    # workgroups share it (64 of them walking 262,144 rows each measured 430 ms per backward at 8 x 512)
+    tiles = -(-M // 64) * -(-N // 64)
+    splits = max(1, min(1024 // tiles, K // 512)) if tiles < 256 else 1
+    partials = torch.empty(splits * M * N, device=a.device, dtype=torch.float32) if splits > 1 else None
     L.check(L.lib().plnerf_gemm_f32(L.dptr(a, "a"), a_rs, a_cs, L.dptr(b, "b"), b_rs, b_cs, L.dptr(bias, "bias"), L.dptr(gate, "gate"),
-                                    M, N, K, int(relu), 0, int(ones_col), L.dptr(c, "c"), c.stride(0), L.stream()), "plnerf_gemm_f32")
+                                    M, N, K, int(relu), 0, int(ones_col), L.dptr(c, "c"), c.stride(0), splits,
+                                    L.dptr(partials, "partials"), L.stream()), "plnerf_gemm_f32")
     return c
 
 

@@ -34,7 +34,7 @@ int main(void) {
     int (*p_depth_loss)(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, const int*, float, float, float*, float*, float*, float*, void*, plnerf_stream_t) = plnerf_depth_loss;
     int (*p_depth_joint_sums)(const float*, const float*, const float*, int, int, int, int, float, double*, plnerf_stream_t) = plnerf_depth_joint_sums;
     int (*p_embed_rows)(const float*, const float*, const float*, int, int, int, int, int, float, const float*, float, float*, plnerf_stream_t) = plnerf_embed_rows;
-    int (*p_gemm_f32)(const float*, int64_t, int64_t, const float*, int64_t, int64_t, const float*, const float*, int, int, int, int, int, int, float*, int64_t, plnerf_stream_t) = plnerf_gemm_f32;
+    int (*p_gemm_f32)(const float*, int64_t, int64_t, const float*, int64_t, int64_t, const float*, const float*, int, int, int, int, int, int, float*, int64_t, int, float*, plnerf_stream_t) = plnerf_gemm_f32;
     size_t (*p_mlp_packed_bytes)(int) = plnerf_mlp_packed_bytes;
     size_t (*p_mlp_status_offset)(int) = plnerf_mlp_status_offset;
     int (*p_mlp_pack_weights)(const float* const*, int, int, int, void*, plnerf_stream_t) = plnerf_mlp_pack_weights;

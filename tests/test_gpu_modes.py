@@ -783,10 +783,11 @@ def test_generic_gemm_vs_fp64(P, M, N, K):
     gen = torch.Generator().manual_seed(M * 1000 + N * 10 + K)
     x, w, b = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen), torch.randn(N, generator=gen)
 
-    def gemm(a, a_rs, a_cs, bm, b_rs, b_cs, m, n, k, bias=None, gate=None, relu=0, acc=0, ones=0, out=None):
+    def gemm(a, a_rs, a_cs, bm, b_rs, b_cs, m, n, k, bias=None, gate=None, relu=0, acc=0, ones=0, out=None, splits=1):
         c = torch.full((m, n), float("nan"), device=dev()) if out is None else out
+        part = torch.full((splits * m * n,), float("nan"), device=dev()) if splits > 1 else None
         L.check(L.lib().plnerf_gemm_f32(L.dptr(a), a_rs, a_cs, L.dptr(bm), b_rs, b_cs, L.dptr(bias), L.dptr(gate), m, n, k, relu, acc,
-                                        ones, L.dptr(c), c.stride(0), L.stream()), "plnerf_gemm_f32")
+                                        ones, L.dptr(c), c.stride(0), splits, L.dptr(part), L.stream()), "plnerf_gemm_f32")
         return c
     tol = lambda ref: 2e-6 * (1.0 + float(ref.abs().max())) * max(1.0, K ** 0.5 / 4)
     y_ref = torch.relu(x.double() @ w.double().T + b.double())
@@ -800,6 +801,14 @@ def test_generic_gemm_vs_fp64(P, M, N, K):
     gwb = gemm(g(gy), 1, N, g(x), K, 1, N, K + 1, M, gate=y, ones=1)
     gwb_ref = torch.cat([gated.T @ x.double(), gated.sum(0)[:, None]], 1)
     assert maxdiff(gwb, gwb_ref.float()) <= 2e-6 * (1.0 + float(gwb_ref.abs().max())) * max(1.0, M ** 0.5 / 4)
+    # the same with the k range (here: the rows) dealt out over several workgroups per tile and summed in order: more ranges
+    # than 16-deep stages must not leave an unwritten partial in the sum (NaN-filled above)
+    for splits in (2, 7, 64):
+        gwb_s = gemm(g(gy), 1, N, g(x), K, 1, N, K + 1, M, gate=y, ones=1, splits=splits)
+        assert torch.isfinite(gwb_s).all(), splits
+        assert maxdiff(gwb_s, gwb_ref.float()) <= 2e-6 * (1.0 + float(gwb_ref.abs().max())) * max(1.0, M ** 0.5 / 4), splits
+    y_s = gemm(g(x), K, 1, g(w), 1, K, M, N, K, bias=g(b), relu=1, splits=3)
+    assert maxdiff(y_s, y_ref.float()) <= tol(y_ref)
     # accumulate into an existing C, no bias, no relu
     c0 = torch.randn(M, N, generator=gen)
     c = gemm(g(x), K, 1, g(w), 1, K, M, N, K, acc=1, out=g(c0).clone())
