@@ -350,7 +350,10 @@ def gpu_numa_node(local_rank):
     try:
         gpus = []
         for node in sorted(os.listdir(base), key=int):
-            props = dict(l.split()[:2] for l in open(os.path.join(base, node, "properties")) if len(l.split()) >= 2)
+            try:      # (a container that is handed some of the node's GPUs may not read the others' entries: they are not its ranks')
+                props = dict(l.split()[:2] for l in open(os.path.join(base, node, "properties")) if len(l.split()) >= 2)
+            except OSError:
+                continue
             if int(props.get("simd_count", "0")) > 0:
                 gpus.append(props)
         domain, loc = int(gpus[local_rank]["domain"]), int(gpus[local_rank]["location_id"])
