@@ -503,7 +503,8 @@ def create_nerf(args, scene_render_params=None, device=None):
                            bb_center=box[0], bb_scale=box[1], netchunk=getattr(args, "netchunk", 1024 * 64))
     # (optim.FlatAdam on the GPU: one launch per network's gradient buffer)
     half_range = device.type == "cuda" and getattr(args, "precision", "fp32") in L.GUARDED_PRECISIONS
-    extra = {"guards": [n for n in (model, model_fine) if n is not None]} if half_range else {}
+    guarded = [n for n in (model, model_fine) if n is not None and n.is_supported()]      # (the layer-by-layer route is fp32: no word)
+    extra = {"guards": guarded} if (half_range and guarded) else {}
     optimizer = (FlatAdam if device.type == "cuda" else torch.optim.Adam)(params=grad_vars, lr=args.lrate,
                                                                            betas=(0.9, 0.999), **extra)
     start = 0
