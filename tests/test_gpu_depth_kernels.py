@@ -412,3 +412,37 @@ def test_depth_step_with_merged_backward_equals_autograd_order(P, golden):
     # (Adam moves every weight by ~lr = 5e-4 per step whatever its gradient's size: an entry whose gradient is ~0 -- and this
     # loss runs through the sampler's ill-conditioned closed form -- may flip sign under another summation order: 2 lr)
     assert worst <= 1.1e-3, worst
+
+
+def test_depth_variant_on_a_shape_outside_the_trunk(P, golden):
+    """The depth-supervised variant with netwidth 320 (outside the fused kernels' trunk): its run_network (pi-scaled encoding by
+    plnerf_embed_rows, softplus density) goes layer by layer (generic.py) -- against the oracle's restatement of
+    model/run_nerf_helpers.py:181-205, which reads its widths off the weights -- and one clipped training step runs."""
+    import warnings
+    from test_gpu_modes import _depth_args
+    from plnerf_amd import depth as Dp
+    gd = golden("g8b_depth_variant_128_64")
+    args = _depth_args(gd, "f16x3")
+    args.netwidth = args.netwidth_fine = 320
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        kw, _, _, grad_vars, opt = Dp.create_nerf(args, device=dev())
+    assert sum("layer by layer" in str(w.message) for w in caught) == 2
+    net = kw["network_fn"]
+    assert not net.is_supported()
+    gen = torch.Generator().manual_seed(77)
+    pts = (torch.rand(9, 33, 3, generator=gen) * 2 - 1) * 0.9
+    vd = torch.nn.functional.normalize(torch.randn(9, 3, generator=gen), dim=-1)
+    with torch.no_grad():
+        raw = kw["network_query_fn"](g(pts), g(vd), torch.tensor((), device=dev()), net)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    ref = orc.query_network_depth(sd, pts, vd)
+    assert_close(raw, ref, what="depth variant, netwidth 320, layer by layer")
+    R = 96
+    batch, target = orc.synthetic_blender_rays(R, seed=9)
+    target_h = 2.0 + 4.0 * torch.rand(3, R, 1, generator=gen)
+    step = Dp.DepthTrainStep(args, kw, opt, grad_vars, distributed=False, seed=2)
+    before = [p.detach().clone() for p in grad_vars]
+    loss, img_loss, sc, _ = step(g(batch), g(target), g(target_h))
+    moved = max(float((a - b.detach()).abs().max()) for a, b in zip(before, grad_vars))
+    assert torch.isfinite(loss) and torch.isfinite(sc) and 0.0 < moved <= 5.5e-4
