@@ -71,26 +71,28 @@ def linear(x, layer, relu):
     return LinearFn.apply(x, layer.weight, layer.bias, relu)
 
 
-def forward(net, flat):
-    """NeRF.forward (run_nerf_helpers.py:105-128; the depth-supervised variant's camera columns and softplus density,
-    depth_supervised_exps/model/run_nerf_helpers.py:164-205) on embedded rows `flat` [N, input_ch + view_ch], any shape."""
-    input_pts, input_views = flat[:, :net.input_ch], flat[:, net.input_ch:net.input_ch + net.view_ch]
-    h = input_pts
-    for i, layer in enumerate(net.pts_linears):
-        h = linear(h, layer, True)
-        if i in net.skips:
-            h = torch.cat([input_pts, h], -1)
-    if net.use_viewdirs:
-        alpha = linear(h, net.alpha_linear, False)
-        feature = linear(h, net.feature_linear, False)
-        hv = torch.cat([feature, input_views], -1)
-        for layer in net.views_linears:
-            hv = linear(hv, layer, True)
-        rgb = linear(hv, net.rgb_linear, False)
-        if net.density_activation == "softplus":
-            alpha = torch.nn.functional.softplus(alpha, beta=10)
-        return torch.cat([rgb, alpha], -1)
-    out = linear(h, net.output_linear, False)
-    if net.density_activation == "softplus":
-        out = torch.cat([out[:, :3], torch.nn.functional.softplus(out[:, 3:4], beta=10), out[:, 4:]], -1)
-    return out
+def _softplus_density(cols, at):
+    """F.softplus(beta=10) on column `at` (the depth-supervised variant's density channel, model/run_nerf_helpers.py:200)."""
+    return torch.cat([cols[:, :at], torch.nn.functional.softplus(cols[:, at:at + 1], beta=10), cols[:, at + 1:]], 1)
+
+
+def forward(net, rows):
+    """The module's layers applied to embedded rows [N, input_ch + view_ch], whatever its shape: what NeRF.forward computes
+    (run_nerf_helpers.py:105-128; with the camera columns and the softplus density of the depth-supervised variant,
+    depth_supervised_exps/model/run_nerf_helpers.py:164-205), every nn.Linear through LinearFn."""
+    xyz = rows[:, :net.input_ch]
+    act = xyz
+    for depth, fc in enumerate(net.pts_linears):
+        act = linear(act, fc, relu=True)
+        if depth in net.skips:      # the encoding re-enters BEHIND this layer, its channels first (:111-112)
+            act = torch.cat((xyz, act), 1)
+    if not net.use_viewdirs:
+        out = linear(act, net.output_linear, relu=False)
+        return _softplus_density(out, 3) if net.density_activation == "softplus" else out
+    sigma = linear(act, net.alpha_linear, relu=False)
+    side = rows[:, net.input_ch:net.input_ch + net.view_ch]      # direction encoding (+ camera code)
+    head = torch.cat((linear(act, net.feature_linear, relu=False), side), 1)
+    for fc in net.views_linears:
+        head = linear(head, fc, relu=True)
+    out = torch.cat((linear(head, net.rgb_linear, relu=False), sigma), 1)
+    return _softplus_density(out, 3) if net.density_activation == "softplus" else out
