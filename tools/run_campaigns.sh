@@ -6,6 +6,11 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$R/gpurun_out/${ROUND:-r06}_fuzz; mkdir -p $out
 declare -A CASES=([render_rays]=300 [render_rays_depth]=150 [train_step]=120 [train_step_depth]=120 [mlp]=200 [render_chunks]=60 [samplers]=400 [quadrature]=400 [glue]=300)
 declare -A SEED=([render_rays]=7 [render_rays_depth]=11 [train_step]=5 [train_step_depth]=31 [mlp]=21 [render_chunks]=17 [samplers]=3 [quadrature]=9 [glue]=13)
+if [ "${SEEDSET:-1}" = 2 ]; then      # round 5's second pass: other seeds, more cases (profiles/r05_fuzz_second_seeds.json)
+  CASES=([render_rays]=600 [render_rays_depth]=300 [train_step]=200 [train_step_depth]=200 [mlp]=400 [render_chunks]=90 [samplers]=600 [quadrature]=600 [glue]=400)
+  SEED=([render_rays]=8 [render_rays_depth]=12 [train_step]=6 [train_step_depth]=32 [mlp]=22 [render_chunks]=18 [samplers]=4 [quadrature]=10 [glue]=14)
+  out=${out}_seeds2; mkdir -p $out
+fi
 tools=${@:-render_rays render_rays_depth train_step train_step_depth mlp render_chunks}
 cd $R
 for t in $tools; do
