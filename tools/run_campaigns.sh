@@ -11,6 +11,11 @@ if [ "${SEEDSET:-1}" = 2 ]; then      # round 5's second pass: other seeds, more
   SEED=([render_rays]=8 [render_rays_depth]=12 [train_step]=6 [train_step_depth]=32 [mlp]=22 [render_chunks]=18 [samplers]=4 [quadrature]=10 [glue]=14)
   out=${out}_seeds2; mkdir -p $out
 fi
+if [ "${SEEDSET:-1}" = 3 ]; then      # round 6's third pass (second session): third seeds at the second pass's counts
+  CASES=([render_rays]=600 [render_rays_depth]=300 [train_step]=200 [train_step_depth]=200 [mlp]=400 [render_chunks]=90 [samplers]=600 [quadrature]=600 [glue]=400)
+  SEED=([render_rays]=108 [render_rays_depth]=112 [train_step]=106 [train_step_depth]=132 [mlp]=122 [render_chunks]=118 [samplers]=104 [quadrature]=110 [glue]=114)
+  out=${out}_seeds3; mkdir -p $out
+fi
 tools=${@:-render_rays render_rays_depth train_step train_step_depth mlp render_chunks}
 cd $R
 for t in $tools; do
