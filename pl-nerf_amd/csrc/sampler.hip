@@ -308,56 +308,96 @@ struct SamplePlBwdArgs {
 // Gradient of invert_segment (above) with respect to (T0, tau0, tau1), following torch's rules for
 // the guards: max(eps, x) passes the gradient to x where x > eps, clamp(t, lo, hi) where
 // lo <= t <= hi.  Returns false when nothing flows (clamped).
+// Which side of every guard the sample stands on is decided on the fp32 values the FORWARD computed (the same expressions, op
+// for op) -- the gradient belongs to the branch the forward took.  The derivative's VALUE is then evaluated in fp64 from the
+// same fp32 inputs: d t / d tau_r is the difference of two terms of size t / (tau_r - tau_l) that cancel to first order
+// (-t / den against (L / den) ln / (span sqrt(disc))), and in fp32 -- the reference's autograd, and this kernel until round 6's
+// third-seed campaign -- that leaves 1e-4 ... 1e-2 of max |g| on intervals with a small density difference (tools/fuzz_train_step_depth.py:
+// the kernel 3-7x further from fp64 than torch's fp32 chain on 4 of 400 steps, 3x nearer on others).  A few dozen fp64 operations per
+// hypothesis, R x N hypotheses per step: nothing next to the networks.  The result is the exact gradient of the forward's fp32 values
+// to fp32 rounding (1e-7 of max |g|), where the reference's own is its fp32 chain's.
 __device__ __forceinline__ bool invert_segment_grad(float s0, float s1, float T0, float tau0, float tau1,
                                                     float u, float eps, bool rising, float g, float& g_T0,
                                                     float& g_a, float& g_b) {
-    const float L = s1 - s0;
-    const float m0 = tmax(eps, T0);
-    const float ratio = (1.0f - u) / m0;
-    const float ln_term = -logf(tmax(eps, ratio));
-    const float span = tmax(eps, L);
-    const float disc = tau0 * tau0 + (rising ? (2.0f * (tau1 - tau0) * ln_term) / span
-                                             : -((2.0f * (tau0 - tau1) * ln_term) / span));
-    const float sq = sqrtf(tmax(eps, disc));
-    const float diff = rising ? tau1 - tau0 : tau0 - tau1;
-    const float den = tmax(eps, diff);
-    const float t_raw = rising ? (L * (-tau0 + sq)) / den : (L * (tau0 - sq)) / den;
     g_T0 = g_a = g_b = 0.0f;
-    if (!(t_raw >= eps && t_raw <= L)) return false;
-    const float sgn = rising ? 1.0f : -1.0f;
-    const float g_sq = g * sgn * (L / den);
-    const float g_disc = disc > eps ? g_sq * (0.5f / sq) : 0.0f;
-    const float g_den = diff > eps ? -g * (t_raw / den) : 0.0f;      // d t_raw / d den = -t_raw / den
+    bool disc_live, diff_live, ln_live;
+    {   // the forward's fp32 values: predicates only
+        const float L = s1 - s0;
+        const float ratio = (1.0f - u) / tmax(eps, T0);
+        const float ln_term = -logf(tmax(eps, ratio));
+        const float span = tmax(eps, L);
+        const float disc = tau0 * tau0 + (rising ? (2.0f * (tau1 - tau0) * ln_term) / span
+                                                 : -((2.0f * (tau0 - tau1) * ln_term) / span));
+        const float sq = sqrtf(tmax(eps, disc));
+        const float diff = rising ? tau1 - tau0 : tau0 - tau1;
+        const float den = tmax(eps, diff);
+        const float t_raw = rising ? (L * (-tau0 + sq)) / den : (L * (tau0 - sq)) / den;
+        if (!(t_raw >= eps && t_raw <= L)) return false;
+        disc_live = disc > eps;
+        diff_live = diff > eps;
+        ln_live = ratio > eps && T0 > eps;
+    }
+    const double e = (double)eps, a0 = (double)tau0, a1 = (double)tau1, gd = (double)g;
+    const double L = (double)s1 - (double)s0;
+    const double m0 = (double)T0 > e ? (double)T0 : e;
+    const double ratio = (1.0 - (double)u) / m0;
+    const double ln_term = -log(ratio > e ? ratio : e);
+    const double span = L > e ? L : e;
+    const double diff = rising ? a1 - a0 : a0 - a1;
+    const double disc = a0 * a0 + (rising ? (2.0 * (a1 - a0) * ln_term) / span : -((2.0 * (a0 - a1) * ln_term) / span));
+    const double sq = sqrt(disc > e ? disc : e);
+    const double den = diff > e ? diff : e;
+    const double t_raw = rising ? (L * (-a0 + sq)) / den : (L * (a0 - sq)) / den;
+    const double sgn = rising ? 1.0 : -1.0;
+    const double g_sq = gd * sgn * (L / den);
+    const double g_disc = disc_live ? g_sq * (0.5 / sq) : 0.0;
+    const double g_den = diff_live ? -gd * (t_raw / den) : 0.0;      // d t_raw / d den = -t_raw / den
     // direct terms, the denominator (d den / d tau0 = -sgn, d den / d tau1 = +sgn), the discriminant
-    g_a = g * (-sgn) * (L / den) - sgn * g_den + g_disc * (2.0f * tau0 - (2.0f * ln_term) / span);
-    g_b = sgn * g_den + g_disc * ((2.0f * ln_term) / span);
-    const float g_ln = g_disc * ((2.0f * (tau1 - tau0)) / span);
+    g_a = (float)(gd * (-sgn) * (L / den) - sgn * g_den + g_disc * (2.0 * a0 - (2.0 * ln_term) / span));
+    g_b = (float)(sgn * g_den + g_disc * ((2.0 * ln_term) / span));
+    const double g_ln = g_disc * ((2.0 * (a1 - a0)) / span);
     // ln_term = -log(max(eps, (1-u) / max(eps, T0)))
-    g_T0 = (ratio > eps && T0 > eps) ? g_ln / T0 : 0.0f;
+    g_T0 = ln_live ? (float)(g_ln / (double)T0) : 0.0f;
     return true;
 }
 
 // d sample / d (s0, s1) of sample = s0 + clamp(t_raw(L), eps, L), L = s1 - s0, as autograd derives it for the reference
 // (run_nerf_helpers.py:340-361; torch.clamp with a tensor bound: a value inside [eps, L] carries the gradient, beyond L --
 // or when eps > L, where clamp returns its upper bound -- the bound does).  t_raw = L num / den depends on L directly and
-// through the discriminant's 1 / span.
+// through the discriminant's 1 / span.  (Sides of the guards from the forward's fp32 values, the value in fp64: as above.)
 __device__ __forceinline__ void invert_segment_knot_grad(float s0, float s1, float T0, float tau0, float tau1, float u,
                                                          float eps, bool rising, float g, float& g_s0, float& g_s1) {
-    const float L = s1 - s0;
-    const float ln_term = -logf(tmax(eps, (1.0f - u) / tmax(eps, T0)));
-    const float span = tmax(eps, L);
-    const float diff = rising ? tau1 - tau0 : tau0 - tau1;
-    const float q = (2.0f * diff * ln_term) / span;
-    const float disc = rising ? tau0 * tau0 + q : tau0 * tau0 - q;
-    const float sq = sqrtf(tmax(eps, disc));
-    const float den = tmax(eps, diff);
-    const float num = rising ? -tau0 + sq : tau0 - sq;
-    const float t_raw = (L * num) / den;
-    if (eps > L || t_raw > L) { g_s0 = 0.0f; g_s1 = g; return; }      // sample = s0 + (s1 - s0)
-    if (t_raw < eps) { g_s0 = g; g_s1 = 0.0f; return; }               // sample = s0 + eps
-    float dt = num / den;
-    if (disc > eps && L > eps) dt -= (L / den) * ((0.5f / sq) * (q / span));
-    g_s1 = g * dt;
+    bool inner_live;
+    {
+        const float L = s1 - s0;
+        const float ln_term = -logf(tmax(eps, (1.0f - u) / tmax(eps, T0)));
+        const float span = tmax(eps, L);
+        const float diff = rising ? tau1 - tau0 : tau0 - tau1;
+        const float q = (2.0f * diff * ln_term) / span;
+        const float disc = rising ? tau0 * tau0 + q : tau0 * tau0 - q;
+        const float sq = sqrtf(tmax(eps, disc));
+        const float den = tmax(eps, diff);
+        const float num = rising ? -tau0 + sq : tau0 - sq;
+        const float t_raw = (L * num) / den;
+        if (eps > L || t_raw > L) { g_s0 = 0.0f; g_s1 = g; return; }      // sample = s0 + (s1 - s0)
+        if (t_raw < eps) { g_s0 = g; g_s1 = 0.0f; return; }               // sample = s0 + eps
+        inner_live = disc > eps && L > eps;
+    }
+    const double e = (double)eps, a0 = (double)tau0, a1 = (double)tau1;
+    const double L = (double)s1 - (double)s0;
+    const double m0 = (double)T0 > e ? (double)T0 : e;
+    const double ratio = (1.0 - (double)u) / m0;
+    const double ln_term = -log(ratio > e ? ratio : e);
+    const double span = L > e ? L : e;
+    const double diff = rising ? a1 - a0 : a0 - a1;
+    const double q = (2.0 * diff * ln_term) / span;
+    const double disc = rising ? a0 * a0 + q : a0 * a0 - q;
+    const double sq = sqrt(disc > e ? disc : e);
+    const double den = diff > e ? diff : e;
+    const double num = rising ? -a0 + sq : a0 - sq;
+    double dt = num / den;
+    if (inner_live) dt -= (L / den) * ((0.5 / sq) * (q / span));
+    g_s1 = (float)((double)g * dt);
     g_s0 = g - g_s1;
 }
 

@@ -272,6 +272,8 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
             z_vals = perturb_z_vals(z_vals, pytest)
         pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]
     raw = network_query_fn(pts, viewdirs, embedded_cam, network_fn)
+    if tap is not None:
+        tap.update(z_vals0=z_vals, raw0=raw)
 
     def last_stage(raw, z_vals, n, load_u):
         """raw2outputs of the final pass + the depth hypotheses on its weights (:909-934), one launch."""
