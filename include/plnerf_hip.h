@@ -173,7 +173,12 @@ int plnerf_sample_pl(const float* z, const float* weights, const float* tau, con
  * with pw_linear_sample_increasing / _decreasing, :499-519) when `pred_hyp` carries the
  * space-carving loss.  inds [R,N] is the index output of the forward call; g_samples [R,N].
  * Outputs g_tau, g_T [R,S+2] are written (not accumulated); the per-knot sums run in
- * sample order, so the result is deterministic. */
+ * sample order, so the result is deterministic.  Which side of every guard of the closed
+ * form (max(eps, .), the final clamp, the branch threshold) a sample stands on is decided on
+ * the fp32 values the forward computed; the derivative's VALUE -- d t / d tau is the difference
+ * of two terms that cancel to first order -- is evaluated in fp64 from the same fp32 inputs:
+ * the exact gradient of the forward's values to fp32 rounding, where the reference's fp32
+ * autograd sits 1e-5 ... 1e-2 of max |g| from it (LABNOTES R6-13). */
 int plnerf_sample_pl_bwd(const float* z, const float* tau, const float* T, const float* near,
                          const float* far, const float* u, int u_row_stride, const int64_t* inds,
                          const float* g_samples, int R, int S, int N, float zero_tol, float epsilon,

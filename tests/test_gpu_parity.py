@@ -279,6 +279,9 @@ def test_sampler_backward_vs_oracle_autograd(P):
             e_hip, e_orc = rel(a, b64), rel(b32, b64)
             print(f"sampler bwd R={R} S={S} N={N}: {name} err vs fp64 oracle: HIP {e_hip:.3e}, fp32 oracle {e_orc:.3e}")
             assert e_hip <= 2 * e_orc + 1e-5, (name, e_hip, e_orc)
+            # (round 6: the kernel evaluates the cancelling derivative in fp64 from the fp32 inputs -- it is the exact gradient of
+            # the forward's values to fp32 rounding, whatever the fp32 oracle's own distance is; csrc/sampler.hip)
+            assert e_hip <= 2e-6, (name, e_hip, e_orc)      # (measured 7e-9 ... 3e-7; the fp32 oracle 1.5e-6 ... 1.5e-3)
 
         # stage 2: raw -> (rgb, tau, T) -> samples, one loss through both the image and the sampler
         def raw_grad(dt):
