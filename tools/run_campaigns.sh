@@ -16,6 +16,11 @@ if [ "${SEEDSET:-1}" = 3 ]; then      # round 6's third pass (second session): t
   SEED=([render_rays]=108 [render_rays_depth]=112 [train_step]=106 [train_step_depth]=132 [mlp]=122 [render_chunks]=118 [samplers]=104 [quadrature]=110 [glue]=114)
   out=${out}_seeds3; mkdir -p $out
 fi
+if [ "${SEEDSET:-1}" = 4 ]; then      # fourth seeds (round 6, after the stage-wise gradient bounds of tools/grad_stages.py)
+  CASES=([render_rays]=600 [render_rays_depth]=300 [train_step]=200 [train_step_depth]=200 [mlp]=400 [render_chunks]=90 [samplers]=600 [quadrature]=600 [glue]=400)
+  SEED=([render_rays]=208 [render_rays_depth]=212 [train_step]=206 [train_step_depth]=232 [mlp]=222 [render_chunks]=218 [samplers]=204 [quadrature]=210 [glue]=214)
+  out=${out}_seeds4; mkdir -p $out
+fi
 tools=${@:-render_rays render_rays_depth train_step train_step_depth mlp render_chunks}
 cd $R
 for t in $tools; do
