@@ -73,8 +73,19 @@ for case in range(a.cases):
             continue
         x, y = x.detach().cpu(), y.detach()
         if not torch.equal(torch.isnan(x), torch.isnan(y)):
-            bad.append(f"{name}: NaN pattern differs")
-            continue
+            rows = (torch.isnan(x) != torch.isnan(y)).reshape(x.shape[0], -1).any(-1).nonzero().flatten().tolist()
+            acc_h, acc_o = out_h[2].detach().cpu(), out32[2].detach()
+            detail = [(r_, float(acc_h[r_]), float(acc_o[r_])) for r_ in rows[:4]]
+            # disp = 1 / max(1e-10, depth / acc) is 0 / 0 = NaN on a ray whose every alpha is exactly 0, and finite as soon as ONE alpha
+            # is 1 ulp: 1 - exp(-x) at x ~ 3e-8 sits on the rounding midpoint of exp, where two expf implementations inside 1 ulp
+            # disagree (fourth seeds, case 172: one ray of 257,128).  Such rays -- acc below 1e-6 on both sides -- are not a pattern
+            # difference of the kernels.
+            if name == "disp" and all(max(abs(a_), abs(b_)) < 1e-6 for _, a_, b_ in [(r_, float(acc_h[r_]), float(acc_o[r_])) for r_ in rows]):
+                stats["disp_nan_on_rays_with_acc_below_1e-6"] = stats.get("disp_nan_on_rays_with_acc_below_1e-6", 0) + len(rows)
+                x, y = torch.nan_to_num(x, nan=0.0), torch.nan_to_num(y, nan=0.0)
+            else:
+                bad.append(f"{name}: NaN pattern differs on rays {rows[:4]} (acc path / oracle: {detail})")
+                continue
         err = torch.nan_to_num((x.double() - y.double()).abs() / (1.0 + y.double().abs()), nan=0.0, posinf=0.0)
         if name == "disp":      # 1 / max(1e-10, depth / acc): on an (almost) empty ray the quotient of two roundings -- judged where
             err = err[out32[2].detach() > 1e-2]      # the ray holds something (the tests bound it by its propagated error)
