@@ -150,7 +150,10 @@ int plnerf_sample_const(const float* bins, const float* weights, const float* u,
  * path): what autograd derives for sample_pdf_return_u
  * (depth_supervised_exps/model/run_nerf_helpers.py:343-394) when the depth-supervised variant runs
  * in piecewise-constant mode.  inds [R,N] is the forward's index output; g_weights [R,B-1] is
- * written (not accumulated), deterministically. */
+ * written (not accumulated), deterministically.  The derivative's value is formed from the pdf and
+ * cdf in fp64 (from the fp32 weights; which bins count as empty stays the forward's fp32 decision):
+ * 1e-7 of max |g| from fp64 autograd, where the reference's fp32 chain leaves up to 1e-3 on a narrow
+ * bin (c1 - c0 of two roundings). */
 int plnerf_sample_const_bwd(const float* bins, const float* weights, const float* u,
                             int u_row_stride, const int64_t* inds, const float* g_samples, int R,
                             int B, int N, float* g_weights, plnerf_stream_t stream);

@@ -146,19 +146,28 @@ __global__ __launch_bounds__(256) void sample_const_bwd_kernel(SampleConstBwdArg
     int* lo = reinterpret_cast<int*>(g1 + N);   // N
     int* hi = lo + N;                           // N
     float* gc = reinterpret_cast<float*>(hi + N);   // B: g_cdf
+    // the cdf before its rounding to fp32 (round 6): c1 - c0 of two fp32 roundings carries 6e-8 / (c1 - c0) -- 1e-3 of the gradient
+    // on a narrow bin, in the reference's fp32 autograd and in this kernel until then; the derivative's VALUE now comes from these,
+    // which bins count as empty (c1 - c0 < 1e-5) stays the forward's fp32 decision (as plnerf_sample_pl_bwd: LABNOTES R6-13)
+    double* cdf64 = reinterpret_cast<double*>(gc + B);      // B  (4 B + 4 N floats precede it: 8-byte aligned)
     for (int j = lane; j < B; j += 64) bins[j] = a.bins[(size_t)ray * B + j];
     for (int j = lane; j < n; j += 64) wv[j] = a.weights[(size_t)ray * n + j] + 1e-5f;
     __syncthreads();
     const float total = torch_row_sum(wv, n, lane);
-    double carry = 0.0;
+    double total64 = 0.0;      // (the same row in fp64, from the fp32 weights: w + 1e-5 and its sum before any rounding)
+    for (int j = lane; j < n; j += 64) total64 += (double)a.weights[(size_t)ray * n + j] + 1e-5;
+    total64 = wave_sum(total64);
+    double carry = 0.0, carry64 = 0.0;
     for (int base = 0; base < n; base += 64) {
         const int j = base + lane;
         const float pdf = (j < n) ? wv[j] / total : 0.0f;
         const double incl = wave_incl_sum((double)pdf);
-        if (j < n) cdf[j + 1] = (float)(carry + incl);
+        const double incl64 = wave_incl_sum((j < n) ? ((double)a.weights[(size_t)ray * n + j] + 1e-5) / total64 : 0.0);
+        if (j < n) { cdf[j + 1] = (float)(carry + incl); cdf64[j + 1] = carry64 + incl64; }
         carry = carry + __shfl(incl, 63);
+        carry64 = carry64 + __shfl(incl64, 63);
     }
-    if (lane == 0) cdf[0] = 0.0f;
+    if (lane == 0) { cdf[0] = 0.0f; cdf64[0] = 0.0; }
     __syncthreads();
     const float* urow = a.u + (size_t)ray * a.u_row_stride;
     for (int k = lane; k < N; k += 64) {
@@ -170,12 +179,13 @@ __global__ __launch_bounds__(256) void sample_const_bwd_kernel(SampleConstBwdArg
         const float c0 = cdf[below], c1 = cdf[above];
         const float d = c1 - c0;
         const bool active = !(d < 1e-5f);
-        const float denom = active ? d : 1.0f;
-        const float gt = a.g_samples[o] * (bins[above] - bins[below]);
-        const float q = (u - c0) / denom;            // = t
+        const double c0d = cdf64[below];
+        const double denom = active ? cdf64[above] - c0d : 1.0;
+        const double gt = (double)a.g_samples[o] * ((double)bins[above] - (double)bins[below]);
+        const double q = ((double)u - c0d) / denom;            // = t
         // dt/dc0 = -1/denom + [active] t/denom ;  dt/dc1 = -[active] t/denom
-        g0[k] = gt * ((-1.0f / denom) + (active ? q / denom : 0.0f));
-        g1[k] = active ? gt * (-(q / denom)) : 0.0f;
+        g0[k] = (float)(gt * ((-1.0 / denom) + (active ? q / denom : 0.0)));
+        g1[k] = active ? (float)(gt * (-(q / denom))) : 0.0f;
         lo[k] = below; hi[k] = above;
     }
     __syncthreads();
@@ -555,7 +565,7 @@ extern "C" int plnerf_sample_const_bwd(const float* bins, const float* weights, 
     if (R == 0) return PLNERF_OK;
     if (!bins || !weights || !u || !inds || !g_samples || !g_weights) return PLNERF_EINVAL;
     SampleConstBwdArgs a{bins, weights, u, u_row_stride, inds, g_samples, R, B, N, 0, g_weights};
-    a.lds_stride = ((4 * B + 4 * N) + 3) & ~3;
+    a.lds_stride = ((6 * B + 4 * N) + 3) & ~3;      // (+ the fp64 cdf)
     const size_t lds = (size_t)WAVES * a.lds_stride * sizeof(float);
     int rc = set_lds((const void*)sample_const_bwd_kernel, lds);
     if (rc) return rc;

@@ -332,6 +332,9 @@ def test_sample_const_backward_vs_oracle_autograd(P):
         e_hip, e_orc = rel(wh.grad, g64), rel(g32, g64)
         print(f"sample_const bwd R={R} B={B} N={N}: err vs fp64 oracle: HIP {e_hip:.3e}, fp32 oracle {e_orc:.3e}")
         assert e_hip <= 2 * e_orc + 1e-5, (e_hip, e_orc)
+        # (round 6: the kernel forms pdf and cdf in fp64 from the fp32 weights for the derivative's value -- 1e-7 from fp64 autograd,
+        # where the fp32 chain's c1 - c0 leaves up to 1.7e-3 on a narrow bin; csrc/sampler.hip)
+        assert e_hip <= 2e-6, (e_hip, e_orc)
 
 
 @pytest.mark.parametrize("S", [64, 128, 37, 1])
