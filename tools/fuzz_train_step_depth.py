@@ -31,10 +31,12 @@ from tools import grad_stages as GS
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=80)
 ap.add_argument("--seed", type=int, default=31)
+ap.add_argument("--joint", type=float, default=0.0, help="fraction of the cases with is_joint=True (one shared row of u, the loss's min over the hypotheses of the batch mean); drawn from a stream of its own: the other draws of a seed do not move")
 a = ap.parse_args()
 torch.set_num_threads(min(16, os.cpu_count() or 1))
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(a.seed)
+rng_joint = np.random.default_rng(a.seed + 7919)
 F = torch.nn.functional
 TOL = {"fp32": 5e-3, "f16x3": 1e-2}
 W_SC = 0.05
@@ -102,6 +104,7 @@ for case in range(a.cases):
                color_mode=["midpoint", "left"][int(rng.integers(2))], white_bkgd=bool(rng.integers(2)),
                raw_noise_std=float(rng.choice([0.0, 1.0])), perturb=1.0)
     R = int(rng.choice([3, 33, 64, 130]))
+    joint = bool(rng_joint.random() < a.joint)
     batch, target = orc.synthetic_blender_rays(R, seed=13000 + case)
     gen = torch.Generator().manual_seed(13000 + case)
     target_h = 2.0 + 4.0 * torch.rand(3, R, 1, generator=gen)
@@ -112,10 +115,10 @@ for case in range(a.cases):
         tap = {}
         TAPMOD.STAGE_TAP = tap
         try:
-            ret = Dp.render_rays(batch.to(dev), retraw=True, pytest=True, **dict(kw, **cfg))
+            ret = Dp.render_rays(batch.to(dev), retraw=True, pytest=True, is_joint=joint, **dict(kw, **cfg))
         finally:
             TAPMOD.STAGE_TAP = None
-        sc = Dp.compute_space_carving_loss(ret["pred_hyp"], target_h.to(dev))
+        sc = Dp.compute_space_carving_loss(ret["pred_hyp"], target_h.to(dev), is_joint=joint)
         loss = P.img2mse(ret["rgb_map"], target.to(dev)) + W_SC * sc + P.img2mse(ret["rgb0"], target.to(dev))
         ret["raw"].retain_grad(); tap["raw0"].retain_grad(); ret["pred_hyp"].retain_grad()
         loss.backward()
@@ -129,7 +132,7 @@ for case in range(a.cases):
                             depth_variant=True)
         hyp = orc.sample_pdf_reformulation(z_fine, fs["weights"], fs["tau"], fs["T"], near, far, cfg["N_importance"],
                                            u=ret["u"].detach().cpu())[0]
-        ref_loss = torch.mean((fs["rgb_map"] - target) ** 2) + W_SC * orc.compute_space_carving_loss(hyp, target_h) \
+        ref_loss = torch.mean((fs["rgb_map"] - target) ** 2) + W_SC * orc.compute_space_carving_loss(hyp, target_h, is_joint=joint) \
             + torch.mean((ref["rgb0"] - target) ** 2)
         ref_loss.backward()
         bad = []
@@ -156,13 +159,13 @@ for case in range(a.cases):
             if cos < 0.9999:
                 bad.append(f"{tag} cosine {cos:.6f}")
         if bad:
-            info.append({"case": case, "precision": prec, "R": R, "what": bad})
+            info.append({"case": case, "precision": prec, "R": R, "is_joint": joint, "what": bad})
         # ---- the stages, each on the path's own inputs (tools/grad_stages.py): these are the bounds
         vd = batch[:, 8:11]
         staged = []
         g_hyp = ret["pred_hyp"].grad.detach().cpu().double()
         hp = ret["pred_hyp"].detach().cpu().double().requires_grad_(True)
-        (W_SC * orc.compute_space_carving_loss(hp, target_h.double())).backward()
+        (W_SC * orc.compute_space_carving_loss(hp, target_h.double(), is_joint=joint)).backward()
         e_gh = float((g_hyp - hp.grad).abs().max()) / max(float(hp.grad.abs().max()), 1e-30)
         worst[prec]["loss_gradient_at_the_paths_hypotheses"] = max(worst[prec].get("loss_gradient_at_the_paths_hypotheses", 0.0), e_gh)
         if e_gh > 1e-6:
@@ -208,9 +211,9 @@ for case in range(a.cases):
                 staged.append(f"{tag} d loss / d raw: {e_up:.2e} of its maximum (fp32 oracle at the same raw: {e_up32:.2e})")
             staged += [f"{tag} network stage {b}" for b in bad_net]
         if staged:
-            violations.append({"case": case, "precision": prec, "R": R, "cfg": cfg, "what": staged})
+            violations.append({"case": case, "precision": prec, "R": R, "is_joint": joint, "cfg": cfg, "what": staged})
 print(json.dumps({"what": "depth-supervised step: gradient campaign vs the CPU oracle's autograd on identical samples, decisive networks",
-                  "cases": a.cases, "seed": a.seed, "bounds": dict(TOL, upstream=GS.UP_TOL, stages="tools/grad_stages.py"), "worst": worst,
+                  "cases": a.cases, "seed": a.seed, "joint_fraction": a.joint, "bounds": dict(TOL, upstream=GS.UP_TOL, stages="tools/grad_stages.py"), "worst": worst,
                   "violations": violations, "beyond_end_to_end_bounds": info,
                   "rays_exempt_from_the_upstream_stage": {p: f"{exempt[p]} of {rays_seen[p]} (a hypothesis on a switch of the sampler's closed form: tools/grad_stages.py)" for p in TOL}}))
 sys.exit(1 if violations else 0)
