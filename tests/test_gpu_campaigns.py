@@ -12,10 +12,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("tool,cases", [("fuzz_render_rays.py", 12), ("fuzz_render_rays_depth.py", 8), ("fuzz_train_step.py", 8),
-                                        ("fuzz_samplers.py", 40), ("fuzz_quadrature.py", 40), ("fuzz_mlp.py", 24), ("fuzz_glue.py", 30), ("fuzz_render_chunks.py", 6), ("fuzz_train_step_depth.py", 8)])
-def test_campaign(tool, cases):
-    run = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "--cases", str(cases), "--seed", "2026"],
+@pytest.mark.parametrize("tool,cases,extra", [
+    ("fuzz_render_rays.py", 12, ()), ("fuzz_render_rays_depth.py", 8, ()), ("fuzz_train_step.py", 8, ()), ("fuzz_samplers.py", 40, ()),
+    ("fuzz_quadrature.py", 40, ()), ("fuzz_mlp.py", 24, ()), ("fuzz_glue.py", 30, ()), ("fuzz_render_chunks.py", 6, ()),
+    ("fuzz_train_step_depth.py", 8, ()),
+    # (round 6) the depth-supervised step with half of its cases at is_joint=True; both training-step campaigns bound the gradient's
+    # stages on the path's own inputs (tools/grad_stages.py) and report the end-to-end numbers
+    ("fuzz_train_step_depth.py", 8, ("--joint", "0.5"))])
+def test_campaign(tool, cases, extra):
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "--cases", str(cases), "--seed", "2026", *extra],
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert run.stdout.strip(), run.stderr[-2000:]
     out = json.loads(run.stdout.strip().splitlines()[-1])
