@@ -11,20 +11,18 @@ if [ "${SEEDSET:-1}" = 2 ]; then      # round 5's second pass: other seeds, more
   SEED=([render_rays]=8 [render_rays_depth]=12 [train_step]=6 [train_step_depth]=32 [mlp]=22 [render_chunks]=18 [samplers]=4 [quadrature]=10 [glue]=14)
   out=${out}_seeds2; mkdir -p $out
 fi
-if [ "${SEEDSET:-1}" = 3 ]; then      # round 6's third pass (second session): third seeds at the second pass's counts
+if [ "${SEEDSET:-1}" -ge 3 ]; then      # round 6's further passes: the second pass's counts, its seeds + 100 (SEEDSET - 2): 108, 112, ... / 208, 212, ...
   CASES=([render_rays]=600 [render_rays_depth]=300 [train_step]=200 [train_step_depth]=200 [mlp]=400 [render_chunks]=90 [samplers]=600 [quadrature]=600 [glue]=400)
-  SEED=([render_rays]=108 [render_rays_depth]=112 [train_step]=106 [train_step_depth]=132 [mlp]=122 [render_chunks]=118 [samplers]=104 [quadrature]=110 [glue]=114)
-  out=${out}_seeds3; mkdir -p $out
+  o=$(( 100 * (SEEDSET - 2) ))
+  SEED=([render_rays]=$((8 + o)) [render_rays_depth]=$((12 + o)) [train_step]=$((6 + o)) [train_step_depth]=$((32 + o)) [mlp]=$((22 + o)) [render_chunks]=$((18 + o)) [samplers]=$((4 + o)) [quadrature]=$((10 + o)) [glue]=$((14 + o)))
+  out=${out}_seeds${SEEDSET}; mkdir -p $out
 fi
-if [ "${SEEDSET:-1}" = 4 ]; then      # fourth seeds (round 6, after the stage-wise gradient bounds of tools/grad_stages.py)
-  CASES=([render_rays]=600 [render_rays_depth]=300 [train_step]=200 [train_step_depth]=200 [mlp]=400 [render_chunks]=90 [samplers]=600 [quadrature]=600 [glue]=400)
-  SEED=([render_rays]=208 [render_rays_depth]=212 [train_step]=206 [train_step_depth]=232 [mlp]=222 [render_chunks]=218 [samplers]=204 [quadrature]=210 [glue]=214)
-  out=${out}_seeds4; mkdir -p $out
-fi
+declare -A EXTRA=()
+[ "${SEEDSET:-1}" -ge 5 ] && EXTRA[train_step_depth]="--joint 0.5"      # (from the fifth pass on: half of the depth-supervised steps with is_joint=True)
 tools=${@:-render_rays render_rays_depth train_step train_step_depth mlp render_chunks}
 cd $R
 for t in $tools; do
   s=$(date +%s)
-  timeout ${CAMPAIGN_TIMEOUT:-1500} python tools/fuzz_$t.py --cases ${CASES[$t]} --seed ${SEED[$t]} 2> $out/fuzz_$t.err | tail -1 > $out/fuzz_$t.json
+  timeout ${CAMPAIGN_TIMEOUT:-1500} python tools/fuzz_$t.py --cases ${CASES[$t]} --seed ${SEED[$t]} ${EXTRA[$t]} 2> $out/fuzz_$t.err | tail -1 > $out/fuzz_$t.json
   echo "fuzz_$t: rc=${PIPESTATUS[0]} $(( $(date +%s) - s )) s  $(python -c "import json,sys; d=json.load(open('$out/fuzz_$t.json')); print('violations', len(d['violations']))" 2>&1 | tail -1)"
 done
